@@ -1,0 +1,243 @@
+// hipemu -- a tiny CPU emulator of the HIP device programming model (TEST INFRASTRUCTURE).
+//
+// The build container has hipcc but no GPU.  To exercise the *actual kernel sources* of
+// virtex_amd/csrc on CPU, the emulator build puts this directory in front of the include
+// path so that `#include <hip/hip_runtime.h>` resolves here, and compiles the unchanged
+// .hip files as host C++ (clang, for ext_vector_type).  Every HIP thread becomes a fiber;
+// __syncthreads(), wave shuffles and MFMA are implemented as rendezvous points of the
+// block's / wave's fibers, using the gfx950 lane<->element maps documented in
+// /opt/skills/guides/cdna_hip_programming.md section 3.  The product never loads this.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <type_traits>
+
+#define HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)hipemu::dyn_smem();
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+enum { hipMemcpyDeviceToDevice = 3 };
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_ { unsigned x, y, z; };
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+struct ushort4 { unsigned short x, y, z, w; };
+inline float2 make_float2(float a, float b) { return {a, b}; }
+inline float4 make_float4(float a, float b, float c, float d) { return {a, b, c, d}; }
+inline uint2 make_uint2(unsigned a, unsigned b) { return {a, b}; }
+inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return {a, b, c, d}; }
+inline int4 make_int4(int a, int b, int c, int d) { return {a, b, c, d}; }
+
+namespace hipemu {
+struct Fiber;
+struct ThreadCtx {           // one per OS worker thread
+    Fiber* cur = nullptr;
+    uint3_ bid{}, bdim{}, gdim{};
+    char* dyn = nullptr;
+};
+extern thread_local ThreadCtx tls;
+struct Fiber {
+    uint3_ tid;
+    int linear, wave, lane;
+    // scheduler state lives in the runtime
+};
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void block_barrier();
+void* wave_exchange(const void* mine, size_t bytes);  // returns base of 64 slots (stride 64 B)
+inline char* dyn_smem() { return tls.dyn; }
+const uint3_& cur_tid();
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur_tid())
+#define blockIdx (hipemu::tls.bid)
+#define blockDim (hipemu::tls.bdim)
+#define gridDim (hipemu::tls.gdim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
+
+inline void __syncthreads() { hipemu::block_barrier(); }
+inline int __lane_id() { return hipemu::tls.cur->lane; }
+
+// ---- wave cross-lane ops -------------------------------------------------------------
+template <class T> inline T __shfl(T v, int src, int width = 64) {
+    static_assert(sizeof(T) <= 64, "");
+    int lane = hipemu::tls.cur->lane;
+    char* base = (char*)hipemu::wave_exchange(&v, sizeof(T));
+    int s = (lane & ~(width - 1)) + (src & (width - 1));
+    T r; memcpy(&r, base + 64 * s, sizeof(T)); return r;
+}
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
+    int lane = hipemu::tls.cur->lane;
+    char* base = (char*)hipemu::wave_exchange(&v, sizeof(T));
+    int s = lane ^ mask;
+    if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+    T r; memcpy(&r, base + 64 * s, sizeof(T)); return r;
+}
+template <class T> inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    int lane = hipemu::tls.cur->lane;
+    char* base = (char*)hipemu::wave_exchange(&v, sizeof(T));
+    int s = lane + (int)delta;
+    if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+    T r; memcpy(&r, base + 64 * s, sizeof(T)); return r;
+}
+inline unsigned long long __ballot(int pred) {
+    int p = pred != 0;
+    char* base = (char*)hipemu::wave_exchange(&p, sizeof(int));
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) { int q; memcpy(&q, base + 64 * l, 4); if (q) m |= 1ull << l; }
+    return m;
+}
+
+// ---- MFMA (gfx950 lane<->element maps, guide section 3) -------------------------------
+typedef short hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+inline float hipemu_bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+// D(16x16) = A(16x32) B(32x16) + C.  lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15];
+// C/D reg i of lane l = element [4*(l>>4)+i][l&15].
+inline hipemu_f32x4 hipemu_mfma_16x16x32_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x4 c) {
+    struct { hipemu_bf16x8 a, b; } mine{a, b};
+    char* base = (char*)hipemu::wave_exchange(&mine, sizeof(mine));
+    int lane = hipemu::tls.cur->lane, col = lane & 15;
+    hipemu_f32x4 d = c;
+    for (int i = 0; i < 4; ++i) {
+        int row = 4 * (lane >> 4) + i;
+        float acc = c[i];
+        for (int k = 0; k < 32; ++k) {
+            unsigned short av, bv;
+            memcpy(&av, base + 64 * (row + 16 * (k >> 3)) + 2 * (k & 7), 2);
+            memcpy(&bv, base + 64 * (col + 16 * (k >> 3)) + 16 + 2 * (k & 7), 2);
+            acc += hipemu_bf2f(av) * hipemu_bf2f(bv);
+        }
+        d[i] = acc;
+    }
+    return d;
+}
+// D(32x32) = A(32x16) B(16x32) + C. lane l: A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31];
+// C/D reg r of lane l = [(r&3)+8*(r>>2)+4*(l>>5)][l&31].
+inline hipemu_f32x16 hipemu_mfma_32x32x16_bf16(hipemu_bf16x8 a, hipemu_bf16x8 b, hipemu_f32x16 c) {
+    struct { hipemu_bf16x8 a, b; } mine{a, b};
+    char* base = (char*)hipemu::wave_exchange(&mine, sizeof(mine));
+    int lane = hipemu::tls.cur->lane, col = lane & 31;
+    hipemu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            unsigned short av, bv;
+            memcpy(&av, base + 64 * (row + 32 * (k >> 3)) + 2 * (k & 7), 2);
+            memcpy(&bv, base + 64 * (col + 32 * (k >> 3)) + 16 + 2 * (k & 7), 2);
+            acc += hipemu_bf2f(av) * hipemu_bf2f(bv);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+// f32 16x16x4: lane l holds A[l&15][l>>4], B[l>>4][l&15].
+inline hipemu_f32x4 hipemu_mfma_16x16x4_f32(float a, float b, hipemu_f32x4 c) {
+    struct { float a, b; } mine{a, b};
+    char* base = (char*)hipemu::wave_exchange(&mine, sizeof(mine));
+    int lane = hipemu::tls.cur->lane, col = lane & 15;
+    hipemu_f32x4 d = c;
+    for (int i = 0; i < 4; ++i) {
+        int row = 4 * (lane >> 4) + i;
+        float acc = c[i];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, base + 64 * (row + 16 * k), 4);
+            memcpy(&bv, base + 64 * (col + 16 * k) + 4, 4);
+            acc = fmaf(av, bv, acc);
+        }
+        d[i] = acc;
+    }
+    return d;
+}
+// f32 32x32x2: lane l holds A[l&31][l>>5], B[l>>5][l&31].
+inline hipemu_f32x16 hipemu_mfma_32x32x2_f32(float a, float b, hipemu_f32x16 c) {
+    struct { float a, b; } mine{a, b};
+    char* base = (char*)hipemu::wave_exchange(&mine, sizeof(mine));
+    int lane = hipemu::tls.cur->lane, col = lane & 31;
+    hipemu_f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, base + 64 * (row + 32 * k), 4);
+            memcpy(&bv, base + 64 * (col + 32 * k) + 4, 4);
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma_16x16x32_bf16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_32x32x16_bf16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4_f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2_f32(a, b, c)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+
+// ---- atomics (blocks run on several OS threads) ---------------------------------------
+inline float atomicAdd(float* p, float v) {
+    unsigned* ip = (unsigned*)p; unsigned old = __atomic_load_n(ip, __ATOMIC_RELAXED), nw;
+    float f;
+    do { memcpy(&f, &old, 4); f += v; memcpy(&nw, &f, 4); }
+    while (!__atomic_compare_exchange_n(ip, &old, nw, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    memcpy(&f, &old, 4); return f;
+}
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline float atomicMax(float* p, float v) {  // not in HIP for float; helper for tests only
+    unsigned* ip = (unsigned*)p; unsigned old = __atomic_load_n(ip, __ATOMIC_RELAXED), nw; float f;
+    do { memcpy(&f, &old, 4); if (f >= v) break; memcpy(&nw, &v, 4); }
+    while (!__atomic_compare_exchange_n(ip, &old, nw, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return f;
+}
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+// ---- math -----------------------------------------------------------------------------
+inline float __expf(float x) { return expf(x); }
+inline float __logf(float x) { return logf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+template <class T> inline T min(T a, T b) { return a < b ? a : b; }
+template <class T> inline T max(T a, T b) { return a > b ? a : b; }

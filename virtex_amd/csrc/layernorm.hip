@@ -1,0 +1,231 @@
+// Fused residual + dropout + LayerNorm, forward and backward (HBM-bound; one wave64 per row).
+//
+//   z   = x + dropout_p(y)            (y optional: plain LayerNorm when y == nullptr)
+//   out = (z - mean) * rstd * gamma + beta
+//
+// Reference: torch.nn.TransformerDecoderLayer post-norm blocks
+// `x = norm(x + dropout(sublayer(x)))` reached from
+// /root/reference/virtex/modules/textual_heads.py:181-194,270-275 (eps 1e-5).
+// Rows are kept in registers (NV 16-byte vectors per lane), statistics in fp32, two-pass
+// variance like ATen's CPU kernel.
+#include "vtx_common.h"
+
+namespace {
+
+template <class T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean_out,
+    float* __restrict__ rstd_out, int rows, int H, float eps, Dropout drop) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;  // whole wave exits together (row is wave-uniform)
+    const size_t base = (size_t)row * H;
+    Vec16<T> z[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC;
+        if (col < H) {
+            z[i].load(x + base + col);
+            if (y) {
+                Vec16<T> t; t.load(y + base + col);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) z[i].v[j] += drop.apply(t.v[j], base + col + j);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s += z[i].v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) z[i].v[j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC;
+        if (col < H) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const float d = z[i].v[j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC;
+        if (col < H) {
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                o.v[j] = (z[i].v[j] - mean) * rstd * gamma[col + j] + beta[col + j];
+            o.store(out + base + col);
+        }
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// dz = rstd * (g - mean_H(g) - xhat * mean_H(g * xhat)),  g = dout * gamma
+// dy = dropout-mask(dz)  (written only when dy != nullptr)
+// dgamma += sum_rows dout * xhat ; dbeta += sum_rows dout      (fp32 atomics, once per block)
+template <class T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+    const T* __restrict__ dout, T* __restrict__ dz, T* __restrict__ dy,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int H, Dropout drop) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float ag[NV][VEC], ab[NV][VEC];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) ag[i][j] = ab[i][j] = 0.f;
+
+    for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
+        const size_t base = (size_t)row * H;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        Vec16<T> xh[NV], g[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * VEC;
+            if (col < H) {
+                xh[i].load(x + base + col);
+                if (y) {
+                    Vec16<T> t; t.load(y + base + col);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) xh[i].v[j] += drop.apply(t.v[j], base + col + j);
+                }
+                g[i].load(dout + base + col);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float h = (xh[i].v[j] - mean) * rstd;
+                    const float d = g[i].v[j];
+                    ag[i][j] += d * h; ab[i][j] += d;
+                    const float gg = d * gamma[col + j];
+                    xh[i].v[j] = h; g[i].v[j] = gg;
+                    s1 += gg; s2 += gg * h;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * VEC;
+            if (col < H) {
+                Vec16<T> o;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o.v[j] = rstd * (g[i].v[j] - s1 - xh[i].v[j] * s2);
+                o.store(dz + base + col);
+                if (dy) {
+                    Vec16<T> m;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) m.v[j] = drop.apply(o.v[j], base + col + j);
+                    m.store(dy + base + col);
+                }
+            }
+        }
+    }
+    // block-level combine of the 4 waves' column partials through LDS, then one atomic/column
+    __shared__ float red[4][64 * VEC + 1];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) red[wv][lane * VEC + j] = pass ? ab[i][j] : ag[i][j];
+            __syncthreads();
+            if (wv == 0 && col < H) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float t = red[0][lane * VEC + j] + red[1][lane * VEC + j] +
+                                    red[2][lane * VEC + j] + red[3][lane * VEC + j];
+                    atomicAdd((pass ? dbeta : dgamma) + col + j, t);
+                }
+            }
+        }
+    }
+}
+
+template <class T>
+int ln_fwd_t(const void* x, const void* y, const float* gamma, const float* beta, void* out,
+             float* mean, float* rstd, int rows, int H, float eps, Dropout d, hipStream_t st) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int nv = vtx_cdiv(H, 64 * VEC);
+    dim3 grid(vtx_cdiv(rows, 4)), block(256);
+#define VTX_LN_FWD(NV)                                                                          \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)y,    \
+                       gamma, beta, (T*)out, mean, rstd, rows, H, eps, d)
+    if (nv <= 1) VTX_LN_FWD(1);
+    else if (nv <= 2) VTX_LN_FWD(2);
+    else if (nv <= 4) VTX_LN_FWD(4);
+    else VTX_LN_FWD(8);
+#undef VTX_LN_FWD
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+template <class T>
+int ln_bwd_t(const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
+             const void* dout, void* dz, void* dy, float* dgamma, float* dbeta, int rows, int H,
+             Dropout d, hipStream_t st) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int nv = vtx_cdiv(H, 64 * VEC);
+    int nblk = vtx_cdiv(rows, 4);
+    if (nblk > 1024) nblk = 1024;
+    dim3 grid(nblk), block(256);
+#define VTX_LN_BWD(NV)                                                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)y,    \
+                       gamma, mean, rstd, (const T*)dout, (T*)dz, (T*)dy, dgamma, dbeta, rows,  \
+                       H, d)
+    if (nv <= 1) VTX_LN_BWD(1);
+    else if (nv <= 2) VTX_LN_BWD(2);
+    else if (nv <= 4) VTX_LN_BWD(4);
+    else VTX_LN_BWD(8);
+#undef VTX_LN_BWD
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+}  // namespace
+
+extern "C" int vtx_layernorm_residual_fwd(int dtype, const void* x, const void* y,
+                                          const float* gamma, const float* beta, void* out,
+                                          float* mean, float* rstd, int rows, int H, float eps,
+                                          float p_drop, uint64_t seed, void* stream) {
+    VTX_CHECK(x && gamma && beta && out && mean && rstd, VTX_ERR_ARG, "layernorm_fwd: null pointer");
+    VTX_CHECK(rows >= 0 && H > 0, VTX_ERR_ARG, "layernorm_fwd: bad shape rows=%d H=%d", rows, H);
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(H % vec == 0 && H <= 64 * vec * 8, VTX_ERR_SHAPE,
+              "layernorm_fwd: H=%d must be a multiple of %d and <= %d", H, vec, 64 * vec * 8);
+    if (rows == 0) return VTX_OK;
+    Dropout d = make_dropout(y ? p_drop : 0.f, seed);
+    if (dtype == VTX_BF16)
+        return ln_fwd_t<bf16_t>(x, y, gamma, beta, out, mean, rstd, rows, H, eps, d, (hipStream_t)stream);
+    if (dtype == VTX_F32)
+        return ln_fwd_t<float>(x, y, gamma, beta, out, mean, rstd, rows, H, eps, d, (hipStream_t)stream);
+    VTX_CHECK(false, VTX_ERR_DTYPE, "layernorm_fwd: bad dtype %d", dtype);
+}
+
+extern "C" int vtx_layernorm_residual_bwd(int dtype, const void* x, const void* y,
+                                          const float* gamma, const float* mean, const float* rstd,
+                                          const void* dout, void* dz, void* dy, float* dgamma,
+                                          float* dbeta, int rows, int H, float p_drop,
+                                          uint64_t seed, void* stream) {
+    VTX_CHECK(x && gamma && mean && rstd && dout && dz && dgamma && dbeta, VTX_ERR_ARG,
+              "layernorm_bwd: null pointer");
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(H > 0 && H % vec == 0 && H <= 64 * vec * 8, VTX_ERR_SHAPE, "layernorm_bwd: bad H=%d", H);
+    if (rows == 0) return VTX_OK;
+    Dropout d = make_dropout(y ? p_drop : 0.f, seed);
+    if (dtype == VTX_BF16)
+        return ln_bwd_t<bf16_t>(x, y, gamma, mean, rstd, dout, dz, dy, dgamma, dbeta, rows, H, d, (hipStream_t)stream);
+    if (dtype == VTX_F32)
+        return ln_bwd_t<float>(x, y, gamma, mean, rstd, dout, dz, dy, dgamma, dbeta, rows, H, d, (hipStream_t)stream);
+    VTX_CHECK(false, VTX_ERR_DTYPE, "layernorm_bwd: bad dtype %d", dtype);
+}

@@ -1,0 +1,167 @@
+// Shared device/host helpers for the virtex_amd HIP kernels (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/virtex_amd.h"
+
+// ---------------------------------------------------------------------------------------
+// Error plumbing for the C ABI: every entry point returns 0 or a negative vtx_status and
+// records a thread-local message (backward arrives on autograd's thread -> no globals).
+// ---------------------------------------------------------------------------------------
+void vtx_set_error(const char* fmt, ...);
+#define VTX_CHECK(cond, code, ...)            \
+    do {                                      \
+        if (!(cond)) {                        \
+            vtx_set_error(__VA_ARGS__);       \
+            return (code);                    \
+        }                                     \
+    } while (0)
+#define VTX_LAUNCH_CHECK()                                                     \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess) {                                                \
+            vtx_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,       \
+                          hipGetErrorString(e_));                              \
+            return VTX_ERR_LAUNCH;                                             \
+        }                                                                      \
+    } while (0)
+
+static inline int vtx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// bf16 stored as raw uint16 (round-to-nearest-even), fp32 math everywhere.
+// ---------------------------------------------------------------------------------------
+typedef uint16_t bf16_t;
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));   // one 16x16x32 MFMA operand
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <class T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;  // elements per 16-byte access
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte vector of T unpacked to / packed from fp32 registers.
+template <class T> struct Vec16;
+template <> struct Vec16<float> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec16<bf16_t> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        uint4 t = *reinterpret_cast<const uint4*>(p);
+        uint32_t w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        uint32_t w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// wave64 / block reductions
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+// Sum over a block of NW waves; every thread gets the result.  `red` = NW floats of LDS.
+template <int NW> __device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+template <int NW> __device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// Counter-based dropout RNG: keep-mask = f(seed, element index) recomputed in backward, so
+// no mask tensor ever touches HBM.  (Bit parity with torch's Philox stream is a non-goal:
+// SURVEY.md 7.3-8; parity runs use p = 0.)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t vtx_hash32(uint32_t seed, uint32_t idx_lo, uint32_t idx_hi) {
+    uint32_t x = idx_lo * 0x9E3779B1u + (idx_hi ^ seed) * 0x85EBCA77u + seed;
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16; x += seed * 0xC2B2AE3Du;
+    x ^= x >> 15; x *= 0x2c1b3c6du;
+    x ^= x >> 12;
+    return x;
+}
+struct Dropout {
+    uint32_t seed;
+    uint32_t thresh;  // keep iff hash >= thresh ; thresh = p * 2^32
+    float scale;      // 1/(1-p)
+    __device__ __forceinline__ float apply(float v, uint64_t idx) const {
+        if (thresh == 0u) return v;
+        return vtx_hash32(seed, (uint32_t)idx, (uint32_t)(idx >> 32)) >= thresh ? v * scale : 0.f;
+    }
+};
+static inline Dropout make_dropout(float p, uint64_t seed) {
+    Dropout d;
+    d.seed = (uint32_t)(seed * 0x9E3779B97F4A7C15ull >> 32) ^ (uint32_t)seed;
+    if (p <= 0.f) { d.thresh = 0u; d.scale = 1.f; }
+    else {
+        double t = (double)p * 4294967296.0;
+        d.thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+        d.scale = 1.f / (1.f - p);
+    }
+    return d;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
