@@ -53,6 +53,21 @@ int vtx_layernorm_residual_bwd(int dtype, const void* x, const void* y, const fl
                                void* dy, float* dgamma, float* dbeta, int rows, int H,
                                float p_drop, uint64_t seed, void* stream);
 
+/* ---- GEMMs (MFMA; csrc/gemm_kernel.h) --------------------------------------------------
+ * vtx_gemm_nt : C[M][N] = dropout(act(alpha * A[M][K] . B[N][K]^T + bias[N])) + residual
+ *   replaces aten::linear / addmm (text-head linears, textual_heads.py:245,270-277) and the
+ *   1x1 stride-1 convolutions of the backbone; also input-gradients with a pre-transposed
+ *   weight.  A,B,C,residual,preact: dtype; bias fp32; act: 0 none, 1 GELU(erf), 2 ReLU.
+ *   preact (optional) receives alpha*A.B^T+bias before the activation (GELU backward).
+ * vtx_gemm_tn_acc : C[M][N] (fp32) += alpha * A[K][M]^T . B[K][N]   (weight gradients;
+ *   replaces the mm inside aten::linear_backward / 1x1 convolution_backward).  split_k <= 0
+ *   lets the library choose; partial sums are combined with fp32 atomics. */
+int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                void* C, long ldc, const float* bias, const void* residual, long ldr, void* preact,
+                int act, float alpha, float p_drop, uint64_t seed, void* stream);
+int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                    float* C, long ldc, float alpha, int split_k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

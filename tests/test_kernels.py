@@ -60,3 +60,44 @@ def test_layernorm_dropout_statistics(backend):
     assert ((dy2 != 0) != (dy != 0)).float().mean().item() > 0.05
     _, dy3 = ops.layernorm_residual_bwd(x, y, gamma, mean, rstd, dout, dg, db, p, seed=123)
     assert torch.equal(dy3, dy)
+
+
+def _gemm_tol(dtype, K):
+    # fp32 MFMA is an exact fmaf chain; bf16 inputs are exact products accumulated in fp32,
+    # so against the fp32 product of the SAME (already rounded) inputs both are tight.
+    return 2e-5 if dtype == torch.float32 else 1e-2
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(98, 64, 64), (130, 200, 96), (257, 128, 40), (64, 1000, 128), (300, 72, 256)])
+def test_gemm_nt(backend, dtype, M, N, K):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(dtype)
+    b = torch.randn(N, K, generator=g).to(dtype)
+    bias = torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(dtype)
+    ref_pre = a.float() @ b.float().t() * 0.5 + bias
+    ref = F.gelu(ref_pre) + res.float()
+    out, pre = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), res.to(dev), act=ops.ACT_GELU,
+                           want_preact=True, alpha=0.5)
+    assert rel_err(pre.float().cpu(), ref_pre) < _gemm_tol(dtype, K)
+    assert rel_err(out.float().cpu(), ref) < _gemm_tol(dtype, K)
+    # asymmetric check without epilogue (catches transposes)
+    out2 = ops.gemm_nt(a.to(dev), b.to(dev))
+    assert rel_err(out2.float().cpu(), a.float() @ b.float().t()) < _gemm_tol(dtype, K)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,split", [(64, 64, 50, 1), (136, 200, 300, 3), (1000, 128, 77, 0), (72, 264, 513, 4)])
+def test_gemm_tn_acc(backend, dtype, M, N, K, split):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(K, M, generator=g).to(dtype)
+    b = torch.randn(K, N, generator=g).to(dtype)
+    c0 = torch.randn(M, N, generator=g)
+    out = ops.gemm_tn_acc(a.to(dev), b.to(dev), c0.clone().to(dev), alpha=2.0, split_k=split)
+    ref = c0 + 2.0 * a.float().t() @ b.float()
+    assert rel_err(out.cpu(), ref) < _gemm_tol(dtype, K)

@@ -1,0 +1,394 @@
+// One MFMA contraction kernel for every GEMM-shaped op of the hot path (gfx950, wave64).
+//
+//   C[m][n] (+)= epilogue( sum_k A(m,k) * B(n,k) )
+//
+// Block = 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (64|128), wave tile
+// (BM/2)x(BN/2) as (MT x NT) 16x16 MFMA tiles, K advanced in steps of BK = 64 bytes per row.
+// Operand tiles are staged global -> VGPR (16-byte loads, issued one K-step ahead) -> LDS
+// ([row][BK+pad], double buffered, one barrier per K-step) -> MFMA fragments.
+//   bf16: v_mfma_f32_16x16x32_bf16 (fragment = ds_read_b128 of 8 consecutive k)
+//   fp32: v_mfma_f32_16x16x4_f32   (exact fp32; parity mode)
+// The MFMA is issued as D = Btile x Atile so that each lane ends up with 4 CONSECUTIVE n of
+// one m (lane l: m = l&15, n = 4*(l>>4)..+3) -> vector epilogue loads/stores.
+//
+// Operands are described by "loaders" (how a 16-byte chunk of the tile maps to global
+// memory):
+//   KC loaders: chunk = VEC consecutive k of one row   (row-major [rows][K] views, im2col-free
+//               NHWC conv gathers for forward and input-gradient)
+//   MC loaders: chunk = VEC consecutive rows at one k  (k-major [K][rows] views: weight
+//               gradients; transposed into the LDS tile on store)
+#pragma once
+#include "vtx_common.h"
+
+namespace vtxg {
+
+constexpr int NTHREADS = 256;
+
+template <class T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static constexpr int KI = 32;
+    typedef bf16x8_t Frag;
+    __device__ static __forceinline__ Frag load(const bf16_t* tile_row, int lane, int kk) {
+        return *reinterpret_cast<const bf16x8_t*>(tile_row + kk * 32 + (lane >> 4) * 8);
+    }
+    __device__ static __forceinline__ f32x4_t mma(Frag a, Frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KI = 4;
+    typedef float Frag;
+    __device__ static __forceinline__ Frag load(const float* tile_row, int lane, int kk) {
+        return tile_row[kk * 4 + (lane >> 4)];
+    }
+    __device__ static __forceinline__ f32x4_t mma(Frag a, Frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// q = n / d for 0 <= n < 2^24 (exact after one correction step); inv = 1.0f / d
+__device__ __forceinline__ int fdiv(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    int r = n - q * d;
+    if (r < 0) --q; else if (r >= d) ++q;
+    return q;
+}
+
+// ------------------------------------------------------------------ plain matrix loaders
+// rows x K view, k contiguous: element (r,k) at p[r*ld + k]
+template <class T, int SL> struct PlainKC {
+    static constexpr bool MC = false;
+    const T* p; long ld; int rows; int K;
+    struct State { const T* rp[SL]; int kc; };
+    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
+        s.kc = (tid & 3) * Elem<T>::VEC;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) {
+            const int r = row0 + (tid >> 2) + 64 * i;
+            s.rp[i] = r < rows ? p + (long)r * ld + s.kc : nullptr;
+        }
+    }
+    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
+        return (s.rp[i] && k0 + s.kc < K) ? ld16(s.rp[i] + k0) : zero16();
+    }
+};
+// K x rows view, rows contiguous: element (r,k) at p[k*ld + r]
+template <class T, int SL> struct PlainMC {
+    static constexpr bool MC = true;
+    const T* p; long ld; int rows; int K;
+    struct State { int r0; bool ok; };
+    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
+        constexpr int CPR = 64 * SL / Elem<T>::VEC;
+        s.r0 = row0 + (tid % CPR) * Elem<T>::VEC;
+        s.ok = s.r0 < rows;
+    }
+    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
+        constexpr int CPR = 64 * SL / Elem<T>::VEC;
+        const int k = k0 + (threadIdx.x + NTHREADS * i) / CPR;
+        return (s.ok && k < K) ? ld16(p + (long)k * ld + s.r0) : zero16();
+    }
+};
+
+// ------------------------------------------------------------------ NHWC conv geometry
+struct ConvGeo {
+    int N, H, W, C, logC;      // input  NHWC (C power of two, >= VEC)
+    int KO, logKO;             // output channels (power of two for dgrad)
+    int R, S, rcpS;            // filter; rcpS = ceil(65536 / S)
+    int stride, logStride, pad;
+    int OH, OW;
+    float inv_ow, inv_ohow;
+};
+static inline int vtx_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// forward: A(m,k): m = (n,oh,ow), k = (kh,kw,ci) -> x[n][oh*s-p+kh][ow*s-p+kw][ci]
+template <class T, int SL> struct ConvFwdA {
+    static constexpr bool MC = false;
+    const T* x; ConvGeo g; int rows; int K;
+    struct State { long base[SL]; int ih0[SL], iw0[SL]; bool ok[SL]; int kc; };
+    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
+        s.kc = (tid & 3) * Elem<T>::VEC;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) {
+            const int m = row0 + (tid >> 2) + 64 * i;
+            s.ok[i] = m < rows;
+            const int mm = s.ok[i] ? m : 0;
+            const int n = mm / (g.OH * g.OW), rem = mm - n * g.OH * g.OW;
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            s.base[i] = (long)n * g.H * g.W * g.C;
+            s.ih0[i] = oh * g.stride - g.pad;
+            s.iw0[i] = ow * g.stride - g.pad;
+        }
+    }
+    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
+        const int k = k0 + s.kc;
+        const int tap = k >> g.logC, ci = k & (g.C - 1);
+        const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
+        const int ih = s.ih0[i] + kh, iw = s.iw0[i] + kw;
+        const bool ok = s.ok[i] && k < K && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        return ok ? ld16(x + s.base[i] + ((long)ih * g.W + iw) * g.C + ci) : zero16();
+    }
+};
+
+// input gradient: A(m,k): m = (n,ih,iw), k = (kh,kw,co) -> dy[n][(ih+p-kh)/s][(iw+p-kw)/s][co]
+template <class T, int SL> struct ConvDgradA {
+    static constexpr bool MC = false;
+    const T* dy; ConvGeo g; int rows; int K;
+    struct State { long base[SL]; int ihp[SL], iwp[SL]; bool ok[SL]; int kc; };
+    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
+        s.kc = (tid & 3) * Elem<T>::VEC;
+#pragma unroll
+        for (int i = 0; i < SL; ++i) {
+            const int m = row0 + (tid >> 2) + 64 * i;
+            s.ok[i] = m < rows;
+            const int mm = s.ok[i] ? m : 0;
+            const int n = mm / (g.H * g.W), rem = mm - n * g.H * g.W;
+            const int ih = rem / g.W, iw = rem - ih * g.W;
+            s.base[i] = (long)n * g.OH * g.OW * g.KO;
+            s.ihp[i] = ih + g.pad;
+            s.iwp[i] = iw + g.pad;
+        }
+    }
+    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
+        const int k = k0 + s.kc;
+        const int tap = k >> g.logKO, co = k & (g.KO - 1);
+        const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
+        const int th = s.ihp[i] - kh, tw = s.iwp[i] - kw;
+        const int sm = g.stride - 1;
+        const int oh = th >> g.logStride, ow = tw >> g.logStride;
+        const bool ok = s.ok[i] && k < K && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 &&
+                        oh < g.OH && ow < g.OW;
+        return ok ? ld16(dy + s.base[i] + ((long)oh * g.OW + ow) * g.KO + co) : zero16();
+    }
+};
+
+// weight gradient: B(r,k): r = (kh,kw,ci), k = (n,oh,ow) -> x[n][oh*s-p+kh][ow*s-p+kw][ci]
+template <class T, int SL> struct ConvWgradB {
+    static constexpr bool MC = true;
+    const T* x; ConvGeo g; int rows; int K;  // rows = R*S*C, K = N*OH*OW
+    struct State { int kh, kw, ci; bool ok; };
+    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
+        constexpr int CPR = 64 * SL / Elem<T>::VEC;
+        const int r0 = row0 + (tid % CPR) * Elem<T>::VEC;
+        s.ok = r0 < rows;
+        const int tap = r0 >> g.logC;
+        s.ci = r0 & (g.C - 1);
+        s.kh = (tap * g.rcpS) >> 16;
+        s.kw = tap - s.kh * g.S;
+    }
+    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
+        constexpr int CPR = 64 * SL / Elem<T>::VEC;
+        const int pix = k0 + (threadIdx.x + NTHREADS * i) / CPR;
+        const int ohow = g.OH * g.OW;
+        const int n = fdiv(pix, ohow, g.inv_ohow), rem = pix - n * ohow;
+        const int oh = fdiv(rem, g.OW, g.inv_ow), ow = rem - oh * g.OW;
+        const int ih = oh * g.stride - g.pad + s.kh, iw = ow * g.stride - g.pad + s.kw;
+        const bool ok = s.ok && pix < K && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        return ok ? ld16(x + (((long)n * g.H + ih) * g.W + iw) * g.C + s.ci) : zero16();
+    }
+};
+
+// ------------------------------------------------------------------ epilogues
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+
+template <class T> __device__ __forceinline__ void st4(T* p, const float* v);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float* v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
+                                              (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+}
+template <class T> __device__ __forceinline__ void ld4(const T* p, float* v);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float* v) {
+    float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float* v) {
+    uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
+// out = dropout(act(acc*alpha + bias)) + residual ; optional copy of the pre-activation
+template <class T> struct EpiStore {
+    T* out; long ldc; const float* bias; const T* residual; long ldr; T* preact; int act;
+    float alpha; Dropout drop; int M, N;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
+        if (m >= M || n >= N) return;
+        float v[4] = {acc[0] * alpha, acc[1] * alpha, acc[2] * alpha, acc[3] * alpha};
+        if (bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bias[n + j];
+        }
+        const long o = (long)m * ldc + n;
+        if (preact) st4<T>(preact + o, v);
+        if (act == ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        } else if (act == ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (drop.thresh) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = drop.apply(v[j], (uint64_t)(o + j));
+        }
+        if (residual) {
+            float r[4]; ld4<T>(residual + (long)m * ldr + n, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        st4<T>(out + o, v);
+    }
+};
+// out(fp32) += alpha * acc     (split-K partial sums and "+=" gradient accumulation)
+struct EpiAtomic {
+    float* out; long ldc; float alpha; int M, N;
+    __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
+        if (m >= M || n >= N) return;
+        float* o = out + (long)m * ldc + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(o + j, alpha * acc[j]);
+    }
+};
+
+// ------------------------------------------------------------------ the kernel
+template <class T, int BM, int BN, class AL, class BL, class EP>
+__global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP ep, int K,
+                                                               int tiles_n, int kt_per_split) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int BK = 4 * VEC;        // 64 bytes of k per row
+    constexpr int LDSK = BK + VEC;     // +16 B pad
+    constexpr int SLA = BM / 64, SLB = BN / 64;
+    constexpr int MT = BM / 32, NT = BN / 32;
+    constexpr int KSTEPS = BK / Mma<T>::KI;
+    __shared__ __attribute__((aligned(16))) T lds[2][(BM + BN) * LDSK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int nkt = (K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
+
+    typename AL::State sa;
+    typename BL::State sb;
+    al.init(sa, m0, tid);
+    bl.init(sb, n0, tid);
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[SLA], rb[SLB];
+    auto gload = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < SLA; ++i) ra[i] = al.load(sa, i, kt * BK);
+#pragma unroll
+        for (int i = 0; i < SLB; ++i) rb[i] = bl.load(sb, i, kt * BK);
+    };
+    auto lstore = [&](int buf) {
+        T* ta = lds[buf];
+        T* tb = lds[buf] + BM * LDSK;
+#pragma unroll
+        for (int i = 0; i < SLA; ++i) {
+            if constexpr (!AL::MC) {
+                *reinterpret_cast<uint4*>(ta + ((tid >> 2) + 64 * i) * LDSK + (tid & 3) * VEC) = ra[i];
+            } else {
+                constexpr int CPR = BM / VEC;
+                const int c = tid + NTHREADS * i;
+                const int kl = c / CPR, r = (c % CPR) * VEC;
+                const T* e = reinterpret_cast<const T*>(&ra[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) ta[(r + j) * LDSK + kl] = e[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SLB; ++i) {
+            if constexpr (!BL::MC) {
+                *reinterpret_cast<uint4*>(tb + ((tid >> 2) + 64 * i) * LDSK + (tid & 3) * VEC) = rb[i];
+            } else {
+                constexpr int CPR = BN / VEC;
+                const int c = tid + NTHREADS * i;
+                const int kl = c / CPR, r = (c % CPR) * VEC;
+                const T* e = reinterpret_cast<const T*>(&rb[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) tb[(r + j) * LDSK + kl] = e[j];
+            }
+        }
+    };
+
+    if (kt0 < kt1) {
+        gload(kt0);
+        lstore(0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) gload(kt + 1);
+            const T* ta = lds[buf] + (wm * (BM / 2) + (lane & 15)) * LDSK;
+            const T* tb = lds[buf] + (BM + wn * (BN / 2) + (lane & 15)) * LDSK;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                typename Mma<T>::Frag fa[MT], fb[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[i] = Mma<T>::load(ta + i * 16 * LDSK, lane, kk);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) fb[j] = Mma<T>::load(tb + j * 16 * LDSK, lane, kk);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
+            }
+            if (kt + 1 < kt1) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // D = Btile x Atile  =>  lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            ep(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4),
+               acc[i][j]);
+}
+
+// ------------------------------------------------------------------ host-side launch
+template <class T, int BM, int BN, class AL, class BL, class EP>
+inline void launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k,
+                        hipStream_t st) {
+    constexpr int BK = 4 * Elem<T>::VEC;
+    const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
+    const int nkt = vtx_cdiv(K, BK);
+    if (split_k < 1) split_k = 1;
+    if (split_k > nkt) split_k = nkt;
+    const int per = vtx_cdiv(nkt, split_k);
+    split_k = vtx_cdiv(nkt, per);
+    dim3 grid(tiles_m * tiles_n, split_k), block(NTHREADS);
+    hipLaunchKernelGGL((contraction_kernel<T, BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K,
+                       tiles_n, per);
+}
+
+// Tile choice: 128x128 by default; narrower N tile for N <= 64; smaller M tile when M is tiny
+// or when the grid would not fill the 256 CUs.
+template <class T, template <class, int> class ALT, template <class, int> class BLT, class EP, class FA, class FB>
+inline void launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
+    const bool n64 = N <= 64;
+    const long blocks128 = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, n64 ? 64 : 128) * (split_k < 1 ? 1 : split_k);
+    const bool m64 = M <= 64 || blocks128 < 256;
+    if (m64) {
+        ALT<T, 1> a; make_a(a);
+        if (n64 || blocks128 < 128) { BLT<T, 1> b; make_b(b); launch_tile<T, 64, 64>(a, b, ep, M, N, K, split_k, st); }
+        else { BLT<T, 2> b; make_b(b); launch_tile<T, 64, 128>(a, b, ep, M, N, K, split_k, st); }
+    } else {
+        ALT<T, 2> a; make_a(a);
+        if (n64) { BLT<T, 1> b; make_b(b); launch_tile<T, 128, 64>(a, b, ep, M, N, K, split_k, st); }
+        else { BLT<T, 2> b; make_b(b); launch_tile<T, 128, 128>(a, b, ep, M, N, K, split_k, st); }
+    }
+}
+
+}  // namespace vtxg
