@@ -59,14 +59,99 @@ int vtx_layernorm_residual_bwd(int dtype, const void* x, const void* y, const fl
  *   1x1 stride-1 convolutions of the backbone; also input-gradients with a pre-transposed
  *   weight.  A,B,C,residual,preact: dtype; bias fp32; act: 0 none, 1 GELU(erf), 2 ReLU.
  *   preact (optional) receives alpha*A.B^T+bias before the activation (GELU backward).
+ *   out_f32 != 0: C/residual/preact are fp32 even when dtype is bf16 (vocabulary logits).
  * vtx_gemm_tn_acc : C[M][N] (fp32) += alpha * A[K][M]^T . B[K][N]   (weight gradients;
  *   replaces the mm inside aten::linear_backward / 1x1 convolution_backward).  split_k <= 0
  *   lets the library choose; partial sums are combined with fp32 atomics. */
 int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                 void* C, long ldc, const float* bias, const void* residual, long ldr, void* preact,
-                int act, float alpha, float p_drop, uint64_t seed, void* stream);
+                int act, float alpha, float p_drop, uint64_t seed, int out_f32, void* stream);
 int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                     float* C, long ldc, float alpha, int split_k, void* stream);
+
+/* ---- NHWC convolutions (im2col-free implicit GEMM on MFMA; csrc/conv_*.hip) -------------
+ * Replace aten::convolution / convolution_backward of the torchvision ResNet reached from
+ * virtex/modules/visual_backbones.py:68-74.  x:[N][H][W][C], y/dy:[N][OH][OW][KO] (dtype),
+ * w:[KO][R][S][C], wt:[C][R][S][KO] (dtype; see vtx_weight_prep), dw:[KO][R][S][C] fp32,
+ * ACCUMULATED.  C and KO must be powers of two >= 16 bytes worth of elements (the 3-channel
+ * stem input is zero-padded to 8 channels by vtx_image_to_nhwc).  OH = (H+2p-R)/s+1. */
+int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
+                   const void* x, const void* w, void* y, void* stream);
+int vtx_conv2d_dgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
+                     const void* dy, const void* wt, void* dx, void* stream);
+int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
+                     const void* x, const void* dy, float* dw, int split_k, void* stream);
+
+/* ---- BatchNorm2d (training) + ReLU + residual on NHWC, x viewed as [P=N*H*W][C] ---------
+ * Replaces aten::batch_norm/relu_/add_ (+backward) of torchvision's Bottleneck
+ * (visual_backbones.py:68-74): y = act(gamma*(x-mean)*rstd + beta (+ residual)), running
+ * stats updated with `momentum` and the unbiased variance, num_batches_tracked += 1.
+ * fwd workspace: 4*C floats whose first 2*C are ZERO on entry.
+ * bwd: dz = dy * (ymask > 0) (ymask = the post-ReLU tensor, NULL if no ReLU follows);
+ *      dx = grad wrt x; dz_out (optional) receives dz (the residual-branch gradient);
+ *      dgamma/dbeta accumulated; workspace: 5*C floats, first 2*C ZERO on entry. */
+int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamma, const float* beta,
+               float* running_mean, float* running_var, long long* num_batches_tracked, void* y,
+               float* save_mean, float* save_rstd, float* workspace, int P, int C, float eps,
+               float momentum, int relu, void* stream);
+int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, const float* gamma,
+               const float* save_mean, const float* save_rstd, void* dx, void* dz_out, float* dgamma,
+               float* dbeta, float* workspace, int P, int C, void* stream);
+
+/* ---- MaxPool2d(3, stride 2, pad 1) NHWC (aten::max_pool2d_with_indices of the stem) ---- */
+int vtx_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,
+                         void* stream);
+int vtx_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* argmax, void* dx, int N, int H, int W,
+                         int C, void* stream);
+
+/* ---- layout / precision preparation -------------------------------------------------- */
+int vtx_image_to_nhwc(int dtype, const float* src_nchw, void* dst_nhwc, int N, int Cin, int H, int W,
+                      int Cpad, void* stream);
+int vtx_weight_prep(int dtype, const float* w32 /*[KO][T][C]*/, void* w /*[KO][T][Cp] or NULL*/,
+                    void* wt /*[Cp][T][KO] or NULL*/, int KO, int T, int C, int Cp, void* stream);
+int vtx_cast_from_f32(int dtype, const float* src, void* dst, long n, void* stream);
+
+/* ---- WordAndPositionalEmbedding (virtex/modules/embedding.py:46-74) -------------------
+ * out[b][t] = (tok != padding_idx) * dropout(LN_eps(words[tok] + positions[t])); tables and
+ * LN parameters fp32, out dtype.  bwd accumulates (fp32 atomics) into dwords (tied matrix;
+ * padding_idx rows untouched), dpositions, dgamma, dbeta. */
+int vtx_embedding_fwd(int dtype, const long long* tokens, const float* words, const float* positions,
+                      const float* gamma, const float* beta, void* out, float* mean, float* rstd, int B,
+                      int T, int H, int V, int padding_idx, float eps, float p_drop, uint64_t seed,
+                      void* stream);
+int vtx_embedding_bwd(int dtype, const long long* tokens, const float* words, const float* positions,
+                      const float* gamma, const float* mean, const float* rstd, const void* dout,
+                      float* dwords, float* dpositions, float* dgamma, float* dbeta, int B, int T, int H,
+                      int V, int padding_idx, float p_drop, uint64_t seed, void* stream);
+
+/* ---- fused multi-head attention, head_dim 64, T<=32 queries, S<=56 keys ----------------
+ * Replaces aten::scaled_dot_product_attention (+backward) of nn.TransformerDecoderLayer
+ * (textual_heads.py:270-275).  q:[B*T][ldq], k,v:[B*S][ld*], o:[B*T][ldo]; head h uses
+ * columns h*64..h*64+63 of each.  causal: mask j>i; key_lengths (nullable int64[B]): mask
+ * keys j >= key_lengths[b] (tgt_key_padding_mask, textual_heads.py:255-256). */
+int vtx_attention_fwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                      void* o, long ldo, int B, int heads, int T, int S, int head_dim, int causal,
+                      const long long* key_lengths, float p_drop, uint64_t seed, void* stream);
+int vtx_attention_bwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                      const void* dout, long ldo, void* dq, long lddq, void* dk, long lddk, void* dv,
+                      long lddv, int B, int heads, int T, int S, int head_dim, int causal,
+                      const long long* key_lengths, float p_drop, uint64_t seed, void* stream);
+
+/* ---- softmax cross-entropy (virtex/models/captioning.py:69,111-114) --------------------
+ * fwd: lse[R], row_loss[R], loss_and_count[2] = {mean loss over targets != ignore, count}.
+ * bwd: dlogits[r][c] = grad_out[0]/count * (softmax - onehot), 0 for ignored rows. */
+int vtx_cross_entropy_fwd(const float* logits, long ld, const long long* targets, float* lse,
+                          float* row_loss, float* loss_and_count, int R, int V, int ignore_index,
+                          void* stream);
+int vtx_cross_entropy_bwd(int dtype, const float* logits, long ld, const long long* targets,
+                          const float* lse, const float* loss_and_count, const float* grad_out,
+                          void* dlogits, long ldd, int R, int V, int ignore_index, void* stream);
+
+/* ---- small helpers -------------------------------------------------------------------- */
+int vtx_colsum_acc(int dtype, const void* x, long ld, float* out /*[C] +=*/, int R, int C, void* stream);
+int vtx_add(int dtype, const void* a, const void* b, void* out, long n, void* stream);
+int vtx_gelu_bwd(int dtype, const void* h, const void* da, void* dh, long n, float p_drop, uint64_t seed,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,3 +101,236 @@ def test_gemm_tn_acc(backend, dtype, M, N, K, split):
     out = ops.gemm_tn_acc(a.to(dev), b.to(dev), c0.clone().to(dev), alpha=2.0, split_k=split)
     ref = c0 + 2.0 * a.float().t() @ b.float()
     assert rel_err(out.cpu(), ref) < _gemm_tol(dtype, K)
+
+
+CONV_CASES = [
+    # N, H, W, C, KO, R, S, stride, pad
+    (2, 9, 9, 16, 32, 3, 3, 1, 1),
+    (2, 10, 10, 16, 16, 3, 3, 2, 1),
+    (3, 8, 8, 32, 64, 1, 1, 2, 0),
+    (2, 8, 8, 64, 16, 1, 1, 1, 0),
+    (2, 22, 22, 8, 64, 7, 7, 2, 3),
+    (1, 7, 7, 128, 128, 3, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(backend, dtype, case):
+    dev = select(backend)
+    N, H, W, C, KO, R, S, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, C, generator=g).to(dtype)
+    w = (torch.randn(KO, R, S, C, generator=g) / (R * S * C) ** 0.5).to(dtype)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+    wr = w.float().permute(0, 3, 1, 2).requires_grad_()
+    yr = F.conv2d(xr, wr, stride=stride, padding=pad)
+    dy = torch.randn(yr.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dtype)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    e = 2e-5 if dtype == torch.float32 else 1e-2
+
+    y = ops.conv2d_fwd(x.to(dev), w.to(dev), stride, pad)
+    assert y.shape == dy.shape
+    assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < e
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), x.shape, stride, pad)
+    assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < e
+    dw0 = torch.randn(KO, R, S, C, generator=g)
+    dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), stride, pad)
+    assert rel_err(dw.cpu() - dw0, wr.grad.permute(0, 2, 3, 1)) < 2 * e
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,W,C,relu,res", [(2, 7, 7, 64, True, False), (3, 5, 6, 256, True, True),
+                                              (2, 4, 4, 2048, False, False), (4, 9, 9, 16, True, True)])
+def test_batchnorm(backend, dtype, N, H, W, C, relu, res):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(N * C + H)
+    x = (1.5 * torch.randn(N, H, W, C, generator=g) + 0.3).to(dtype)
+    r = torch.randn(N, H, W, C, generator=g).to(dtype) if res else None
+    gamma = 0.5 + torch.rand(C, generator=g); beta = 0.1 * torch.randn(C, generator=g)
+    rm0 = 0.1 * torch.randn(C, generator=g); rv0 = 0.5 + torch.rand(C, generator=g)
+    dy = torch.randn(N, H, W, C, generator=g).to(dtype)
+
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+    rr = r.float().permute(0, 3, 1, 2).requires_grad_() if res else None
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rm, rv = rm0.clone(), rv0.clone()
+    yr = F.batch_norm(xr, rm, rv, gr, br, True, 0.1, 1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+
+    ws = torch.zeros(4 * C, device=dev)
+    rmd, rvd = rm0.clone().to(dev), rv0.clone().to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    y, mean, rstd = ops.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmd, rvd, nbt, ws, relu=relu,
+                               residual=r.to(dev) if res else None)
+    e = 3e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < e
+    assert rel_err(rmd.cpu(), rm) < 1e-4 and rel_err(rvd.cpu(), rv) < 1e-4 and int(nbt) == 1
+    ws2 = torch.zeros(5 * C, device=dev)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx, dz = ops.bn_bwd(x.to(dev), dy.to(dev), y if relu else None, gamma.to(dev), mean, rstd, dg, db, ws2,
+                        want_dz=True)
+    assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(dg.cpu(), gr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    assert rel_err(db.cpu(), br.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
+    if res:
+        assert rel_err(dz.float().cpu(), rr.grad.permute(0, 2, 3, 1)) < e
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,W,C", [(2, 8, 8, 64), (1, 7, 9, 16), (2, 14, 14, 8)])
+def test_maxpool(backend, dtype, N, H, W, C):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(H * W)
+    x = F.relu(torch.randn(N, H, W, C, generator=g)).to(dtype)  # ties at 0, like post-ReLU activations
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(yr.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dtype)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    y, arg = ops.maxpool_fwd(x.to(dev))
+    assert torch.equal(y.float().cpu(), yr.detach().permute(0, 2, 3, 1))
+    dx = ops.maxpool_bwd(dy.to(dev), arg, x.shape)
+    assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_prep_kernels(backend, dtype):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(2, 3, 6, 5, generator=g)
+    out = ops.image_to_nhwc(img.to(dev), dtype, 8).float().cpu()
+    assert torch.equal(out[..., :3], img.permute(0, 2, 3, 1).to(dtype).float()) and out[..., 3:].abs().max() == 0
+    w = torch.randn(40, 9, 3, generator=g)
+    wp, wt = ops.weight_prep(w.to(dev), dtype, cpad=8)
+    ref = torch.zeros(40, 9, 8); ref[..., :3] = w
+    assert torch.equal(wp.float().cpu(), ref.to(dtype).float())
+    assert torch.equal(wt.float().cpu(), ref.permute(2, 1, 0).to(dtype).float())
+    w2 = torch.randn(100, 72, generator=g)
+    wp, wt = ops.weight_prep(w2.to(dev), dtype)
+    assert torch.equal(wp.float().cpu().squeeze(1), w2.to(dtype).float())
+    assert torch.equal(wt.float().cpu().squeeze(1), w2.t().to(dtype).float())
+    assert torch.equal(ops.cast_from_f32(w2.to(dev), dtype).float().cpu(), w2.to(dtype).float())
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,T,H,V", [(3, 12, 128, 1000), (5, 30, 1024, 300)])
+def test_embedding(backend, dtype, B, T, H, V):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(B + T)
+    tokens = torch.randint(1, V, (B, T), generator=g)
+    tokens[0, T // 2:] = 0  # padding tail
+    tokens[1, 3] = 0
+    words = 0.02 * torch.randn(V, H, generator=g); words[0] = 0.5  # non-zero pad row: must not matter
+    pos = 0.02 * torch.randn(30, H, generator=g)
+    gamma = 0.5 + torch.rand(H, generator=g); beta = 0.1 * torch.randn(H, generator=g)
+    dout = torch.randn(B, T, H, generator=g).to(dtype)
+
+    wr, pr, gr, br = (t.clone().requires_grad_() for t in (words, pos, gamma, beta))
+    e = F.embedding(tokens, wr, padding_idx=0) + pr[:T].unsqueeze(0)
+    ref = F.layer_norm(e, (H,), gr, br, 1e-8) * (tokens != 0).unsqueeze(-1).float()
+    ref.backward(dout.float())
+
+    td = tokens.to(dev)
+    out, mean, rstd = ops.embedding_fwd(td, words.to(dev), pos.to(dev), gamma.to(dev), beta.to(dev), dtype)
+    assert torch.allclose(out.float().cpu(), ref.detach(), **tol(dtype))
+    dw, dp = torch.zeros(V, H, device=dev), torch.zeros(30, H, device=dev)
+    dg, db = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    ops.embedding_bwd(td, words.to(dev), pos.to(dev), gamma.to(dev), mean, rstd, dout.to(dev), dw, dp, dg, db)
+    tl = 5e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(dw.cpu(), wr.grad) < tl and dw[0].abs().max() == 0
+    assert rel_err(dp.cpu(), pr.grad) < tl
+    assert rel_err(dg.cpu(), gr.grad) < tl and rel_err(db.cpu(), br.grad) < tl
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,A,T,S,causal", [(2, 4, 12, 12, True), (3, 2, 30, 49, False), (2, 16, 30, 30, True)])
+def test_attention(backend, dtype, B, A, T, S, causal):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(T + S)
+    Hd = A * 64
+    if causal:   # self-attention: packed qkv projection output, ragged key lengths
+        qkv = torch.randn(B * T, 3 * Hd, generator=g).to(dtype)
+        q, k, v = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
+        lengths = torch.randint(2, T + 1, (B,), generator=g); lengths[0] = T
+    else:
+        q = torch.randn(B * T, Hd, generator=g).to(dtype)
+        kv = torch.randn(B * S, 2 * Hd, generator=g).to(dtype)
+        k, v = kv[:, :Hd], kv[:, Hd:]
+        lengths = None
+    dout = torch.randn(B * T, Hd, generator=g).to(dtype)
+
+    def heads(t, L):
+        return t.float().reshape(B, L, A, 64).transpose(1, 2)
+    qr, kr, vr = (heads(q, T).requires_grad_(), heads(k, S).requires_grad_(), heads(v, S).requires_grad_())
+    mask = torch.zeros(B, 1, T, S)
+    if causal:
+        mask = mask + torch.triu(torch.full((T, S), float("-inf")), 1)
+        mask = mask.masked_fill((torch.arange(S)[None, :] >= lengths[:, None])[:, None, None, :], float("-inf"))
+    p = torch.softmax(qr @ kr.transpose(-1, -2) / 8.0 + mask, dim=-1)
+    oref = (p @ vr).transpose(1, 2).reshape(B * T, Hd)
+    oref.backward(dout.float())
+
+    ld = lengths.to(dev) if lengths is not None else None
+    if causal:
+        qkvd = qkv.to(dev); qd, kd, vd = qkvd[:, :Hd], qkvd[:, Hd:2 * Hd], qkvd[:, 2 * Hd:]
+        dqkv = torch.empty_like(qkvd); dq, dk, dv = dqkv[:, :Hd], dqkv[:, Hd:2 * Hd], dqkv[:, 2 * Hd:]
+    else:
+        qd = q.to(dev); kvd = kv.to(dev); kd, vd = kvd[:, :Hd], kvd[:, Hd:]
+        dq = torch.empty_like(qd); dkv = torch.empty_like(kvd); dk, dv = dkv[:, :Hd], dkv[:, Hd:]
+    o = ops.attention_fwd(qd, kd, vd, B, A, T, S, causal, ld)
+    e = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(o.float().cpu(), oref.detach()) < e
+    ops.attention_bwd(qd, kd, vd, dout.to(dev), dq, dk, dv, B, A, T, S, causal, ld)
+
+    def unheads(t, L):
+        return t.transpose(1, 2).reshape(B * L, Hd)
+    assert rel_err(dq.float().cpu(), unheads(qr.grad, T)) < 2 * e
+    assert rel_err(dk.float().cpu(), unheads(kr.grad, S)) < 2 * e
+    assert rel_err(dv.float().cpu(), unheads(vr.grad, S)) < 2 * e
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("R,V", [(20, 1000), (58, 10000)])
+def test_cross_entropy(backend, dtype, R, V):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(R)
+    logits = 3 * torch.randn(R, V, generator=g)
+    targets = torch.randint(1, V, (R,), generator=g)
+    targets[::5] = 0
+    lr = logits.clone().requires_grad_()
+    ref = F.cross_entropy(lr, targets, ignore_index=0)
+    (ref * 1.7).backward()
+    lc, lse = ops.cross_entropy_fwd(logits.to(dev), targets.to(dev), 0)
+    assert abs(lc[0].item() - ref.item()) < 1e-5 * abs(ref.item()) + 1e-6
+    assert int(lc[1].item()) == int((targets != 0).sum())
+    d = ops.cross_entropy_bwd(logits.to(dev), targets.to(dev), lse, lc, torch.tensor([1.7], device=dev), dtype, 0)
+    assert rel_err(d.float().cpu(), lr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_small_helpers(backend, dtype):
+    dev = select(backend)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(333, 1000, generator=g).to(dtype)
+    out0 = torch.randn(1000, generator=g)
+    out = ops.colsum_acc(x.to(dev), out0.clone().to(dev))
+    assert rel_err(out.cpu(), out0 + x.float().sum(0)) < (1e-5 if dtype == torch.float32 else 1e-5)
+    a = torch.randn(64, 40, generator=g).to(dtype); b = torch.randn(64, 40, generator=g).to(dtype)
+    assert torch.allclose(ops.add(a.to(dev), b.to(dev)).float().cpu(), (a.float() + b.float()).to(dtype).float())
+    h = torch.randn(64, 40, generator=g).to(dtype); da = torch.randn(64, 40, generator=g).to(dtype)
+    hr = h.float().requires_grad_()
+    F.gelu(hr).backward(da.float())
+    assert rel_err(ops.gelu_bwd(h.to(dev), da.to(dev)).float().cpu(), hr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)

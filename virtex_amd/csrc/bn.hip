@@ -1,0 +1,244 @@
+// Training-mode BatchNorm2d on NHWC activations, fused with ReLU and the residual add
+// (HBM-bound).  x is viewed as [P = N*H*W][C]; statistics are fp32.
+//
+//   forward : stats (sum, sum of squares per channel) -> finalize (mean, rstd, running stats,
+//             per-channel scale/shift) -> apply  y = act(x*scale + shift (+ residual))
+//   backward: dz = dy * (y > 0)   [y = the post-ReLU tensor, nullptr when no ReLU follows]
+//             reduce  s1 = sum dz, s2 = sum dz*xhat  -> finalize (dgamma += s2, dbeta += s1)
+//             apply   dx = gamma*rstd * (dz - s1/P - xhat*s2/P) ; optionally also emit dz
+//
+// Replaces aten::batch_norm / relu_ / add_ (+ their backward) of torchvision's Bottleneck,
+// reached from /root/reference/virtex/modules/visual_backbones.py:68-74 (eps 1e-5,
+// momentum 0.1, unbiased running variance).
+#include "vtx_common.h"
+
+namespace {
+
+// x viewed as [P][cv] 16-byte vectors.  Block: TX threads across channel vectors, TY = 256/TX
+// pixel rows; blockIdx.y selects the channel-vector group, blockIdx.x a strip of pixels.
+template <class T, bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ ymask,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ sums,
+    int P, int C, int TX, int rows_per_block) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+    const int c0 = (blockIdx.y * TX + tx) * VEC;
+    const int p0 = blockIdx.x * rows_per_block;
+    const int p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
+    float a[VEC], b[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        a[j] = b[j] = 0.f;
+        mu[j] = BWD ? mean[c0 + j] : 0.f;
+        rs[j] = BWD ? rstd[c0 + j] : 0.f;
+    }
+    for (int p = p0 + ty; p < p1; p += TY) {
+        const size_t off = (size_t)p * C + c0;
+        Vec16<T> xv; xv.load(x + off);
+        if (BWD) {
+            Vec16<T> g; g.load(dy + off);
+            if (ymask) {
+                Vec16<T> m; m.load(ymask + off);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) g.v[j] = m.v[j] > 0.f ? g.v[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { a[j] += g.v[j]; b[j] += g.v[j] * (xv.v[j] - mu[j]) * rs[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { a[j] += xv.v[j]; b[j] += xv.v[j] * xv.v[j]; }
+        }
+    }
+    __shared__ float red[2][256 * VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        red[0][(ty * TX + tx) * VEC + j] = a[j];
+        red[1][(ty * TX + tx) * VEC + j] = b[j];
+    }
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int r = 0; r < TY; ++r) { s0 += red[0][(r * TX + tx) * VEC + j]; s1 += red[1][(r * TX + tx) * VEC + j]; }
+            atomicAdd(sums + c0 + j, s0);
+            atomicAdd(sums + C + c0 + j, s1);
+        }
+    }
+}
+
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ mean,
+                                       float* __restrict__ rstd, float* __restrict__ scale,
+                                       float* __restrict__ shift, float* __restrict__ running_mean,
+                                       float* __restrict__ running_var, long long* __restrict__ nbt,
+                                       int P, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const float m = sums[c] / (float)P;
+    float var = sums[C + c] / (float)P - m * m;
+    var = var > 0.f ? var : 0.f;
+    const float r = rsqrtf(var + eps);
+    mean[c] = m; rstd[c] = r;
+    const float sc = gamma[c] * r;
+    scale[c] = sc; shift[c] = beta[c] - m * sc;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        const float unbiased = P > 1 ? var * ((float)P / (float)(P - 1)) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ residual,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, T* __restrict__ y,
+                                                       long nvec, int C, int relu) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * VEC;
+        Vec16<T> v; v.load(x + i * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v.v[j] = v.v[j] * scale[c0 + j] + shift[c0 + j];
+        if (residual) {
+            Vec16<T> r; r.load(residual + i * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.v[j] += r.v[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.v[j] = fmaxf(v.v[j], 0.f);
+        }
+        v.store(y + i * VEC);
+    }
+}
+
+// coef[0][c] = gamma*rstd, coef[1][c] = s1/P, coef[2][c] = s2/P ; dgamma += s2 ; dbeta += s1
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                       const float* __restrict__ rstd, float* __restrict__ coef,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int P, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s1 = sums[c], s2 = sums[C + c];
+    coef[c] = gamma[c] * rstd[c];
+    coef[C + c] = s1 / (float)P;
+    coef[2 * C + c] = s2 / (float)P;
+    dgamma[c] += s2;
+    dbeta[c] += s1;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ ymask,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
+    T* __restrict__ dx, T* __restrict__ dz_out, long nvec, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * VEC;
+        Vec16<T> xv, g; xv.load(x + i * VEC); g.load(dy + i * VEC);
+        if (ymask) {
+            Vec16<T> m; m.load(ymask + i * VEC);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) g.v[j] = m.v[j] > 0.f ? g.v[j] : 0.f;
+        }
+        if (dz_out) g.store(dz_out + i * VEC);
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv.v[j] - mean[c0 + j]) * rstd[c0 + j];
+            o.v[j] = coef[c0 + j] * (g.v[j] - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
+        }
+        o.store(dx + i * VEC);
+    }
+}
+
+struct ReducePlan { int TX, gy, gx, rows; };
+static ReducePlan plan_reduce(int P, int C, int vec) {
+    ReducePlan r;
+    const int cv = C / vec;
+    r.TX = cv < 256 ? cv : 256;
+    r.gy = cv / r.TX;
+    const int TY = 256 / r.TX;
+    int gx = 2048 / r.gy;
+    const int max_gx = vtx_cdiv(P, TY * 4);
+    if (gx > max_gx) gx = max_gx;
+    if (gx < 1) gx = 1;
+    r.rows = vtx_cdiv(P, gx);
+    r.gx = vtx_cdiv(P, r.rows);
+    return r;
+}
+static int apply_grid(long nvec) {
+    long g = (nvec + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+static bool bn_shape_ok(int C, int vec) { return C > 0 && C % vec == 0 && ((C / vec) & (C / vec - 1)) == 0; }
+
+}  // namespace
+
+// workspace layout (fp32): sums[2*C] (must be ZERO on entry; left dirty) | scale[C] | shift[C]
+extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, void* y, float* save_mean, float* save_rstd,
+                          float* workspace, int P, int C, float eps, float momentum, int relu, void* stream) {
+    VTX_CHECK(x && gamma && beta && y && save_mean && save_rstd && workspace, VTX_ERR_ARG, "bn_fwd: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_fwd: bad dtype %d", dtype);
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_fwd: C=%d must be vec*2^k, P=%d > 0", C, P);
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = workspace; float* scale = workspace + 2 * C; float* shift = workspace + 3 * C;
+    ReducePlan rp = plan_reduce(P, C, vec);
+    const long nvec = (long)P * C / vec;
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
+                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, sums, gamma, beta, save_mean,
+                       save_rstd, scale, shift, running_mean, running_var, num_batches_tracked, P, C, eps, momentum);
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+                           (const bf16_t*)residual, scale, shift, (bf16_t*)y, nvec, C, relu);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+                           (const float*)residual, scale, shift, (float*)y, nvec, C, relu);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+// workspace (fp32): sums[2*C] (ZERO on entry) | coef[3*C]
+extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, const float* gamma,
+                          const float* save_mean, const float* save_rstd, void* dx, void* dz_out,
+                          float* dgamma, float* dbeta, float* workspace, int P, int C, void* stream) {
+    VTX_CHECK(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace, VTX_ERR_ARG,
+              "bn_bwd: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_bwd: bad dtype %d", dtype);
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_bwd: C=%d must be vec*2^k, P=%d > 0", C, P);
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = workspace; float* coef = workspace + 2 * C;
+    ReducePlan rp = plan_reduce(P, C, vec);
+    const long nvec = (long)P * C / vec;
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
+                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, sums, P, C, rp.TX, rp.rows);
+    else
+        hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
+                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, sums, P, C, rp.TX, rp.rows);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
+                       dgamma, dbeta, P, C);
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, coef, (bf16_t*)dx,
+                           (bf16_t*)dz_out, nvec, C);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, coef, (float*)dx,
+                           (float*)dz_out, nvec, C);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}

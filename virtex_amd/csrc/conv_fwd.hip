@@ -1,0 +1,30 @@
+// NHWC convolution forward as an im2col-free implicit GEMM on MFMA:
+//   y[n][oh][ow][ko] = sum_{kh,kw,ci} x[n][oh*s-p+kh][ow*s-p+kw][ci] * w[ko][kh][kw][ci]
+// GEMM view: M = N*OH*OW, N = KO, K = R*S*C (gfx950 kernel: gemm_kernel.h, loader ConvFwdA).
+// Replaces aten::convolution (cudnn/MIOpen/mkldnn) for the 53 bias-free convs of ResNet-50
+// reached from /root/reference/virtex/modules/visual_backbones.py:68-74.
+#include "conv_common.h"
+
+using namespace vtxg;
+
+template <class T>
+static int conv_fwd_t(const ConvGeo& g, const void* x, const void* w, void* y, const void* residual,
+                      int act, hipStream_t st) {
+    const int M = g.N * g.OH * g.OW, Kd = g.R * g.S * g.C;
+    EpiStore<T> ep{(T*)y, g.KO, nullptr, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
+    launch_auto<T, ConvFwdA, PlainKC>(
+        [&](auto& a) { a.x = (const T*)x; a.g = g; a.rows = M; a.K = Kd; },
+        [&](auto& b) { b.p = (const T*)w; b.ld = Kd; b.rows = g.KO; b.K = Kd; }, ep, M, g.KO, Kd, 1, st);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+extern "C" int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride,
+                              int pad, const void* x, const void* w, void* y, void* stream) {
+    VTX_CHECK(x && w && y, VTX_ERR_ARG, "conv2d_fwd: null pointer");
+    ConvGeo g;
+    int rc = make_geo("conv2d_fwd", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
+    if (rc) return rc;
+    if (dtype == VTX_BF16) return conv_fwd_t<bf16_t>(g, x, w, y, nullptr, ACT_NONE, (hipStream_t)stream);
+    return conv_fwd_t<float>(g, x, w, y, nullptr, ACT_NONE, (hipStream_t)stream);
+}

@@ -1,0 +1,122 @@
+// Small HBM-bound helpers: column sums (bias gradients), elementwise add, GELU backward.
+#include "vtx_common.h"
+
+namespace {
+
+// out[c] += sum_r x[r][c]   (x: [R][ld] dtype, C columns).  Same geometry as the BN reductions.
+template <class T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ld, float* __restrict__ out,
+                                                     int R, int C, int TX, int rows_per_block) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+    const int c0 = (blockIdx.y * TX + tx) * VEC;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    float a[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a[j] = 0.f;
+    if (c0 < C)
+        for (int r = r0 + ty; r < r1; r += TY) {
+            Vec16<T> v; v.load(x + (long)r * ld + c0);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[j] += v.v[j];
+        }
+    __shared__ float red[256 * VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[(ty * TX + tx) * VEC + j] = a[j];
+    __syncthreads();
+    if (ty == 0 && c0 < C) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float s = 0.f;
+            for (int r = 0; r < TY; ++r) s += red[(r * TX + tx) * VEC + j];
+            atomicAdd(out + c0 + j, s);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                                                  long nvec) {
+    constexpr int VEC = Elem<T>::VEC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        Vec16<T> x, y; x.load(a + i * VEC); y.load(b + i * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) x.v[j] += y.v[j];
+        x.store(out + i * VEC);
+    }
+}
+
+// dh = dropout'(da) * gelu'(h)   (FFN: a = dropout(gelu(h)))
+template <class T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ da,
+                                                       T* __restrict__ dh, long nvec, Dropout drop) {
+    constexpr int VEC = Elem<T>::VEC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        Vec16<T> x, g; x.load(h + i * VEC); g.load(da + i * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g.v[j] = drop.apply(g.v[j], (uint64_t)(i * VEC + j)) * gelu_erf_grad(x.v[j]);
+        g.store(dh + i * VEC);
+    }
+}
+
+static int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int vtx_colsum_acc(int dtype, const void* x, long ld, float* out, int R, int C, void* stream) {
+    VTX_CHECK(x && out, VTX_ERR_ARG, "colsum_acc: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "colsum_acc: bad dtype");
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(R >= 0 && C > 0 && C % vec == 0 && ld % vec == 0, VTX_ERR_SHAPE, "colsum_acc: C and ld must be multiples of %d", vec);
+    if (R == 0) return VTX_OK;
+    const int cv = C / vec;
+    int TX = 1;
+    while (TX * 2 <= cv && TX < 256) TX *= 2;      // power of two <= min(cv, 256)
+    const int gy = vtx_cdiv(cv, TX), TY = 256 / TX;
+    int gx = 1024 / gy;
+    const int max_gx = vtx_cdiv(R, TY * 4);
+    if (gx > max_gx) gx = max_gx;
+    if (gx < 1) gx = 1;
+    const int rows = vtx_cdiv(R, gx);
+    gx = vtx_cdiv(R, rows);
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, R, C, TX, rows);
+    else
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, out, R, C, TX, rows);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+extern "C" int vtx_add(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
+    VTX_CHECK(a && b && out, VTX_ERR_ARG, "add: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "add: bad dtype");
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(n >= 0 && n % vec == 0, VTX_ERR_SHAPE, "add: n must be a multiple of %d", vec);
+    if (n == 0) return VTX_OK;
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / vec);
+    else
+        hipLaunchKernelGGL((add_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, n / vec);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+extern "C" int vtx_gelu_bwd(int dtype, const void* h, const void* da, void* dh, long n, float p_drop, uint64_t seed,
+                            void* stream) {
+    VTX_CHECK(h && da && dh, VTX_ERR_ARG, "gelu_bwd: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "gelu_bwd: bad dtype");
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(n >= 0 && n % vec == 0, VTX_ERR_SHAPE, "gelu_bwd: n must be a multiple of %d", vec);
+    if (n == 0) return VTX_OK;
+    Dropout d = make_dropout(p_drop, seed);
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (const bf16_t*)da, (bf16_t*)dh, n / vec, d);
+    else
+        hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)h, (const float*)da, (float*)dh, n / vec, d);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}

@@ -11,11 +11,11 @@ using namespace vtxg;
 
 namespace {
 
-template <class T>
+template <class T, class TO>
 int gemm_nt_t(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
               const float* bias, const void* residual, long ldr, void* preact, int act, float alpha,
               Dropout drop, hipStream_t st) {
-    EpiStore<T> ep{(T*)C, ldc, bias, (const T*)residual, ldr, (T*)preact, act, alpha, drop, M, N};
+    EpiStore<TO> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
     launch_auto<T, PlainKC, PlainKC>(
         [&](auto& a) { a.p = (const T*)A; a.ld = lda; a.rows = M; a.K = K; },
         [&](auto& b) { b.p = (const T*)B; b.ld = ldb; b.rows = N; b.K = K; }, ep, M, N, K, 1, st);
@@ -50,7 +50,7 @@ int vtx_pick_split_k(int M, int N, int K, int bk) {
 extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
                            long ldb, void* C, long ldc, const float* bias, const void* residual,
                            long ldr, void* preact, int act, float alpha, float p_drop, uint64_t seed,
-                           void* stream) {
+                           int out_f32, void* stream) {
     VTX_CHECK(A && B && C, VTX_ERR_ARG, "gemm_nt: null pointer");
     VTX_CHECK(M >= 0 && N > 0 && K > 0, VTX_ERR_ARG, "gemm_nt: bad shape %dx%dx%d", M, N, K);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
@@ -62,9 +62,11 @@ extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long l
     VTX_CHECK(aligned16(A) && aligned16(B) && aligned16(C), VTX_ERR_SHAPE, "gemm_nt: operands must be 16-byte aligned");
     if (M == 0) return VTX_OK;
     Dropout d = make_dropout(p_drop, seed);
+    if (dtype == VTX_BF16 && out_f32)
+        return gemm_nt_t<bf16_t, float>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
     if (dtype == VTX_BF16)
-        return gemm_nt_t<bf16_t>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
-    return gemm_nt_t<float>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
+        return gemm_nt_t<bf16_t, bf16_t>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
+    return gemm_nt_t<float, float>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
 }
 
 extern "C" int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, const void* B,

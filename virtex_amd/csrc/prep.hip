@@ -1,0 +1,105 @@
+// Layout / precision preparation kernels (HBM-bound plumbing of the step):
+//  * vtx_image_to_nhwc : fp32 NCHW image (the batch format of the reference collate function,
+//    /root/reference/virtex/data/datasets/captioning.py:79-100) -> NHWC dtype with the 3 input
+//    channels zero-padded to Cp (8), so the stem conv runs on the same implicit-GEMM kernel.
+//  * vtx_weight_prep   : fp32 master weight [KO][T][C] (T = R*S taps; 1 for linears) ->
+//    compute copy w[KO][T][Cp] and transposed copy wt[Cp][T][KO] (both `dtype`); the
+//    transposed copy is the B operand of every input-gradient GEMM.
+//  * vtx_cast          : fp32 -> dtype elementwise.
+#include "vtx_common.h"
+
+namespace {
+
+template <class T>
+__global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                            int N, int Cin, int HW, int Cp) {
+    const long total = (long)N * HW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / HW, p = i % HW;
+        for (int c = 0; c < Cp; ++c) {
+            const float v = c < Cin ? src[(n * Cin + c) * HW + p] : 0.f;
+            Elem<T>::st(dst + i * Cp + c, v);
+        }
+    }
+}
+
+// one 32x32 (ko x c) tile per block, for tap blockIdx.z
+template <class T>
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w32, T* __restrict__ w,
+                                                          T* __restrict__ wt, int KO, int Tn, int C, int Cp) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int ko = k0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (ko < KO && c < C) v = w32[((long)ko * Tn + t) * C + c];
+        tile[r][tx] = v;
+        if (w && ko < KO && c < Cp) Elem<T>::st(w + ((long)ko * Tn + t) * Cp + c, v);
+    }
+    __syncthreads();
+    if (wt) {
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r, ko = k0 + tx;
+            if (c < Cp && ko < KO) Elem<T>::st(wt + ((long)c * Tn + t) * KO + ko, tile[tx][r]);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        Elem<T>::st(dst + i, src[i]);
+}
+
+static int grid_for(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int vtx_image_to_nhwc(int dtype, const float* src, void* dst, int N, int Cin, int H, int W, int Cp,
+                                 void* stream) {
+    VTX_CHECK(src && dst, VTX_ERR_ARG, "image_to_nhwc: null pointer");
+    VTX_CHECK(N > 0 && Cin > 0 && Cp >= Cin && H > 0 && W > 0, VTX_ERR_SHAPE, "image_to_nhwc: bad shape");
+    const long total = (long)N * H * W;
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((image_to_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           src, (bf16_t*)dst, N, Cin, H * W, Cp);
+    else if (dtype == VTX_F32)
+        hipLaunchKernelGGL((image_to_nhwc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           src, (float*)dst, N, Cin, H * W, Cp);
+    else VTX_CHECK(false, VTX_ERR_DTYPE, "image_to_nhwc: bad dtype");
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+extern "C" int vtx_weight_prep(int dtype, const float* w32, void* w, void* wt, int KO, int T, int C, int Cp,
+                               void* stream) {
+    VTX_CHECK(w32 && (w || wt), VTX_ERR_ARG, "weight_prep: null pointer");
+    VTX_CHECK(KO > 0 && T > 0 && C > 0 && Cp >= C && T < 65536, VTX_ERR_SHAPE, "weight_prep: bad shape");
+    dim3 grid(vtx_cdiv(Cp, 32), vtx_cdiv(KO, 32), T), block(256);
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((weight_prep_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, w32, (bf16_t*)w,
+                           (bf16_t*)wt, KO, T, C, Cp);
+    else if (dtype == VTX_F32)
+        hipLaunchKernelGGL((weight_prep_kernel<float>), grid, block, 0, (hipStream_t)stream, w32, (float*)w,
+                           (float*)wt, KO, T, C, Cp);
+    else VTX_CHECK(false, VTX_ERR_DTYPE, "weight_prep: bad dtype");
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+extern "C" int vtx_cast_from_f32(int dtype, const float* src, void* dst, long n, void* stream) {
+    VTX_CHECK(src && dst && n >= 0, VTX_ERR_ARG, "cast: bad args");
+    if (n == 0) return VTX_OK;
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n);
+    else if (dtype == VTX_F32)
+        hipLaunchKernelGGL((cast_kernel<float>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, n);
+    else VTX_CHECK(false, VTX_ERR_DTYPE, "cast: bad dtype");
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}

@@ -53,23 +53,26 @@ c_long = _lib.ctypes.c_long
 
 
 def gemm_nt(a, b, bias=None, residual=None, act=ACT_NONE, want_preact=False, alpha=1.0,
-            p_drop=0.0, seed=0, out=None):
+            p_drop=0.0, seed=0, out=None, out_f32=False):
     """C[M,N] = dropout(act(alpha * a[M,K] @ b[N,K]^T + bias)) + residual.
     a, b: 2-D (row stride may exceed the row length).  Returns C (and preact if asked)."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and b.dtype == a.dtype
+    odt = torch.float32 if out_f32 else a.dtype
     if out is None:
-        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
-    pre = torch.empty(M, N, dtype=a.dtype, device=a.device) if want_preact else None
+        out = torch.empty(M, N, dtype=odt, device=a.device)
+    assert out.dtype == odt
+    pre = torch.empty(M, N, dtype=odt, device=a.device) if want_preact else None
     _chk(bias, "bias", torch.float32)
     if residual is not None:
-        assert residual.dim() == 2 and residual.stride(1) == 1 and residual.dtype == a.dtype
+        assert residual.dim() == 2 and residual.stride(1) == 1 and residual.dtype == odt
     call("vtx_gemm_nt", c_int(dtype_code(a.dtype)), c_int(M), c_int(N), c_int(K), ptr(a),
          c_long(a.stride(0)), ptr(b), c_long(b.stride(0)), ptr(out), c_long(out.stride(0)), ptr(bias),
          ptr(residual), c_long(residual.stride(0) if residual is not None else 0), ptr(pre),
-         c_int(act), c_float(alpha), c_float(p_drop), c_u64(seed), stream_ptr(a))
+         c_int(act), c_float(alpha), c_float(p_drop), c_u64(seed), c_int(1 if out_f32 else 0),
+         stream_ptr(a))
     return (out, pre) if want_preact else out
 
 
@@ -84,3 +87,216 @@ def gemm_tn_acc(a, b, out, alpha=1.0, split_k=0):
          c_long(a.stride(0)), ptr(b), c_long(b.stride(0)), ptr(out), c_long(out.stride(0)),
          c_float(alpha), c_int(split_k), stream_ptr(a))
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# NHWC convolutions.  x: (N,H,W,C) contiguous; w: (KO,R,S,C); wt: (C,R,S,KO).
+def _conv_out(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv2d_fwd(x, w, stride, pad):
+    N, H, W, C = x.shape
+    KO, R, S, C2 = w.shape
+    assert C2 == C and w.dtype == x.dtype
+    _chk(x, "x"); _chk(w, "w")
+    OH, OW = _conv_out(H, W, R, S, stride, pad)
+    y = torch.empty(N, OH, OW, KO, dtype=x.dtype, device=x.device)
+    call("vtx_conv2d_fwd", c_int(dtype_code(x.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
+         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(x), ptr(w), ptr(y), stream_ptr(x))
+    return y
+
+
+def conv2d_dgrad(dy, wt, x_shape, stride, pad):
+    N, H, W, C = x_shape
+    C2, R, S, KO = wt.shape
+    assert C2 == C and dy.shape[-1] == KO and wt.dtype == dy.dtype
+    _chk(dy, "dy"); _chk(wt, "wt")
+    dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    call("vtx_conv2d_dgrad", c_int(dtype_code(dy.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
+         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(dy), ptr(wt), ptr(dx), stream_ptr(dy))
+    return dx
+
+
+def conv2d_wgrad(x, dy, dw, stride, pad, split_k=0):
+    """dw (KO,R,S,C) fp32 += weight gradient."""
+    N, H, W, C = x.shape
+    KO, R, S, C2 = dw.shape
+    assert C2 == C and dy.shape[-1] == KO and dw.dtype == torch.float32
+    _chk(x, "x"); _chk(dy, "dy", x.dtype); _chk(dw, "dw")
+    call("vtx_conv2d_wgrad", c_int(dtype_code(x.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
+         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(x), ptr(dy), ptr(dw), c_int(split_k), stream_ptr(x))
+    return dw
+
+
+# ---------------------------------------------------------------------------------------
+# BatchNorm (training) on NHWC, fused ReLU / residual.  `ws` = zeroed fp32 workspace slice.
+def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, ws, eps=1e-5, momentum=0.1, relu=True,
+           residual=None):
+    C = x.shape[-1]
+    P = x.numel() // C
+    _chk(x, "x"); _chk(residual, "residual", x.dtype)
+    assert ws.dtype == torch.float32 and ws.numel() >= 4 * C
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    call("vtx_bn_fwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(residual), ptr(gamma), ptr(beta),
+         ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mean), ptr(rstd), ptr(ws), c_int(P),
+         c_int(C), c_float(eps), c_float(momentum), c_int(1 if relu else 0), stream_ptr(x))
+    return y, mean, rstd
+
+
+def bn_bwd(x, dy, ymask, gamma, mean, rstd, dgamma, dbeta, ws, want_dz=False):
+    C = x.shape[-1]
+    P = x.numel() // C
+    _chk(x, "x"); _chk(dy, "dy", x.dtype); _chk(ymask, "ymask", x.dtype)
+    assert ws.dtype == torch.float32 and ws.numel() >= 5 * C
+    dx = torch.empty_like(x)
+    dz = torch.empty_like(x) if want_dz else None
+    call("vtx_bn_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(dy), ptr(ymask), ptr(gamma), ptr(mean),
+         ptr(rstd), ptr(dx), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(P), c_int(C), stream_ptr(x))
+    return (dx, dz) if want_dz else dx
+
+
+def maxpool_fwd(x):
+    N, H, W, C = x.shape
+    _chk(x, "x")
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
+    arg = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
+    call("vtx_maxpool3x3s2_fwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(y), ptr(arg), c_int(N), c_int(H),
+         c_int(W), c_int(C), stream_ptr(x))
+    return y, arg
+
+
+def maxpool_bwd(dy, arg, x_shape):
+    N, H, W, C = x_shape
+    _chk(dy, "dy")
+    dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    call("vtx_maxpool3x3s2_bwd", c_int(dtype_code(dy.dtype)), ptr(dy), ptr(arg), ptr(dx), c_int(N), c_int(H),
+         c_int(W), c_int(C), stream_ptr(dy))
+    return dx
+
+
+def image_to_nhwc(image, dtype, cpad=8):
+    """fp32 NCHW (B,3,H,W) -> NHWC `dtype` with channels zero-padded to `cpad`."""
+    N, Cin, H, W = image.shape
+    _chk(image, "image", torch.float32)
+    out = torch.empty(N, H, W, cpad, dtype=dtype, device=image.device)
+    call("vtx_image_to_nhwc", c_int(dtype_code(dtype)), ptr(image), ptr(out), c_int(N), c_int(Cin), c_int(H),
+         c_int(W), c_int(cpad), stream_ptr(image))
+    return out
+
+
+def weight_prep(w32, dtype, cpad=None, want_w=True, want_wt=True):
+    """fp32 [KO, T, C] (or [KO, C]) -> (w [KO,T,Cp], wt [Cp,T,KO]) in `dtype`."""
+    if w32.dim() == 2:
+        w32 = w32.unsqueeze(1)
+    KO, T, C = w32.shape
+    _chk(w32, "w32", torch.float32)
+    Cp = cpad or C
+    w = torch.empty(KO, T, Cp, dtype=dtype, device=w32.device) if want_w else None
+    wt = torch.empty(Cp, T, KO, dtype=dtype, device=w32.device) if want_wt else None
+    call("vtx_weight_prep", c_int(dtype_code(dtype)), ptr(w32), ptr(w), ptr(wt), c_int(KO), c_int(T), c_int(C),
+         c_int(Cp), stream_ptr(w32))
+    return w, wt
+
+
+def cast_from_f32(src, dtype):
+    _chk(src, "src", torch.float32)
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    call("vtx_cast_from_f32", c_int(dtype_code(dtype)), ptr(src), ptr(out), c_long(src.numel()), stream_ptr(src))
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+def embedding_fwd(tokens, words, positions, gamma, beta, dtype, padding_idx=0, eps=1e-8, p_drop=0.0, seed=0):
+    B, T = tokens.shape
+    V, H = words.shape
+    _chk(tokens, "tokens", torch.int64); _chk(words, "words", torch.float32); _chk(positions, "positions", torch.float32)
+    assert positions.shape[0] >= T
+    out = torch.empty(B, T, H, dtype=dtype, device=tokens.device)
+    mean = torch.empty(B * T, dtype=torch.float32, device=tokens.device)
+    rstd = torch.empty(B * T, dtype=torch.float32, device=tokens.device)
+    call("vtx_embedding_fwd", c_int(dtype_code(dtype)), ptr(tokens), ptr(words), ptr(positions), ptr(gamma),
+         ptr(beta), ptr(out), ptr(mean), ptr(rstd), c_int(B), c_int(T), c_int(H), c_int(V), c_int(padding_idx),
+         c_float(eps), c_float(p_drop), c_u64(seed), stream_ptr(tokens))
+    return out, mean, rstd
+
+
+def embedding_bwd(tokens, words, positions, gamma, mean, rstd, dout, dwords, dpositions, dgamma, dbeta,
+                  padding_idx=0, p_drop=0.0, seed=0):
+    B, T = tokens.shape
+    V, H = words.shape
+    _chk(dout, "dout")
+    call("vtx_embedding_bwd", c_int(dtype_code(dout.dtype)), ptr(tokens), ptr(words), ptr(positions), ptr(gamma),
+         ptr(mean), ptr(rstd), ptr(dout), ptr(dwords), ptr(dpositions), ptr(dgamma), ptr(dbeta), c_int(B),
+         c_int(T), c_int(H), c_int(V), c_int(padding_idx), c_float(p_drop), c_u64(seed), stream_ptr(tokens))
+
+
+# ---------------------------------------------------------------------------------------
+def attention_fwd(q, k, v, B, heads, T, S, causal, key_lengths=None, p_drop=0.0, seed=0):
+    """q: [B*T, >=heads*64] view, k/v: [B*S, ...] views (unit column stride). Returns o [B*T, heads*64]."""
+    for t in (q, k, v):
+        assert t.dim() == 2 and t.stride(1) == 1
+    o = torch.empty(B * T, heads * 64, dtype=q.dtype, device=q.device)
+    call("vtx_attention_fwd", c_int(dtype_code(q.dtype)), ptr(q), c_long(q.stride(0)), ptr(k), c_long(k.stride(0)),
+         ptr(v), c_long(v.stride(0)), ptr(o), c_long(o.stride(0)), c_int(B), c_int(heads), c_int(T), c_int(S),
+         c_int(64), c_int(1 if causal else 0), ptr(key_lengths), c_float(p_drop), c_u64(seed), stream_ptr(q))
+    return o
+
+
+def attention_bwd(q, k, v, dout, dq, dk, dv, B, heads, T, S, causal, key_lengths=None, p_drop=0.0, seed=0):
+    for t in (q, k, v, dout, dq, dk, dv):
+        assert t.dim() == 2 and t.stride(1) == 1
+    call("vtx_attention_bwd", c_int(dtype_code(q.dtype)), ptr(q), c_long(q.stride(0)), ptr(k), c_long(k.stride(0)),
+         ptr(v), c_long(v.stride(0)), ptr(dout), c_long(dout.stride(0)), ptr(dq), c_long(dq.stride(0)), ptr(dk),
+         c_long(dk.stride(0)), ptr(dv), c_long(dv.stride(0)), c_int(B), c_int(heads), c_int(T), c_int(S), c_int(64),
+         c_int(1 if causal else 0), ptr(key_lengths), c_float(p_drop), c_u64(seed), stream_ptr(q))
+
+
+# ---------------------------------------------------------------------------------------
+def cross_entropy_fwd(logits, targets, ignore_index=0):
+    """logits fp32 [R, V]; targets int64 [R]. Returns (loss_and_count[2], lse[R])."""
+    R, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    _chk(targets, "targets", torch.int64)
+    lse = torch.empty(R, dtype=torch.float32, device=logits.device)
+    row_loss = torch.empty(R, dtype=torch.float32, device=logits.device)
+    lc = torch.empty(2, dtype=torch.float32, device=logits.device)
+    call("vtx_cross_entropy_fwd", ptr(logits), c_long(logits.stride(0)), ptr(targets), ptr(lse), ptr(row_loss),
+         ptr(lc), c_int(R), c_int(V), c_int(ignore_index), stream_ptr(logits))
+    return lc, lse
+
+
+def cross_entropy_bwd(logits, targets, lse, lc, grad_out, dtype, ignore_index=0):
+    R, V = logits.shape
+    _chk(grad_out, "grad_out", torch.float32)
+    d = torch.empty(R, V, dtype=dtype, device=logits.device)
+    call("vtx_cross_entropy_bwd", c_int(dtype_code(dtype)), ptr(logits), c_long(logits.stride(0)), ptr(targets),
+         ptr(lse), ptr(lc), ptr(grad_out), ptr(d), c_long(V), c_int(R), c_int(V), c_int(ignore_index),
+         stream_ptr(logits))
+    return d
+
+
+def colsum_acc(x, out):
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
+    call("vtx_colsum_acc", c_int(dtype_code(x.dtype)), ptr(x), c_long(x.stride(0)), ptr(out), c_int(x.shape[0]),
+         c_int(x.shape[1]), stream_ptr(x))
+    return out
+
+
+def add(a, b, out=None):
+    _chk(a, "a"); _chk(b, "b", a.dtype)
+    if out is None:
+        out = torch.empty_like(a)
+    call("vtx_add", c_int(dtype_code(a.dtype)), ptr(a), ptr(b), ptr(out), c_long(a.numel()), stream_ptr(a))
+    return out
+
+
+def gelu_bwd(h, da, p_drop=0.0, seed=0):
+    _chk(h, "h"); _chk(da, "da", h.dtype)
+    dh = torch.empty_like(h)
+    call("vtx_gelu_bwd", c_int(dtype_code(h.dtype)), ptr(h), ptr(da), ptr(dh), c_long(h.numel()), c_float(p_drop),
+         c_u64(seed), stream_ptr(h))
+    return dh
