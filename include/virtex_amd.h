@@ -78,7 +78,8 @@ int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, con
 int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
                    const void* x, const void* w, void* y, void* stream);
 int vtx_conv2d_dgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
-                     const void* dy, const void* wt, void* dx, void* stream);
+                     const void* dy, const void* wt, void* dx, const void* residual /*nullable: dx += */,
+                     void* stream);
 int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
                      const void* x, const void* dy, float* dw, int split_k, void* stream);
 

@@ -36,7 +36,7 @@ CASES = {
         dict(textual="transdec_postnorm::L1_H1024_A16_F4096", vocab_size=10000),
         dict(batch_size=2, image_size=224, max_len=30, vocab_size=10000, seed=1, ragged=True)),
     "r50_l2_h128_b3_small": (
-        dict(textual="transdec_postnorm::L2_H128_A4_F256", vocab_size=1000),
+        dict(textual="transdec_postnorm::L2_H128_A2_F256", vocab_size=1000),
         dict(batch_size=3, image_size=64, max_len=12, vocab_size=1000, seed=2, ragged=True)),
 }
 

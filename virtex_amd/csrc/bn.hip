@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         a[j] = b[j] = 0.f;
-        mu[j] = BWD ? mean[c0 + j] : 0.f;
+        // forward: shift by the channel's first sample (shifted-data variance: no catastrophic
+        // cancellation in E[x^2]-E[x]^2 when |mean| >> std); backward: the saved statistics
+        mu[j] = BWD ? mean[c0 + j] : Elem<T>::ld(x + c0 + j);
         rs[j] = BWD ? rstd[c0 + j] : 0.f;
     }
     for (int p = p0 + ty; p < p1; p += TY) {
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
             for (int j = 0; j < VEC; ++j) { a[j] += g.v[j]; b[j] += g.v[j] * (xv.v[j] - mu[j]) * rs[j]; }
         } else {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { a[j] += xv.v[j]; b[j] += xv.v[j] * xv.v[j]; }
+            for (int j = 0; j < VEC; ++j) { const float d = xv.v[j] - mu[j]; a[j] += d; b[j] += d * d; }
         }
     }
     __shared__ float red[2][256 * VEC];
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     }
 }
 
-__global__ void bn_fwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+template <class T>
+__global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ mean,
                                        float* __restrict__ rstd, float* __restrict__ scale,
                                        float* __restrict__ shift, float* __restrict__ running_mean,
@@ -77,9 +80,10 @@ __global__ void bn_fwd_finalize_kernel(const float* __restrict__ sums, const flo
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    const float m = sums[c] / (float)P;
-    float var = sums[C + c] / (float)P - m * m;
+    const float ms = sums[c] / (float)P;              // mean of (x - x[0][c])
+    float var = sums[C + c] / (float)P - ms * ms;
     var = var > 0.f ? var : 0.f;
+    const float m = Elem<T>::ld(x + c) + ms;
     const float r = rsqrtf(var + eps);
     mean[c] = m; rstd[c] = r;
     const float sc = gamma[c] * r;
@@ -93,8 +97,9 @@ __global__ void bn_fwd_finalize_kernel(const float* __restrict__ sums, const flo
 
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ residual,
+                                                       const float* __restrict__ mean,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, T* __restrict__ y,
+                                                       const float* __restrict__ beta, T* __restrict__ y,
                                                        long nvec, int C, int relu) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         const int c0 = (int)(i % cv) * VEC;
         Vec16<T> v; v.load(x + i * VEC);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v.v[j] = v.v[j] * scale[c0 + j] + shift[c0 + j];
+        for (int j = 0; j < VEC; ++j) v.v[j] = (v.v[j] - mean[c0 + j]) * scale[c0 + j] + beta[c0 + j];  // centred first: no cancellation
         if (residual) {
             Vec16<T> r; r.load(residual + i * VEC);
 #pragma unroll
@@ -198,14 +203,18 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     else
         hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, sums, gamma, beta, save_mean,
-                       save_rstd, scale, shift, running_mean, running_var, num_batches_tracked, P, C, eps, momentum);
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta,
+                           save_mean, save_rstd, scale, shift, running_mean, running_var, num_batches_tracked, P, C, eps, momentum);
+    else
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, (const float*)x, sums, gamma, beta,
+                           save_mean, save_rstd, scale, shift, running_mean, running_var, num_batches_tracked, P, C, eps, momentum);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)residual, scale, shift, (bf16_t*)y, nvec, C, relu);
+                           (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
     else
         hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
-                           (const float*)residual, scale, shift, (float*)y, nvec, C, relu);
+                           (const float*)residual, save_mean, scale, beta, (float*)y, nvec, C, relu);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -2,15 +2,17 @@
 //   dx[n][ih][iw][ci] = sum_{kh,kw,ko} dy[n][(ih+p-kh)/s][(iw+p-kw)/s][ko] * wt[ci][kh][kw][ko]
 // (terms exist only where the divisions are exact and in range).  GEMM view: M = N*H*W,
 // N = C, K = R*S*KO; `wt` is the weight pre-transposed to [C][R][S][KO] by vtx_weight_prep.
+// `residual` (optional, same shape as dx) is added in the epilogue: the gradient join of a
+// bottleneck's two branches costs no extra pass.
 // Replaces the input-gradient half of aten::convolution_backward.
 #include "conv_common.h"
 
 using namespace vtxg;
 
 template <class T>
-static int conv_dgrad_t(const ConvGeo& g, const void* dy, const void* wt, void* dx, hipStream_t st) {
+static int conv_dgrad_t(const ConvGeo& g, const void* dy, const void* wt, void* dx, const void* residual, hipStream_t st) {
     const int M = g.N * g.H * g.W, Kd = g.R * g.S * g.KO;
-    EpiStore<T> ep{(T*)dx, g.C, nullptr, nullptr, 0, nullptr, ACT_NONE, 1.f, make_dropout(0.f, 0), M, g.C};
+    EpiStore<T> ep{(T*)dx, g.C, nullptr, (const T*)residual, g.C, nullptr, ACT_NONE, 1.f, make_dropout(0.f, 0), M, g.C};
     launch_auto<T, ConvDgradA, PlainKC>(
         [&](auto& a) { a.dy = (const T*)dy; a.g = g; a.rows = M; a.K = Kd; },
         [&](auto& b) { b.p = (const T*)wt; b.ld = Kd; b.rows = g.C; b.K = Kd; }, ep, M, g.C, Kd, 1, st);
@@ -19,11 +21,11 @@ static int conv_dgrad_t(const ConvGeo& g, const void* dy, const void* wt, void* 
 }
 
 extern "C" int vtx_conv2d_dgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride,
-                                int pad, const void* dy, const void* wt, void* dx, void* stream) {
+                                int pad, const void* dy, const void* wt, void* dx, const void* residual, void* stream) {
     VTX_CHECK(dy && wt && dx, VTX_ERR_ARG, "conv2d_dgrad: null pointer");
     ConvGeo g;
     int rc = make_geo("conv2d_dgrad", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
     if (rc) return rc;
-    if (dtype == VTX_BF16) return conv_dgrad_t<bf16_t>(g, dy, wt, dx, (hipStream_t)stream);
-    return conv_dgrad_t<float>(g, dy, wt, dx, (hipStream_t)stream);
+    if (dtype == VTX_BF16) return conv_dgrad_t<bf16_t>(g, dy, wt, dx, residual, (hipStream_t)stream);
+    return conv_dgrad_t<float>(g, dy, wt, dx, residual, (hipStream_t)stream);
 }

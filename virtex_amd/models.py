@@ -1,0 +1,156 @@
+"""MI355X-native bicaptioning model: drop-in for the reference's ``CaptioningModel`` family
+(/root/reference/virtex/models/captioning.py:13-283).
+
+Same constructor, attribute tree (``visual``, ``textual``, ``backward_textual``, ``loss``,
+``padding_idx``, ``sos_index``, ``eos_index``, ``decoder``), weight tying and output dict:
+``{"loss", "loss_components": {"captioning_forward", "captioning_backward"}, ["predictions"]}``.
+
+Training takes a fused path the reference does not have: decoder hidden states go straight
+into the tied-projection + cross-entropy op (`_TiedCrossEntropyFn`) whose fp32 logits live
+only between two kernels, never as an autograd-visible (B,T,V) tensor.  The eval branch and
+``decoding_step`` keep the reference semantics through ``textual(...)`` which returns logits.
+"""
+import copy
+import functools
+from typing import Any, Dict
+
+import torch
+from torch import nn
+
+from . import ops
+from .modules.textual_heads import TextualHead
+from .modules.visual_backbones import VisualBackbone
+
+
+class _TiedCrossEntropyFn(torch.autograd.Function):
+    """mean_{tok[b,t+1] != pad} CE(hidden[b,t] @ words^T + bias, tok[b,t+1])
+    (reference: captioning.py:111-114 on textual_heads.py:277 logits)."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, tokens, padding_idx):
+        B, T, H = hidden.shape
+        dt = hidden.dtype
+        V = weight.shape[0]
+        # row (b,t) predicts token t+1; the last step has no target -> ignore
+        targets = torch.full((B, T), padding_idx, dtype=torch.int64, device=tokens.device)
+        targets[:, :-1] = tokens[:, 1:]
+        targets = targets.view(-1)
+        w = weight.detach() if dt == torch.float32 else ops.cast_from_f32(weight.detach(), dt)
+        h2 = hidden.reshape(B * T, H)
+        logits = ops.gemm_nt(h2, w, bias=bias.detach(), out_f32=True)
+        lc, lse = ops.cross_entropy_fwd(logits, targets, padding_idx)
+        ctx.save_for_backward(h2, weight, targets, logits, lse, lc)
+        ctx.cfg = (B, T, H, V, padding_idx, dt)
+        return lc[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        h2, weight, targets, logits, lse, lc = ctx.saved_tensors
+        B, T, H, V, padding_idx, dt = ctx.cfg
+        g = gout.reshape(1).to(torch.float32).contiguous()
+        d = ops.cross_entropy_bwd(logits, targets, lse, lc, g, dt, padding_idx)      # (B*T, V) compute dtype
+        _, wt = ops.weight_prep(weight.detach(), dt, want_w=False)
+        dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
+        dW = torch.zeros_like(weight)
+        ops.gemm_tn_acc(d, h2, dW)
+        db = torch.zeros(V, dtype=torch.float32, device=d.device)
+        ops.colsum_acc(d, db)
+        return dh, dW, db, None, None
+
+
+class CaptioningModel(nn.Module):
+    def __init__(self, visual: VisualBackbone, textual: TextualHead, caption_backward: bool = False,
+                 sos_index: int = 1, eos_index: int = 2, decoder: Any = None):
+        super().__init__()
+        self.visual = visual
+        self.textual = textual
+        self.padding_idx = self.textual.padding_idx
+        self.caption_backward = caption_backward
+        if self.caption_backward:
+            self.backward_textual = copy.deepcopy(self.textual)
+            self.backward_textual.visual_projection = self.textual.visual_projection
+            self.backward_textual.embedding = self.textual.embedding
+            self.backward_textual.output = self.textual.output
+        self.sos_index = sos_index
+        self.eos_index = eos_index
+        self.decoder = decoder
+        self.loss = nn.CrossEntropyLoss(ignore_index=self.padding_idx)  # kept for API parity
+
+    def _head_loss(self, head, visual_features, tokens, lengths):
+        hidden = head.features(visual_features, tokens, lengths)
+        return _TiedCrossEntropyFn.apply(hidden, head.output.weight, head.output.bias, tokens,
+                                         self.padding_idx)
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        visual_features = self.visual(batch["image"])
+        batch_size = visual_features.size(0)
+        if "caption_tokens" in batch:
+            caption_tokens = batch["caption_tokens"]
+            caption_lengths = batch["caption_lengths"]
+            if self.training:
+                loss = self._head_loss(self.textual, visual_features, caption_tokens, caption_lengths)
+            else:
+                output_logits = self.textual(visual_features, caption_tokens, caption_lengths)
+                loss = _logits_loss(output_logits, caption_tokens, self.padding_idx)
+            output_dict: Dict[str, Any] = {
+                "loss": loss, "loss_components": {"captioning_forward": loss.clone().detach()}}
+            if self.caption_backward:
+                backward_caption_tokens = batch["noitpac_tokens"]
+                if self.training:
+                    backward_loss = self._head_loss(self.backward_textual, visual_features,
+                                                    backward_caption_tokens, caption_lengths)
+                else:
+                    backward_loss = _logits_loss(
+                        self.backward_textual(visual_features, backward_caption_tokens, caption_lengths),
+                        backward_caption_tokens, self.padding_idx)
+                output_dict["loss"] = output_dict["loss"] + backward_loss
+                output_dict["loss_components"].update(captioning_backward=backward_loss.clone().detach())
+            if not self.training:
+                output_dict["predictions"] = torch.argmax(output_logits, dim=-1)
+        else:
+            if self.decoder is None:
+                raise ValueError("Decoder for predicting captions is missing!")
+            start_predictions = visual_features.new_full((batch_size,), self.sos_index).long()
+            decoding_step = functools.partial(self.decoding_step, visual_features)
+            predicted_caption, _ = self.decoder.search(start_predictions, decoding_step)
+            output_dict = {"predictions": predicted_caption}
+        return output_dict
+
+    def decoding_step(self, visual_features: torch.Tensor, partial_captions: torch.Tensor) -> torch.Tensor:
+        """Next-token logits for (possibly beam-expanded) partial captions
+        (reference: captioning.py:165-213)."""
+        batch_size, channels, height, width = visual_features.size()
+        beam_size = int(partial_captions.size(0) / batch_size)
+        if beam_size > 1:
+            visual_features = visual_features.unsqueeze(1).repeat(1, beam_size, 1, 1, 1)
+            visual_features = visual_features.view(batch_size * beam_size, channels, height, width)
+        caption_lengths = torch.ones_like(partial_captions)
+        if len(caption_lengths.size()) == 2:
+            caption_lengths = caption_lengths.sum(1)
+        else:
+            partial_captions = partial_captions.unsqueeze(1)
+        logits = self.textual(visual_features, partial_captions, caption_lengths)
+        return logits[:, -1, :]
+
+
+def _logits_loss(logits, tokens, padding_idx):
+    B, T, V = logits.shape
+    targets = tokens[:, 1:].contiguous().view(-1)
+    lc, _ = ops.cross_entropy_fwd(logits[:, :-1].contiguous().view(-1, V), targets, padding_idx)
+    return lc[0].clone()
+
+
+class ForwardCaptioningModel(CaptioningModel):
+    def __init__(self, visual, textual, sos_index=1, eos_index=2, decoder=None):
+        super().__init__(visual, textual, sos_index=sos_index, eos_index=eos_index,
+                         caption_backward=False, decoder=decoder)
+
+
+class BidirectionalCaptioningModel(CaptioningModel):
+    def __init__(self, visual, textual, sos_index=1, eos_index=2, decoder=None):
+        super().__init__(visual, textual, sos_index=sos_index, eos_index=eos_index,
+                         caption_backward=True, decoder=decoder)
+
+
+# Convenient handle, as in the reference (captioning.py:282-283).
+VirTexModel = BidirectionalCaptioningModel

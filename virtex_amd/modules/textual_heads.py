@@ -1,0 +1,339 @@
+"""MI355X-native textual head: drop-ins for the reference's ``WordAndPositionalEmbedding``
+(/root/reference/virtex/modules/embedding.py:8-86) and ``TransformerDecoderTextualHead``
+(/root/reference/virtex/modules/textual_heads.py:98-292).
+
+Same constructor arguments, same attribute tree and parameter names
+(``visual_projection.*``, ``embedding.{words,positions,layer_norm}.*``,
+``transformer.layers.{l}.{self_attn,multihead_attn,linear1,linear2,norm1,norm2,norm3}.*``,
+``output.*`` with ``output.weight is embedding.words.weight``), re-assignable
+``visual_projection`` / ``embedding`` / ``output`` and ``copy.deepcopy``-able, as
+``CaptioningModel.__init__`` requires (/root/reference/virtex/models/captioning.py:57-63).
+
+``nn.Linear`` / ``nn.Embedding`` / ``nn.TransformerDecoder`` objects appear below ONLY as
+parameter containers (they give the reference's state-dict keys for free); their forward
+methods are never called.  All arithmetic is a hand-scheduled sequence of C-ABI kernel launches:
+MFMA GEMMs with fused bias/GELU/dropout epilogues, one fused attention kernel per
+(batch, head), fused residual+dropout+LayerNorm, fused embedding gather+LayerNorm.
+"""
+import itertools
+
+import torch
+from torch import nn
+
+from .. import ops
+
+_seed_counter = itertools.count(1)
+
+
+def next_dropout_seed() -> int:
+    """Host-side counter mixed with torch's seed: deterministic given torch.manual_seed."""
+    return (torch.initial_seed() * 1000003 + next(_seed_counter) * 7919) & 0x7FFFFFFFFFFFFFFF
+
+
+class WordAndPositionalEmbedding(nn.Module):
+    def __init__(self, vocab_size: int, hidden_size: int, dropout: float = 0.0,
+                 max_caption_length: int = 30, padding_idx: int = 0):
+        super().__init__()
+        self.vocab_size, self.padding_idx = vocab_size, padding_idx
+        self.words = nn.Embedding(vocab_size, hidden_size, padding_idx=padding_idx)
+        self.positions = nn.Embedding(max_caption_length, hidden_size)
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-8, elementwise_affine=True)
+        self.dropout = nn.Dropout(p=dropout)
+        self.compute_dtype = torch.bfloat16
+
+    def forward(self, tokens: torch.Tensor) -> torch.Tensor:
+        p = self.dropout.p if self.training else 0.0
+        return _EmbeddingFn.apply(tokens, self.words.weight, self.positions.weight, self.layer_norm.weight,
+                                  self.layer_norm.bias, self.padding_idx, self.layer_norm.eps, p,
+                                  self.compute_dtype)
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens, words, positions, gamma, beta, padding_idx, eps, p, dtype):
+        tokens = tokens.contiguous()
+        seed = next_dropout_seed()
+        out, mean, rstd = ops.embedding_fwd(tokens, words.detach(), positions.detach(), gamma.detach(),
+                                            beta.detach(), dtype, padding_idx, eps, p, seed)
+        ctx.save_for_backward(tokens, words, positions, gamma, mean, rstd)
+        ctx.cfg = (padding_idx, p, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        tokens, words, positions, gamma, mean, rstd = ctx.saved_tensors
+        padding_idx, p, seed = ctx.cfg
+        dw, dp = torch.zeros_like(words), torch.zeros_like(positions)
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        ops.embedding_bwd(tokens, words.detach(), positions.detach(), gamma.detach(), mean, rstd,
+                          dout.contiguous(), dw, dp, dg, db, padding_idx, p, seed)
+        return None, dw, dp, dg, db, None, None, None, None
+
+
+class TextualHead(nn.Module):
+    """Base class (reference: virtex/modules/textual_heads.py:15-43)."""
+
+    def __init__(self, visual_feature_size: int, vocab_size: int, hidden_size: int):
+        super().__init__()
+        self.visual_feature_size = visual_feature_size
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+
+    @property
+    def textual_feature_size(self):
+        return self.hidden_size
+
+
+class TransformerDecoderTextualHead(TextualHead):
+    def __init__(self, visual_feature_size: int, vocab_size: int, hidden_size: int, num_layers: int,
+                 attention_heads: int, feedforward_size: int, dropout: float = 0.1,
+                 norm_first: bool = False, mask_future_positions: bool = True,
+                 max_caption_length: int = 30, padding_idx: int = 0,
+                 compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__(visual_feature_size, vocab_size, hidden_size)
+        if norm_first:
+            raise NotImplementedError("pre-norm decoder (transdec_prenorm) is outside the bicaptioning "
+                                      "hot path; only the post-norm variant is implemented")
+        if hidden_size % attention_heads != 0 or hidden_size // attention_heads != 64:
+            raise ValueError("the fused attention kernel needs head_dim == 64 (H/A)")
+        self.num_layers, self.attention_heads = num_layers, attention_heads
+        self.feedforward_size, self.dropout = feedforward_size, dropout
+        self.mask_future_positions, self.padding_idx = mask_future_positions, padding_idx
+        self.compute_dtype = compute_dtype
+
+        self.visual_projection = nn.Linear(visual_feature_size, self.textual_feature_size)
+        self.embedding = WordAndPositionalEmbedding(vocab_size, self.textual_feature_size, dropout=dropout,
+                                                    max_caption_length=max_caption_length,
+                                                    padding_idx=padding_idx)
+        self.embedding.compute_dtype = compute_dtype
+        self.transformer = nn.TransformerDecoder(
+            nn.TransformerDecoderLayer(self.textual_feature_size, attention_heads,
+                                       dim_feedforward=feedforward_size, dropout=dropout, activation="gelu",
+                                       batch_first=True, norm_first=False),
+            num_layers=num_layers, norm=None)
+        self.apply(self._init_weights)
+        self.output = nn.Linear(self.textual_feature_size, vocab_size)
+        self.output.weight = self.embedding.words.weight
+
+    @staticmethod
+    def _init_weights(module):
+        # N(0, 0.02) for Linear / MHA / Embedding weights; biases untouched
+        # (reference: textual_heads.py:202-214)
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+        elif isinstance(module, nn.MultiheadAttention):
+            module.in_proj_weight.data.normal_(mean=0.0, std=0.02)
+            module.out_proj.weight.data.normal_(mean=0.0, std=0.02)
+        elif isinstance(module, nn.Embedding):
+            module.weight.data.normal_(mean=0.0, std=0.02)
+            if module.padding_idx is not None:
+                module.weight.data[module.padding_idx].zero_()
+
+    # -- parameter order shared by forward/backward -------------------------------------
+    def _layer_params(self, layer):
+        return [layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
+                layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
+                layer.norm1.weight, layer.norm1.bias,
+                layer.multihead_attn.in_proj_weight, layer.multihead_attn.in_proj_bias,
+                layer.multihead_attn.out_proj.weight, layer.multihead_attn.out_proj.bias,
+                layer.norm2.weight, layer.norm2.bias,
+                layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+                layer.norm3.weight, layer.norm3.bias]
+
+    def features(self, visual_features, caption_tokens, caption_lengths):
+        """(B,C,h,w) visual grid + (B,T) tokens -> decoder hidden states (B,T,H) in compute dtype."""
+        emb = self.embedding
+        emb.compute_dtype = self.compute_dtype
+        x0 = emb(caption_tokens)
+        params = [self.visual_projection.weight, self.visual_projection.bias]
+        for layer in self.transformer.layers:
+            params += self._layer_params(layer)
+        p = self.dropout if self.training else 0.0
+        return _DecoderFn.apply(visual_features, x0, caption_lengths, self, p, *params)
+
+    def forward(self, visual_features, caption_tokens, caption_lengths):
+        """Returns (B,T,V) fp32 logits, like the reference (textual_heads.py:216-278)."""
+        h = self.features(visual_features, caption_tokens, caption_lengths)
+        return _OutputProjectionFn.apply(h, self.output.weight, self.output.bias)
+
+    @staticmethod
+    def make_future_mask(size, dtype, device):
+        """Kept for API parity (reference :280-292); the fused attention kernel applies the
+        causal mask arithmetically and never materialises it."""
+        return torch.triu(torch.full((size, size), float("-inf"), dtype=dtype, device=device), diagonal=1)
+
+
+def _nhwc_rows(visual_features, dtype):
+    """(B,C,h,w) logical -> ([B*h*w, C] row-major view, B, S).  Zero-copy for NHWC-physical input."""
+    B, C, h, w = visual_features.shape
+    m = visual_features.permute(0, 2, 3, 1)
+    if m.dtype != dtype or not m.is_contiguous():
+        m = m.to(dtype).contiguous()
+    return m.view(B * h * w, C), B, h * w
+
+
+class _DecoderFn(torch.autograd.Function):
+    """visual_projection + L post-norm decoder layers (reference: textual_heads.py:240-275 and
+    torch/nn/modules/transformer.py:1143-1199), forward and hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, visual_features, x0, lengths, head, p, *params):
+        dt = head.compute_dtype
+        A = head.attention_heads
+        H = head.hidden_size
+        mem_in, B, S = _nhwc_rows(visual_features, dt)
+        T = x0.shape[1]
+        x = x0.reshape(B * T, H)
+        lengths = lengths.contiguous()
+        Wv32, bv = params[0].detach(), params[1].detach()
+        Wv, Wv_t = ops.weight_prep(Wv32, dt)
+        Wv, Wv_t = Wv.view(H, -1), Wv_t.view(-1, H)
+        mem = ops.gemm_nt(mem_in, Wv, bias=bv)                       # (B*S, H)
+        saved_layers = []
+        for li in range(head.num_layers):
+            P = [t.detach() for t in params[2 + 18 * li: 2 + 18 * (li + 1)]]
+            (Win, bin_, Wo, bo, g1, b1, Win2, bin2, Wo2, bo2, g2, b2, W1, bf1, W2, bf2, g3, b3) = P
+            seeds = [next_dropout_seed() for _ in range(7)]
+            cw = {}
+            for name, w32 in (("Win", Win), ("Wo", Wo), ("Win2", Win2), ("Wo2", Wo2), ("W1", W1), ("W2", W2)):
+                w, wt = ops.weight_prep(w32, dt)
+                cw[name] = (w.view(w32.shape), wt.view(w32.shape[1], w32.shape[0]))
+            # ---- masked self-attention
+            qkv = ops.gemm_nt(x, cw["Win"][0], bias=bin_)                           # (B*T, 3H)
+            o1 = ops.attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, A, T, T,
+                                   head.mask_future_positions, lengths, p, seeds[0])
+            y1 = ops.gemm_nt(o1, cw["Wo"][0], bias=bo)
+            x1, m1, r1 = ops.layernorm_residual_fwd(x, y1, g1, b1, 1e-5, p, seeds[1])
+            # ---- cross-attention over the visual grid
+            q2 = ops.gemm_nt(x1, cw["Win2"][0][:H], bias=bin2[:H])                  # (B*T, H)
+            kv2 = ops.gemm_nt(mem, cw["Win2"][0][H:], bias=bin2[H:])                # (B*S, 2H)
+            o2 = ops.attention_fwd(q2, kv2[:, :H], kv2[:, H:], B, A, T, S, False, None, p, seeds[2])
+            y2 = ops.gemm_nt(o2, cw["Wo2"][0], bias=bo2)
+            x2, m2, r2 = ops.layernorm_residual_fwd(x1, y2, g2, b2, 1e-5, p, seeds[3])
+            # ---- feed-forward
+            a, hpre = ops.gemm_nt(x2, cw["W1"][0], bias=bf1, act=ops.ACT_GELU, want_preact=True,
+                                  p_drop=p, seed=seeds[4])
+            y3 = ops.gemm_nt(a, cw["W2"][0], bias=bf2)
+            x3, m3, r3 = ops.layernorm_residual_fwd(x2, y3, g3, b3, 1e-5, p, seeds[5])
+            saved_layers.append(dict(x=x, qkv=qkv, o1=o1, y1=y1, m1=m1, r1=r1, x1=x1, q2=q2, kv2=kv2, o2=o2,
+                                     y2=y2, m2=m2, r2=r2, x2=x2, a=a, hpre=hpre, y3=y3, m3=m3, r3=r3,
+                                     seeds=seeds, cw=cw, P=P))
+            x = x3
+        ctx.head, ctx.p, ctx.dims = head, p, (B, T, S, H, A)
+        ctx.saved_layers, ctx.mem, ctx.mem_in, ctx.Wv_t, ctx.lengths = saved_layers, mem, mem_in, Wv_t, lengths
+        ctx.vshape = visual_features.shape
+        ctx.needs_vis_grad = visual_features.requires_grad
+        return x.view(B, T, H)
+
+    @staticmethod
+    def backward(ctx, dhid):
+        head, p = ctx.head, ctx.p
+        B, T, S, H, A = ctx.dims
+        dt = head.compute_dtype
+        dev = dhid.device
+        dx = dhid.reshape(B * T, H)
+        if dx.dtype != dt or not dx.is_contiguous():
+            dx = dx.to(dt).contiguous()
+        dmem = None
+        pgrads = []
+
+        def zeros(*shape):
+            return torch.zeros(*shape, dtype=torch.float32, device=dev)
+
+        def linear_grads(inp, dout, w32_shape):
+            """dW (fp32, [out,in]) and dbias for y = inp @ W^T + b."""
+            dW = zeros(*w32_shape)
+            ops.gemm_tn_acc(dout, inp, dW)
+            db = zeros(w32_shape[0])
+            ops.colsum_acc(dout, db)
+            return dW, db
+
+        for li in reversed(range(head.num_layers)):
+            L = ctx.saved_layers[li]
+            (Win, bin_, Wo, bo, g1, b1, Win2, bin2, Wo2, bo2, g2, b2, W1, bf1, W2, bf2, g3, b3) = L["P"]
+            cw, seeds = L["cw"], L["seeds"]
+            # ---- FFN block: x3 = LN3(x2 + drop(y3))
+            dg3, db3 = zeros(H), zeros(H)
+            dz3, dy3 = ops.layernorm_residual_bwd(L["x2"], L["y3"], g3, L["m3"], L["r3"], dx, dg3, db3, p, seeds[5])
+            dW2, dbf2 = linear_grads(L["a"], dy3, W2.shape)
+            da = ops.gemm_nt(dy3, cw["W2"][1])                                  # (B*T, F)
+            dh = ops.gelu_bwd(L["hpre"], da, p, seeds[4])
+            dW1, dbf1 = linear_grads(L["x2"], dh, W1.shape)
+            dx2 = ops.gemm_nt(dh, cw["W1"][1], residual=dz3)                    # + residual path
+            # ---- cross-attention block: x2 = LN2(x1 + drop(y2))
+            dg2, db2 = zeros(H), zeros(H)
+            dz2, dy2 = ops.layernorm_residual_bwd(L["x1"], L["y2"], g2, L["m2"], L["r2"], dx2, dg2, db2, p, seeds[3])
+            dWo2, dbo2 = linear_grads(L["o2"], dy2, Wo2.shape)
+            do2 = ops.gemm_nt(dy2, cw["Wo2"][1])
+            dq2 = torch.empty_like(L["q2"])
+            dkv2 = torch.empty_like(L["kv2"])
+            ops.attention_bwd(L["q2"], L["kv2"][:, :H], L["kv2"][:, H:], do2, dq2, dkv2[:, :H], dkv2[:, H:],
+                              B, A, T, S, False, None, p, seeds[2])
+            dWin2 = zeros(*Win2.shape)
+            ops.gemm_tn_acc(dq2, L["x1"], dWin2[:H])
+            ops.gemm_tn_acc(dkv2, ctx.mem, dWin2[H:])
+            dbin2 = zeros(3 * H)
+            ops.colsum_acc(dq2, dbin2[:H])
+            ops.colsum_acc(dkv2, dbin2[H:])
+            dx1 = ops.gemm_nt(dq2, _wt_cols(cw["Win2"][1], 0, H), residual=dz2)
+            dmem = ops.gemm_nt(dkv2, _wt_cols(cw["Win2"][1], H, 3 * H), residual=dmem)
+            # ---- self-attention block: x1 = LN1(x + drop(y1))
+            dg1, db1 = zeros(H), zeros(H)
+            dz1, dy1 = ops.layernorm_residual_bwd(L["x"], L["y1"], g1, L["m1"], L["r1"], dx1, dg1, db1, p, seeds[1])
+            dWo, dbo = linear_grads(L["o1"], dy1, Wo.shape)
+            do1 = ops.gemm_nt(dy1, cw["Wo"][1])
+            qkv = L["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], do1, dqkv[:, :H], dqkv[:, H:2 * H],
+                              dqkv[:, 2 * H:], B, A, T, T, head.mask_future_positions, ctx.lengths, p, seeds[0])
+            dWin, dbin = linear_grads(L["x"], dqkv, Win.shape)
+            dx = ops.gemm_nt(dqkv, cw["Win"][1], residual=dz1)
+            pgrads = [dWin, dbin, dWo, dbo, dg1, db1, dWin2, dbin2, dWo2, dbo2, dg2, db2, dW1, dbf1, dW2, dbf2,
+                      dg3, db3] + pgrads
+        # ---- visual projection
+        Cv = ctx.mem_in.shape[1]
+        dWv = zeros(H, Cv)
+        ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
+        dbv = zeros(H)
+        ops.colsum_acc(dmem, dbv)
+        dvis = None
+        if ctx.needs_vis_grad:
+            Bv, C, h, w = ctx.vshape
+            dvis = ops.gemm_nt(dmem, ctx.Wv_t).view(Bv, h, w, C).permute(0, 3, 1, 2)
+        return (dvis, dx.view(B, T, H), None, None, None, dWv, dbv, *pgrads)
+
+
+def _wt_cols(wt, c0, c1):
+    """Columns [c0, c1) of a transposed weight wt = W^T (in_features, out_features) as a strided
+    (in_features, c1-c0) view: the B operand of the input-gradient GEMM of the sub-projection
+    W[c0:c1] (rows = in_features, k = the selected output slice, row stride = out_features)."""
+    return wt[:, c0:c1]
+
+
+class _OutputProjectionFn(torch.autograd.Function):
+    """logits = hidden @ words^T + bias, fp32 (reference: textual_heads.py:199-200,277)."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias):
+        B, T, H = hidden.shape
+        dt = hidden.dtype
+        w = weight.detach() if dt == torch.float32 else ops.cast_from_f32(weight.detach(), dt)
+        logits = ops.gemm_nt(hidden.reshape(B * T, H), w, bias=bias.detach(), out_f32=True)
+        ctx.save_for_backward(hidden, weight)
+        return logits.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        hidden, weight = ctx.saved_tensors
+        B, T, H = hidden.shape
+        dt = hidden.dtype
+        V = weight.shape[0]
+        d = dlogits.reshape(B * T, V)
+        d = d.contiguous() if d.dtype == dt else d.to(dt).contiguous()
+        _, wt = ops.weight_prep(weight.detach(), dt, want_w=False)
+        dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
+        dW = torch.zeros_like(weight)
+        ops.gemm_tn_acc(d, hidden.reshape(B * T, H), dW)
+        db = torch.zeros(V, dtype=torch.float32, device=d.device)
+        ops.colsum_acc(d, db)
+        return dh, dW, db

@@ -1,0 +1,294 @@
+"""MI355X-native visual backbone: a drop-in for the reference's ``TorchvisionVisualBackbone``
+(/root/reference/virtex/modules/visual_backbones.py:20-74).
+
+Same constructor, same ``visual_feature_size`` attribute, same ``.cnn`` sub-module tree with
+torchvision's parameter/buffer names (``conv1.weight``, ``bn1.*``, ``layer{1-4}.{i}.*``,
+``layer*.0.downsample.{0,1}.*``) so reference checkpoints load unchanged and downstream code
+that touches ``model.visual.cnn`` keeps working.  ``forward(image)`` takes the reference's
+(B,3,H,W) fp32 batch and returns logical (B,C,h,w) features -- physically NHWC, which the
+reference's own ``.view(B,C,-1).permute(0,2,1)`` consumes without a copy.
+
+Nothing here computes with torch operators: the whole ResNet forward and backward is a
+hand-scheduled sequence of C-ABI kernel launches (virtex_amd/ops.py) on the caller's HIP
+stream -- NHWC implicit-GEMM convolutions on MFMA, fused BatchNorm+ReLU(+residual), maxpool.
+torch supplies device memory and the autograd edge only.
+"""
+from typing import List
+
+import torch
+from torch import nn
+
+from .. import ops
+
+RESNET_BLOCKS = {"resnet50": ((3, 4, 6, 3), 64), "resnet101": ((3, 4, 23, 3), 64),
+                 "wide_resnet50_2": ((3, 4, 6, 3), 128)}
+STEM_CPAD = 8  # the 3 input channels are zero-padded to 8 (one 16-byte bf16 vector)
+
+
+# ----------------------------------------------------------------------------------------
+# Parameter containers (torchvision's module tree; they only HOLD parameters/buffers).
+# ----------------------------------------------------------------------------------------
+class _Bottleneck(nn.Module):
+    def __init__(self, cin, planes, stride, base_width, project):
+        super().__init__()
+        mid, cout = planes * base_width // 64, planes * 4
+        self.conv1 = nn.Conv2d(cin, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid)
+        self.conv2 = nn.Conv2d(mid, mid, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(mid)
+        self.conv3 = nn.Conv2d(mid, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if project:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(cout))
+        self.stride = stride
+
+
+class _ResNetParams(nn.Module):
+    """torchvision.models.ResNet's attribute tree (conv1 bn1 relu maxpool layer1-4 avgpool fc)."""
+
+    def __init__(self, name: str, zero_init_residual: bool = True):
+        super().__init__()
+        blocks, base_width = RESNET_BLOCKS[name]
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        cin = 64
+        for s, (planes, nblk) in enumerate(zip((64, 128, 256, 512), blocks)):
+            layer = []
+            for b in range(nblk):
+                layer.append(_Bottleneck(cin, planes, 2 if (b == 0 and s > 0) else 1, base_width, b == 0))
+                cin = planes * 4
+            setattr(self, f"layer{s + 1}", nn.Sequential(*layer))
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc = nn.Linear(cin, 1000)
+        self.out_channels = cin
+        for m in self.modules():  # torchvision's init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, _Bottleneck):
+                    nn.init.zeros_(m.bn3.weight)
+
+    def forward(self, x):
+        raise RuntimeError("`.cnn` only holds parameters; call the VisualBackbone (HIP path) instead")
+
+
+# ----------------------------------------------------------------------------------------
+# The hand-scheduled forward / backward.
+# ----------------------------------------------------------------------------------------
+class _Unit:
+    """One conv + BatchNorm (+ReLU) pair: static description and its parameter slots."""
+
+    def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu: bool, cin_pad: int = 0):
+        self.conv, self.bn, self.relu = conv, bn, relu
+        self.k, self.stride, self.pad = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.cin_pad = cin_pad or self.cin
+        self.is_gemm = self.k == 1 and self.stride == 1
+
+
+class VisualBackbone(nn.Module):
+    """Base class (reference: virtex/modules/visual_backbones.py:8-17)."""
+
+    def __init__(self, visual_feature_size: int):
+        super().__init__()
+        self.visual_feature_size = visual_feature_size
+
+
+class TorchvisionVisualBackbone(VisualBackbone):
+    def __init__(self, name: str = "resnet50", visual_feature_size: int = 2048,
+                 pretrained: bool = False, frozen: bool = False,
+                 compute_dtype: torch.dtype = torch.bfloat16):
+        super().__init__(visual_feature_size)
+        if pretrained:
+            raise RuntimeError("ImageNet-pretrained weights need network access; load a state dict instead")
+        if name not in RESNET_BLOCKS:
+            raise KeyError(f"{name} is not a supported torchvision backbone ({sorted(RESNET_BLOCKS)})")
+        self.cnn = _ResNetParams(name, zero_init_residual=True)
+        self.cnn.fc = nn.Identity()
+        self.compute_dtype = compute_dtype
+        self.frozen = frozen
+        if frozen:
+            for p in self.cnn.parameters():
+                p.requires_grad = False
+            self.cnn.eval()
+
+    # -- schedule ---------------------------------------------------------------------
+    def _units(self):
+        c = self.cnn
+        stem = _Unit(c.conv1, c.bn1, True, cin_pad=STEM_CPAD)
+        blocks = []
+        for s in range(1, 5):
+            for blk in getattr(c, f"layer{s}"):
+                u1 = _Unit(blk.conv1, blk.bn1, True)
+                u2 = _Unit(blk.conv2, blk.bn2, True)
+                u3 = _Unit(blk.conv3, blk.bn3, True)  # ReLU after the residual add
+                ud = _Unit(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None
+                blocks.append((u1, u2, u3, ud))
+        return stem, blocks
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        stem, blocks = self._units()
+        units = [stem] + [u for blk in blocks for u in blk if u is not None]
+        params = []
+        for u in units:
+            params += [u.conv.weight, u.bn.weight, u.bn.bias]
+        return _ResNetFn.apply(image, self, *params)
+
+
+def _prep_weight(u: _Unit, dtype, need_wt: bool):
+    """fp32 master (KO,C,R,S logical) -> compute copies w (KO,R,S,Cp) and wt (Cp,R,S,KO)."""
+    w32 = u.conv.weight.detach().permute(0, 2, 3, 1).contiguous().view(u.cout, u.k * u.k, u.cin)
+    if dtype == torch.float32 and u.cin_pad == u.cin:
+        w = w32
+        wt = ops.weight_prep(w32, dtype, want_w=False)[1] if need_wt else None
+    else:
+        w, wt = ops.weight_prep(w32, dtype, cpad=u.cin_pad, want_wt=need_wt)
+    w = w.view(u.cout, u.k, u.k, u.cin_pad)
+    if wt is not None:
+        wt = wt.view(u.cin_pad, u.k, u.k, u.cout)
+    return w, wt
+
+
+def _conv_fwd(u: _Unit, x, w):
+    if u.is_gemm:
+        N, H, W, C = x.shape
+        return ops.gemm_nt(x.view(-1, C), w.view(u.cout, C)).view(N, H, W, u.cout)
+    return ops.conv2d_fwd(x, w, u.stride, u.pad)
+
+
+def _conv_dgrad(u: _Unit, dy, wt, x_shape, residual=None):
+    if u.is_gemm:
+        N, H, W, C = x_shape
+        r = residual.view(-1, C) if residual is not None else None
+        return ops.gemm_nt(dy.view(-1, u.cout), wt.view(C, u.cout), residual=r).view(N, H, W, C)
+    return ops.conv2d_dgrad(dy, wt, x_shape, u.stride, u.pad, residual=residual)
+
+
+def _conv_wgrad(u: _Unit, x, dy):
+    """Returns the gradient in the master weight's logical (KO,C,R,S) shape."""
+    dw = torch.zeros(u.cout, u.k, u.k, u.cin_pad, dtype=torch.float32, device=x.device)
+    if u.is_gemm:
+        ops.gemm_tn_acc(dy.view(-1, u.cout), x.view(-1, u.cin_pad), dw.view(u.cout, u.cin_pad))
+    else:
+        ops.conv2d_wgrad(x, dy, dw, u.stride, u.pad)
+    if u.cin_pad != u.cin:
+        dw = dw[..., :u.cin].contiguous()
+    return dw.permute(0, 3, 1, 2)
+
+
+class _Saved:
+    __slots__ = ("a", "x", "y", "mean", "rstd", "wt")
+
+
+class _ResNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, module, *params):
+        dt = module.compute_dtype
+        dev = image.device
+        stem, blocks = module._units()
+        train = module.training and not module.frozen
+        need_grad = any(p.requires_grad for p in params)
+        units = [stem] + [u for blk in blocks for u in blk if u is not None]
+        ws = torch.zeros(sum(4 * u.cout for u in units), dtype=torch.float32, device=dev)
+        ws_off = [0]
+        saved: List[_Saved] = []
+
+        def run(u: _Unit, a, relu, residual=None, first=False):
+            w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
+            x = _conv_fwd(u, a, w)
+            bn = u.bn
+            if not train:
+                raise RuntimeError("eval-mode (running-statistics) BatchNorm is not part of the "
+                                   "pretraining hot path yet (SURVEY.md 8f row f3)")
+            wsl = ws[ws_off[0]: ws_off[0] + 4 * u.cout]
+            ws_off[0] += 4 * u.cout
+            y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                       bn.num_batches_tracked, wsl, eps=bn.eps,
+                                       momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
+                                       residual=residual)
+            s = _Saved()
+            s.a, s.x, s.y, s.mean, s.rstd, s.wt = a, x, y, mean, rstd, wt
+            saved.append(s)
+            return y
+
+        a0 = ops.image_to_nhwc(image.float().contiguous(), dt, STEM_CPAD)
+        y = run(stem, a0, True, first=True)
+        pooled, argmax = ops.maxpool_fwd(y)
+        cur = pooled
+        for (u1, u2, u3, ud) in blocks:
+            inp = cur
+            t = run(u1, inp, True)
+            t = run(u2, t, True)
+            skip = run(ud, inp, False) if ud is not None else inp
+            cur = run(u3, t, True, residual=skip)
+        ctx.module, ctx.saved, ctx.argmax, ctx.stem_out_shape = module, saved, argmax, y.shape
+        ctx.nparams = len(params)
+        N, H, W, C = cur.shape
+        return cur.permute(0, 3, 1, 2)  # logical NCHW, physical NHWC
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        module, saved = ctx.module, ctx.saved
+        dt = module.compute_dtype
+        stem, blocks = module._units()
+        dcur = dfeat.permute(0, 2, 3, 1)
+        if dcur.dtype != dt or not dcur.is_contiguous():
+            dcur = dcur.to(dt).contiguous()
+        dev = dcur.device
+        units = [stem] + [u for blk in blocks for u in blk if u is not None]
+        ws = torch.zeros(sum(5 * u.cout for u in units), dtype=torch.float32, device=dev)
+        ws_off = [0]
+        grads = {}
+
+        def bn_back(u: _Unit, s: _Saved, dy, masked, want_dz=False):
+            wsl = ws[ws_off[0]: ws_off[0] + 5 * u.cout]
+            ws_off[0] += 5 * u.cout
+            dg = torch.zeros(u.cout, dtype=torch.float32, device=dev)
+            db = torch.zeros(u.cout, dtype=torch.float32, device=dev)
+            out = ops.bn_bwd(s.x, dy, s.y if masked else None, u.bn.weight.detach(), s.mean, s.rstd, dg, db, wsl,
+                             want_dz=want_dz)
+            grads[u] = [None, dg, db]
+            return out
+
+        # index of each unit's saved record, in forward execution order
+        order = [stem]
+        for (u1, u2, u3, ud) in blocks:
+            order += [u1, u2] + ([ud] if ud is not None else []) + [u3]
+        rec = {u: s for u, s in zip(order, saved)}
+
+        for (u1, u2, u3, ud) in reversed(blocks):
+            s1, s2, s3 = rec[u1], rec[u2], rec[u3]
+            dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True)      # dz: gradient of the identity path
+            grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
+            dy2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape)
+            dx2 = bn_back(u2, s2, dy2, True)
+            grads[u2][0] = _conv_wgrad(u2, s2.a, dx2)
+            dy1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape)
+            dx1 = bn_back(u1, s1, dy1, True)
+            grads[u1][0] = _conv_wgrad(u1, s1.a, dx1)
+            if ud is not None:
+                sd = rec[ud]
+                dxd = bn_back(ud, sd, dz, False)
+                grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
+                dmain = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape)
+                dcur = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape, residual=dmain)
+            else:
+                dcur = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=dz)
+        s0 = rec[stem]
+        dstem = ops.maxpool_bwd(dcur, ctx.argmax, ctx.stem_out_shape)
+        dx0 = bn_back(stem, s0, dstem, True)
+        grads[stem][0] = _conv_wgrad(stem, s0.a, dx0)      # no input gradient for the image
+
+        out = [None, None]
+        for u in units:
+            out += grads[u]
+        return tuple(out)

@@ -107,14 +107,14 @@ def conv2d_fwd(x, w, stride, pad):
     return y
 
 
-def conv2d_dgrad(dy, wt, x_shape, stride, pad):
+def conv2d_dgrad(dy, wt, x_shape, stride, pad, residual=None):
     N, H, W, C = x_shape
     C2, R, S, KO = wt.shape
     assert C2 == C and dy.shape[-1] == KO and wt.dtype == dy.dtype
-    _chk(dy, "dy"); _chk(wt, "wt")
+    _chk(dy, "dy"); _chk(wt, "wt"); _chk(residual, "residual", dy.dtype)
     dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
     call("vtx_conv2d_dgrad", c_int(dtype_code(dy.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
-         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(dy), ptr(wt), ptr(dx), stream_ptr(dy))
+         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(dy), ptr(wt), ptr(dx), ptr(residual), stream_ptr(dy))
     return dx
 
 
