@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Headline benchmark: pretrain images/sec of bicaptioning_R_50_L1_H1024 (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One "step" = the reference's whole training-step body (scripts/pretrain_virtex.py:145-163):
+zero_grad -> forward (dropout 0.1 on) -> backward -> gradient all-reduce (N > 1) -> clip 10.0 ->
+SGD(m .9, per-tensor lr/wd) -> Lookahead(5, .5) -> LR schedule, on synthetic COCO-shaped batches
+(224x224 fp32 images, 30-token captions) that are resident in HBM before the timed region.
+Workload at N=1 = BASELINE.json configs[1]: bf16 compute, 256 images per GPU.  For N > 1 the
+driver launches this file under torch.distributed.run, one rank per GPU (weak scaling).
+
+Rank 0 prints ONE JSON line; besides the contract fields it carries
+  "roofline"     : the dominant kernel (the MFMA contraction kernel on its heaviest conv shape),
+                   algorithmic FLOPs / HIP-event time measured here, against the dense bf16 peak
+  "step_mfma"    : whole-step algorithmic FLOP/s (35.17 GFLOP/img) against the same peak
+  "cpu_baseline" : the oracle port of the reference step timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG = {"L1_H1024": 35.17, "L4_H1024": 54.89}
+PEAK_BF16_TFLOPS = 2500.0                                  # MI355X dense bf16 MFMA
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--textual", default="transdec_postnorm::L1_H1024_A16_F4096")
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def device_batch(B, dev, seed):
+    from virtex_amd.synthetic import synthetic_batch
+
+    return synthetic_batch(B, dev, image_size=224, max_len=30, vocab_size=10000, seed=seed)
+
+
+def kernel_roofline(dtype):
+    """Time the dominant kernel alone with HIP events on the launch stream (= torch's current
+    stream, which every C-ABI call is enqueued on)."""
+    from virtex_amd import ops
+
+    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    # heaviest conv shape of ResNet-50 at B=256: 3x3 stride-1 64->64 @56x56 (3 instances fwd, each
+    # 115.6 MMAC/img) -> implicit GEMM M=802816, N=64, K=576
+    N, H, W, C, KO = 256, 56, 56, 64, 64
+    x = torch.randn(N, H, W, C, device="cuda").to(dt)
+    w = (torch.randn(KO, 3, 3, C, device="cuda") / 24).to(dt)
+    for _ in range(3):
+        ops.conv2d_fwd(x, w, 1, 1)
+    torch.cuda.synchronize()
+    iters = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.conv2d_fwd(x, w, 1, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    dur = e0.elapsed_time(e1) / iters * 1e-3
+    flops = 2.0 * N * H * W * KO * 9 * C
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    return {"bound": "mfma", "kernel": "contraction_kernel<ConvFwdA,PlainKC> conv3x3 s1 64->64 @56x56 B=256",
+            "achieved": round(flops / dur / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(flops / dur / 1e12 / peak, 4), "traffic": None,
+            "avg_launch_us": round(dur * 1e6, 1), "flops_per_launch": flops}
+
+
+def cpu_baseline(batch, steps):
+    """Reference step (oracle port, torch CPU fp32, dropout 0.1) on the host cores."""
+    from oracle import bicaptioning as port, synth
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = port.build_model(dropout=0.1).train()
+    step = port.TrainStep(model, start_step=100)
+    b = synth.synthetic_batch(batch, seed=0)
+    step(b)                                   # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        step(b)
+    dt = time.time() - t0
+    return {"value": round(batch * steps / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"{steps} steps of B={batch} (fp32, dropout 0.1, SGD+Lookahead+clip), oracle/bicaptioning.py"}
+
+
+def main():
+    a = parse()
+    from virtex_amd import distributed as vd
+    import virtex_amd.factories as vf
+    from virtex_amd.optim import PretrainOptimizer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and a.gpus > 1:
+        print(f"bench.py: --gpus {a.gpus} must be launched with torch.distributed.run (one rank per GPU)",
+              file=sys.stderr)
+        sys.exit(2)
+    local_rank = vd.init_process_group("nccl" if world > 1 else None)
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    rank = vd.rank()
+
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(0)
+    model = vf.build_bicaptioning_model(textual=a.textual, dropout=a.dropout, compute_dtype=dt).to(dev).train()
+    vd.broadcast_parameters(model)
+    buckets = vd.GradientBuckets(model)
+    opt = PretrainOptimizer(model, start_step=100)      # inside warm-up: non-zero learning rate
+    batches = [device_batch(a.batch, dev, seed=1000 * rank + i) for i in range(2)]
+
+    def step(i):
+        buckets.zero()
+        buckets.begin()
+        out = model(batches[i % 2])
+        out["loss"].backward()
+        scale = buckets.finish()
+        opt.step(grad_scale=scale)
+        return out["loss"]
+
+    for i in range(a.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    vd.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    vd.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = loss.item()
+
+    if rank == 0:
+        ips = a.batch * world * a.steps / elapsed
+        arch = a.textual.split("::")[1]
+        key = "_".join(arch.split("_")[:2])
+        gflop = GFLOP_PER_IMG.get(key)
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        rec = {
+            "metric": "pretrain images/sec", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"bicaptioning_R_50_{key} {a.dtype}, bs={a.batch}/GPU, 224x224 synthetic images + "
+                                   "30-tok captions, full step (fwd+bwd+clip+SGD+Lookahead), dropout "
+                                   f"{a.dropout}", "global_batch": a.batch * world,
+                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+        }
+        if gflop:
+            tf = ips * gflop / 1e3
+            rec["step_mfma"] = {"gflop_per_image": gflop, "achieved_tflops": round(tf, 1),
+                                "peak_tflops": peak * world, "frac": round(tf / (peak * world), 4)}
+        if not a.no_roofline:
+            rec["roofline"] = kernel_roofline(a.dtype)
+        if world == 1 and not a.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps)
+        print(json.dumps(rec), flush=True)
+    vd.synchronize()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,12 +109,25 @@ def test_model_fp32_gpu(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["r50_l1_h1024_b2_full"])
-def test_model_bf16_gpu(case):
-    """bf16 storage (8-bit mantissa) through 50+ layers with B=2 batch statistics: bound
-    calibrated against the fp32 oracle, not a parity claim."""
+def test_model_bf16_gpu():
+    """bf16 compute mode (the throughput mode) is NOT a parity claim; it is bounded against the
+    fp32 oracle where bf16 storage permits: loss to 2e-3, every text-side gradient with cosine
+    >= 0.99.  Backbone gradients are only required to be finite: with bf16 activation gradients
+    the 53 BatchNorm backward projections amplify the 2^-8 rounding past any useful bound on
+    this randomised state (measured, with the well-conditioned states, in
+    profiles/r01_bf16_fidelity.log; discussion in DESIGN.md "Parity")."""
     dev = select("gpu")
-    _check(case, dev, torch.bfloat16, text_tol=0.1, loss_tol=2e-2, cnn_factor=1e9, cnn_floor=1e-3)
+    oracle_model, model, batch = _build_pair("r50_l1_h1024_b2_full", dev, torch.bfloat16)
+    oracle_model.train()
+    oo = oracle_model(batch)
+    oo["loss"].backward()
+    out = _run(model, batch, dev)
+    assert abs(out["loss"].item() - oo["loss"].item()) < 2e-3 * abs(oo["loss"].item())
+    for (n, p), (_, q) in zip(model.named_parameters(), oracle_model.named_parameters()):
+        assert torch.isfinite(p.grad).all(), n
+        if "cnn" not in n:
+            a, b = p.grad.cpu().double().flatten(), q.grad.double().flatten()
+            assert (a @ b / (a.norm() * b.norm())).item() > 0.99, n
 
 
 def test_state_dict_layout():

@@ -114,6 +114,11 @@ class TorchvisionVisualBackbone(VisualBackbone):
             raise KeyError(f"{name} is not a supported torchvision backbone ({sorted(RESNET_BLOCKS)})")
         self.cnn = _ResNetParams(name, zero_init_residual=True)
         self.cnn.fc = nn.Identity()
+        # master conv weights live physically as (KO,R,S,C) -- the kernels' layout -- while keeping
+        # torchvision's logical (KO,C,R,S) shape for state-dict compatibility
+        for m in self.cnn.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         self.compute_dtype = compute_dtype
         self.frozen = frozen
         if frozen:
