@@ -87,10 +87,12 @@ int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S
  * Replaces aten::batch_norm/relu_/add_ (+backward) of torchvision's Bottleneck
  * (visual_backbones.py:68-74): y = act(gamma*(x-mean)*rstd + beta (+ residual)), running
  * stats updated with `momentum` and the unbiased variance, num_batches_tracked += 1.
- * fwd workspace: 4*C floats whose first 2*C are ZERO on entry.
+ * workspace: vtx_bn_workspace_floats(C) fp32 scratch (per-strip partial sums; no zeroing needed;
+ * may be shared by all calls issued on one stream).
  * bwd: dz = dy * (ymask > 0) (ymask = the post-ReLU tensor, NULL if no ReLU follows);
  *      dx = grad wrt x; dz_out (optional) receives dz (the residual-branch gradient);
- *      dgamma/dbeta accumulated; workspace: 5*C floats, first 2*C ZERO on entry. */
+ *      dgamma/dbeta accumulated. */
+long vtx_bn_workspace_floats(int C);
 int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamma, const float* beta,
                float* running_mean, float* running_var, long long* num_batches_tracked, void* y,
                float* save_mean, float* save_rstd, float* workspace, int P, int C, float eps,
@@ -149,7 +151,9 @@ int vtx_cross_entropy_bwd(int dtype, const float* logits, long ld, const long lo
                           void* dlogits, long ldd, int R, int V, int ignore_index, void* stream);
 
 /* ---- small helpers -------------------------------------------------------------------- */
-int vtx_colsum_acc(int dtype, const void* x, long ld, float* out /*[C] +=*/, int R, int C, void* stream);
+long vtx_colsum_workspace_floats(int C);
+int vtx_colsum_acc(int dtype, const void* x, long ld, float* out /*[C] +=*/, float* workspace, int R, int C,
+                   void* stream);
 int vtx_add(int dtype, const void* a, const void* b, void* out, long n, void* stream);
 int vtx_gelu_bwd(int dtype, const void* h, const void* da, void* dh, long n, float p_drop, uint64_t seed,
                  void* stream);

@@ -165,17 +165,15 @@ def test_batchnorm(backend, dtype, N, H, W, C, relu, res):
         yr = F.relu(yr)
     yr.backward(dy.float().permute(0, 3, 1, 2))
 
-    ws = torch.zeros(4 * C, device=dev)
     rmd, rvd = rm0.clone().to(dev), rv0.clone().to(dev)
     nbt = torch.zeros((), dtype=torch.int64, device=dev)
-    y, mean, rstd = ops.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmd, rvd, nbt, ws, relu=relu,
+    y, mean, rstd = ops.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmd, rvd, nbt, relu=relu,
                                residual=r.to(dev) if res else None)
     e = 3e-5 if dtype == torch.float32 else 1e-2
     assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < e
     assert rel_err(rmd.cpu(), rm) < 1e-4 and rel_err(rvd.cpu(), rv) < 1e-4 and int(nbt) == 1
-    ws2 = torch.zeros(5 * C, device=dev)
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
-    dx, dz = ops.bn_bwd(x.to(dev), dy.to(dev), y if relu else None, gamma.to(dev), mean, rstd, dg, db, ws2,
+    dx, dz = ops.bn_bwd(x.to(dev), dy.to(dev), y if relu else None, gamma.to(dev), mean, rstd, dg, db,
                         want_dz=True)
     assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < (2e-4 if dtype == torch.float32 else 2e-2)
     assert rel_err(dg.cpu(), gr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)

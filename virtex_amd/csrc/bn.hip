@@ -64,8 +64,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
         for (int j = 0; j < VEC; ++j) {
             float s0 = 0.f, s1 = 0.f;
             for (int r = 0; r < TY; ++r) { s0 += red[0][(r * TX + tx) * VEC + j]; s1 += red[1][(r * TX + tx) * VEC + j]; }
-            atomicAdd(sums + c0 + j, s0);
-            atomicAdd(sums + C + c0 + j, s1);
+            // one partial per (pixel strip, channel): no atomics (thousands of blocks hitting the
+            // same 2*C addresses serialised in L2), summed by the finalize kernel
+            sums[(size_t)blockIdx.x * 2 * C + c0 + j] = s0;
+            sums[(size_t)blockIdx.x * 2 * C + C + c0 + j] = s1;
         }
     }
 }
@@ -76,12 +78,14 @@ __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __r
                                        float* __restrict__ rstd, float* __restrict__ scale,
                                        float* __restrict__ shift, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, long long* __restrict__ nbt,
-                                       int P, int C, float eps, float momentum) {
+                                       int P, int C, float eps, float momentum, int nparts) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    const float ms = sums[c] / (float)P;              // mean of (x - x[0][c])
-    float var = sums[C + c] / (float)P - ms * ms;
+    float t0 = 0.f, t1 = 0.f;
+    for (int b = 0; b < nparts; ++b) { t0 += sums[(size_t)b * 2 * C + c]; t1 += sums[(size_t)b * 2 * C + C + c]; }
+    const float ms = t0 / (float)P;                   // mean of (x - x[0][c])
+    float var = t1 / (float)P - ms * ms;
     var = var > 0.f ? var : 0.f;
     const float m = Elem<T>::ld(x + c) + ms;
     const float r = rsqrtf(var + eps);
@@ -124,10 +128,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 // coef[0][c] = gamma*rstd, coef[1][c] = s1/P, coef[2][c] = s2/P ; dgamma += s2 ; dbeta += s1
 __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
                                        const float* __restrict__ rstd, float* __restrict__ coef,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int P, int C) {
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int P, int C,
+                                       int nparts) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float s1 = sums[c], s2 = sums[C + c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < nparts; ++b) { s1 += sums[(size_t)b * 2 * C + c]; s2 += sums[(size_t)b * 2 * C + C + c]; }
     coef[c] = gamma[c] * rstd[c];
     coef[C + c] = s1 / (float)P;
     coef[2 * C + c] = s2 / (float)P;
@@ -161,6 +167,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
+constexpr int VTX_BN_MAX_PARTS = 512;
 struct ReducePlan { int TX, gy, gx, rows; };
 static ReducePlan plan_reduce(int P, int C, int vec) {
     ReducePlan r;
@@ -168,7 +175,7 @@ static ReducePlan plan_reduce(int P, int C, int vec) {
     r.TX = cv < 256 ? cv : 256;
     r.gy = cv / r.TX;
     const int TY = 256 / r.TX;
-    int gx = 2048 / r.gy;
+    int gx = VTX_BN_MAX_PARTS;
     const int max_gx = vtx_cdiv(P, TY * 4);
     if (gx > max_gx) gx = max_gx;
     if (gx < 1) gx = 1;
@@ -184,7 +191,9 @@ static bool bn_shape_ok(int C, int vec) { return C > 0 && C % vec == 0 && ((C / 
 
 }  // namespace
 
-// workspace layout (fp32): sums[2*C] (must be ZERO on entry; left dirty) | scale[C] | shift[C]
+extern "C" long vtx_bn_workspace_floats(int C) { return (long)(2 * VTX_BN_MAX_PARTS + 4) * C; }
+
+// workspace layout (fp32): scale[C] | coef[3*C] | partial sums [nparts][2][C]   (need not be zeroed)
 extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamma,
                           const float* beta, float* running_mean, float* running_var,
                           long long* num_batches_tracked, void* y, float* save_mean, float* save_rstd,
@@ -194,7 +203,7 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_fwd: C=%d must be vec*2^k, P=%d > 0", C, P);
     hipStream_t st = (hipStream_t)stream;
-    float* sums = workspace; float* scale = workspace + 2 * C; float* shift = workspace + 3 * C;
+    float* scale = workspace; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(P, C, vec);
     const long nvec = (long)P * C / vec;
     if (dtype == VTX_BF16)
@@ -205,10 +214,10 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta,
-                           save_mean, save_rstd, scale, shift, running_mean, running_var, num_batches_tracked, P, C, eps, momentum);
+                           save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, (const float*)x, sums, gamma, beta,
-                           save_mean, save_rstd, scale, shift, running_mean, running_var, num_batches_tracked, P, C, eps, momentum);
+                           save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
@@ -219,7 +228,7 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     return VTX_OK;
 }
 
-// workspace (fp32): sums[2*C] (ZERO on entry) | coef[3*C]
+// workspace: same buffer / layout as vtx_bn_fwd (vtx_bn_workspace_floats(C) floats)
 extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, const float* gamma,
                           const float* save_mean, const float* save_rstd, void* dx, void* dz_out,
                           float* dgamma, float* dbeta, float* workspace, int P, int C, void* stream) {
@@ -229,7 +238,7 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_bwd: C=%d must be vec*2^k, P=%d > 0", C, P);
     hipStream_t st = (hipStream_t)stream;
-    float* sums = workspace; float* coef = workspace + 2 * C;
+    float* coef = workspace + C; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(P, C, vec);
     const long nvec = (long)P * C / vec;
     if (dtype == VTX_BF16)
@@ -239,7 +248,7 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
         hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, sums, P, C, rp.TX, rp.rows);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
-                       dgamma, dbeta, P, C);
+                       dgamma, dbeta, P, C, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, coef, (bf16_t*)dx,

@@ -30,9 +30,17 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
         for (int j = 0; j < VEC; ++j) {
             float s = 0.f;
             for (int r = 0; r < TY; ++r) s += red[(r * TX + tx) * VEC + j];
-            atomicAdd(out + c0 + j, s);
+            out[(size_t)blockIdx.x * C + c0 + j] = s;   // per-strip partial, summed by colsum_finalize
         }
     }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ parts, float* __restrict__ out, int C, int nparts) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nparts; ++b) s += parts[(size_t)b * C + c];
+    out[c] += s;
 }
 
 template <class T>
@@ -67,8 +75,12 @@ static int grid_for(long total) {
 
 }  // namespace
 
-extern "C" int vtx_colsum_acc(int dtype, const void* x, long ld, float* out, int R, int C, void* stream) {
-    VTX_CHECK(x && out, VTX_ERR_ARG, "colsum_acc: null pointer");
+constexpr int VTX_COLSUM_MAX_PARTS = 256;
+extern "C" long vtx_colsum_workspace_floats(int C) { return (long)VTX_COLSUM_MAX_PARTS * C; }
+
+extern "C" int vtx_colsum_acc(int dtype, const void* x, long ld, float* out, float* workspace, int R, int C,
+                              void* stream) {
+    VTX_CHECK(x && out && workspace, VTX_ERR_ARG, "colsum_acc: null pointer");
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "colsum_acc: bad dtype");
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(R >= 0 && C > 0 && C % vec == 0 && ld % vec == 0, VTX_ERR_SHAPE, "colsum_acc: C and ld must be multiples of %d", vec);
@@ -77,16 +89,17 @@ extern "C" int vtx_colsum_acc(int dtype, const void* x, long ld, float* out, int
     int TX = 1;
     while (TX * 2 <= cv && TX < 256) TX *= 2;      // power of two <= min(cv, 256)
     const int gy = vtx_cdiv(cv, TX), TY = 256 / TX;
-    int gx = 1024 / gy;
+    int gx = VTX_COLSUM_MAX_PARTS;
     const int max_gx = vtx_cdiv(R, TY * 4);
     if (gx > max_gx) gx = max_gx;
     if (gx < 1) gx = 1;
     const int rows = vtx_cdiv(R, gx);
     gx = vtx_cdiv(R, rows);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, out, R, C, TX, rows);
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, workspace, R, C, TX, rows);
     else
-        hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, out, R, C, TX, rows);
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, workspace, R, C, TX, rows);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(vtx_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, workspace, out, C, gx);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

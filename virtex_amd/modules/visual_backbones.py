@@ -203,8 +203,6 @@ class _ResNetFn(torch.autograd.Function):
         train = module.training and not module.frozen
         need_grad = any(p.requires_grad for p in params)
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
-        ws = torch.zeros(sum(4 * u.cout for u in units), dtype=torch.float32, device=dev)
-        ws_off = [0]
         saved: List[_Saved] = []
 
         def run(u: _Unit, a, relu, residual=None, first=False):
@@ -214,10 +212,8 @@ class _ResNetFn(torch.autograd.Function):
             if not train:
                 raise RuntimeError("eval-mode (running-statistics) BatchNorm is not part of the "
                                    "pretraining hot path yet (SURVEY.md 8f row f3)")
-            wsl = ws[ws_off[0]: ws_off[0] + 4 * u.cout]
-            ws_off[0] += 4 * u.cout
             y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                       bn.num_batches_tracked, wsl, eps=bn.eps,
+                                       bn.num_batches_tracked, eps=bn.eps,
                                        momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
                                        residual=residual)
             s = _Saved()
@@ -250,16 +246,12 @@ class _ResNetFn(torch.autograd.Function):
             dcur = dcur.to(dt).contiguous()
         dev = dcur.device
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
-        ws = torch.zeros(sum(5 * u.cout for u in units), dtype=torch.float32, device=dev)
-        ws_off = [0]
         grads = {}
 
         def bn_back(u: _Unit, s: _Saved, dy, masked, want_dz=False):
-            wsl = ws[ws_off[0]: ws_off[0] + 5 * u.cout]
-            ws_off[0] += 5 * u.cout
             dg = torch.zeros(u.cout, dtype=torch.float32, device=dev)
             db = torch.zeros(u.cout, dtype=torch.float32, device=dev)
-            out = ops.bn_bwd(s.x, dy, s.y if masked else None, u.bn.weight.detach(), s.mean, s.rstd, dg, db, wsl,
+            out = ops.bn_bwd(s.x, dy, s.y if masked else None, u.bn.weight.detach(), s.mean, s.rstd, dg, db,
                              want_dz=want_dz)
             grads[u] = [None, dg, db]
             return out

@@ -130,13 +130,29 @@ def conv2d_wgrad(x, dy, dw, stride, pad, split_k=0):
 
 
 # ---------------------------------------------------------------------------------------
-# BatchNorm (training) on NHWC, fused ReLU / residual.  `ws` = zeroed fp32 workspace slice.
-def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, ws, eps=1e-5, momentum=0.1, relu=True,
+# BatchNorm (training) on NHWC, fused ReLU / residual.
+_bn_ws = {}
+
+
+def bn_workspace(device, C):
+    """fp32 scratch for the per-strip partial sums; one buffer per device, shared by every BN call
+    (calls are ordered on the stream)."""
+    lib = _lib.lib()
+    lib.vtx_bn_workspace_floats.restype = _lib.ctypes.c_long
+    need = lib.vtx_bn_workspace_floats(c_int(C))
+    ws = _bn_ws.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, lib.vtx_bn_workspace_floats(c_int(2048))), dtype=torch.float32, device=device)
+        _bn_ws[device] = ws
+    return ws
+
+
+def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, relu=True,
            residual=None):
     C = x.shape[-1]
     P = x.numel() // C
     _chk(x, "x"); _chk(residual, "residual", x.dtype)
-    assert ws.dtype == torch.float32 and ws.numel() >= 4 * C
+    ws = bn_workspace(x.device, C)
     y = torch.empty_like(x)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -146,11 +162,11 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, ws, eps=1e-5, momentu
     return y, mean, rstd
 
 
-def bn_bwd(x, dy, ymask, gamma, mean, rstd, dgamma, dbeta, ws, want_dz=False):
+def bn_bwd(x, dy, ymask, gamma, mean, rstd, dgamma, dbeta, want_dz=False):
     C = x.shape[-1]
     P = x.numel() // C
     _chk(x, "x"); _chk(dy, "dy", x.dtype); _chk(ymask, "ymask", x.dtype)
-    assert ws.dtype == torch.float32 and ws.numel() >= 5 * C
+    ws = bn_workspace(x.device, C)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
     call("vtx_bn_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(dy), ptr(ymask), ptr(gamma), ptr(mean),
@@ -279,10 +295,18 @@ def cross_entropy_bwd(logits, targets, lse, lc, grad_out, dtype, ignore_index=0)
     return d
 
 
+_colsum_ws = {}
+
+
 def colsum_acc(x, out):
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
-    call("vtx_colsum_acc", c_int(dtype_code(x.dtype)), ptr(x), c_long(x.stride(0)), ptr(out), c_int(x.shape[0]),
-         c_int(x.shape[1]), stream_ptr(x))
+    C = x.shape[1]
+    ws = _colsum_ws.get(x.device)
+    if ws is None or ws.numel() < 256 * C:
+        ws = torch.empty(256 * max(C, 10000), dtype=torch.float32, device=x.device)
+        _colsum_ws[x.device] = ws
+    call("vtx_colsum_acc", c_int(dtype_code(x.dtype)), ptr(x), c_long(x.stride(0)), ptr(out), ptr(ws),
+         c_int(x.shape[0]), c_int(C), stream_ptr(x))
     return out
 
 
