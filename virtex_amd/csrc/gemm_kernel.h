@@ -28,8 +28,8 @@ template <class T> struct Mma;
 template <> struct Mma<bf16_t> {
     static constexpr int KI = 32;
     typedef bf16x8_t Frag;
-    __device__ static __forceinline__ Frag load(const bf16_t* tile_row, int lane, int kk) {
-        return *reinterpret_cast<const bf16x8_t*>(tile_row + kk * 32 + (lane >> 4) * 8);
+    __device__ static __forceinline__ Frag load(const bf16_t* frag, int kk) {
+        return *reinterpret_cast<const bf16x8_t*>(frag + kk * 32);
     }
     __device__ static __forceinline__ f32x4_t mma(Frag a, Frag b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
@@ -38,9 +38,7 @@ template <> struct Mma<bf16_t> {
 template <> struct Mma<float> {
     static constexpr int KI = 4;
     typedef float Frag;
-    __device__ static __forceinline__ Frag load(const float* tile_row, int lane, int kk) {
-        return tile_row[kk * 4 + (lane >> 4)];
-    }
+    __device__ static __forceinline__ Frag load(const float* frag, int kk) { return frag[kk * 4]; }
     __device__ static __forceinline__ f32x4_t mma(Frag a, Frag b, f32x4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
@@ -80,14 +78,9 @@ template <class T, int SL> struct PlainMC {
     static constexpr bool MC = true;
     const T* p; long ld; int rows; int K;
     struct State { int r0; bool ok; };
-    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
-        constexpr int CPR = 64 * SL / Elem<T>::VEC;
-        s.r0 = row0 + (tid % CPR) * Elem<T>::VEC;
-        s.ok = s.r0 < rows;
-    }
-    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
-        constexpr int CPR = 64 * SL / Elem<T>::VEC;
-        const int k = k0 + (threadIdx.x + NTHREADS * i) / CPR;
+    // r0 = first of the VEC consecutive rows this thread stages; k = global k of the chunk
+    __device__ __forceinline__ void init(State& s, int r0) const { s.r0 = r0; s.ok = r0 < rows; }
+    __device__ __forceinline__ uint4 load(const State& s, int k) const {
         return (s.ok && k < K) ? ld16(p + (long)k * ld + s.r0) : zero16();
     }
 };
@@ -169,18 +162,14 @@ template <class T, int SL> struct ConvWgradB {
     static constexpr bool MC = true;
     const T* x; ConvGeo g; int rows; int K;  // rows = R*S*C, K = N*OH*OW
     struct State { int kh, kw, ci; bool ok; };
-    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
-        constexpr int CPR = 64 * SL / Elem<T>::VEC;
-        const int r0 = row0 + (tid % CPR) * Elem<T>::VEC;
+    __device__ __forceinline__ void init(State& s, int r0) const {
         s.ok = r0 < rows;
         const int tap = r0 >> g.logC;
         s.ci = r0 & (g.C - 1);
         s.kh = (tap * g.rcpS) >> 16;
         s.kw = tap - s.kh * g.S;
     }
-    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
-        constexpr int CPR = 64 * SL / Elem<T>::VEC;
-        const int pix = k0 + (threadIdx.x + NTHREADS * i) / CPR;
+    __device__ __forceinline__ uint4 load(const State& s, int pix) const {
         const int ohow = g.OH * g.OW;
         const int n = fdiv(pix, ohow, g.inv_ohow), rem = pix - n * ohow;
         const int oh = fdiv(rem, g.OW, g.inv_ow), ow = rem - oh * g.OW;
@@ -255,15 +244,105 @@ struct EpiAtomic {
 };
 
 // ------------------------------------------------------------------ the kernel
+// LDS image of one operand tile.
+//  * padded   (KC operands, and every fp32 operand): elem(row,k) at row*(BK+VEC) + k
+//  * swizzled (bf16 MC operands): 64-byte rows, the four 16-byte k-slots of a row XOR-permuted
+//    by SWZ(row>>2) so that (a) the transposing 4-byte stores of a half-wave hit 32 distinct banks
+//    and (b) every 16-lane group of the ds_read_b128 fragment loads hits 64 distinct banks.
+__device__ __forceinline__ int swz_slot(int slot, int row) { return slot ^ ((0x78 >> (2 * ((row >> 2) & 3))) & 3); }
+
+template <class T, bool MC> struct TileImage {
+    static constexpr int VEC = Elem<T>::VEC, BK = 4 * VEC;
+    static constexpr bool SWZ = MC && (sizeof(T) == 2);
+    static constexpr int RS = SWZ ? BK : BK + VEC;   // row stride (elements)
+    // element offset of the fragment (8 consecutive k for bf16 / 1 element for fp32) of `row`
+    __device__ static __forceinline__ int frag(int row, int lane) {
+        if constexpr (SWZ) return row * RS + swz_slot(lane >> 4, row) * 8;
+        else if constexpr (sizeof(T) == 2) return row * RS + (lane >> 4) * 8;
+        else return row * RS + (lane >> 4);
+    }
+};
+
+// Stages one operand tile (ROWS x BK) : global -> registers (load) -> LDS (store).
+template <class T, int ROWS, class L> struct Stager {
+    static constexpr int VEC = Elem<T>::VEC, BK = 4 * VEC, SL = ROWS / 64;
+    static constexpr bool MC = L::MC, PACK = MC && (sizeof(T) == 2);
+    static constexpr int NR = PACK ? 2 : SL;   // 16-byte registers held per thread
+    static constexpr int CPR = ROWS / VEC;     // 16-byte chunks per k (MC)
+    typedef TileImage<T, MC> Img;
+    uint4 r[NR];
+    typename L::State st;
+    int rc, kq;                                // MC: row chunk / k index (pair index when PACK)
+    bool active;
+
+    __device__ __forceinline__ void init(const L& l, int row0, int tid) {
+        if constexpr (!MC) { l.init(st, row0, tid); active = true; rc = kq = 0; }
+        else if constexpr (PACK) {             // thread = (k pair kq in 0..15, row chunk rc), kq fastest
+            kq = tid & 15; rc = tid >> 4; active = rc < CPR;
+            l.init(st, row0 + (active ? rc : 0) * VEC);
+        } else {                               // fp32: chunk c = tid + 256*i -> (k = c / CPR, rc = c % CPR)
+            rc = tid % CPR; kq = tid / CPR; active = true;
+            l.init(st, row0 + rc * VEC);
+        }
+    }
+    __device__ __forceinline__ void load(const L& l, int k0) {
+        if constexpr (!MC) {
+#pragma unroll
+            for (int i = 0; i < SL; ++i) r[i] = l.load(st, i, k0);
+        } else if constexpr (PACK) {
+            r[0] = active ? l.load(st, k0 + 2 * kq) : zero16();
+            r[1] = active ? l.load(st, k0 + 2 * kq + 1) : zero16();
+        } else {
+#pragma unroll
+            for (int i = 0; i < SL; ++i) r[i] = l.load(st, k0 + kq + (NTHREADS / CPR) * i);
+        }
+    }
+    __device__ __forceinline__ void store(T* tile, int tid) const {
+        if constexpr (!MC) {
+#pragma unroll
+            for (int i = 0; i < SL; ++i)
+                *reinterpret_cast<uint4*>(tile + ((tid >> 2) + 64 * i) * Img::RS + (tid & 3) * VEC) = r[i];
+        } else if constexpr (PACK) {
+            if (!active) return;
+            // r[0] = rows rc*8..+7 at k = 2*kq, r[1] = same rows at k+1 -> 8 dwords {k, k+1} per row
+            const uint32_t a[4] = {r[0].x, r[0].y, r[0].z, r[0].w}, b[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
+            uint32_t d[8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                d[2 * m] = (a[m] & 0xffffu) | (b[m] << 16);
+                d[2 * m + 1] = (a[m] >> 16) | (b[m] & 0xffff0000u);
+            }
+            const bool odd = rc & 1;           // odd row chunks walk their rows pairwise swapped, so
+            uint32_t* t32 = reinterpret_cast<uint32_t*>(tile);   // the two half-waves use different bank halves
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t v = odd ? d[j ^ 1] : d[j];
+                const int row = rc * 8 + (odd ? (j ^ 1) : j);
+                t32[row * 16 + swz_slot(kq >> 2, row) * 4 + (kq & 3)] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SL; ++i) {
+                const int kl = kq + (NTHREADS / CPR) * i;
+                const T* e = reinterpret_cast<const T*>(&r[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) tile[(rc * VEC + j) * Img::RS + kl] = e[j];
+            }
+        }
+    }
+};
+
 template <class T, int BM, int BN, class AL, class BL, class EP>
 __global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP ep, int K,
                                                                int tiles_n, int kt_per_split) {
     constexpr int VEC = Elem<T>::VEC;
     constexpr int BK = 4 * VEC;        // 64 bytes of k per row
-    constexpr int LDSK = BK + VEC;     // +16 B pad
-    constexpr int SLA = BM / 64, SLB = BN / 64;
+    constexpr int LDSK = BK + VEC;     // padded row (allocation uses the larger image)
     constexpr int MT = BM / 32, NT = BN / 32;
     constexpr int KSTEPS = BK / Mma<T>::KI;
+    typedef TileImage<T, AL::MC> ImgA;
+    typedef TileImage<T, BL::MC> ImgB;
+    static_assert(!(ImgA::SWZ || ImgB::SWZ) || KSTEPS == 1, "swizzled image assumes one MFMA k-step per tile");
     __shared__ __attribute__((aligned(16))) T lds[2][(BM + BN) * LDSK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -274,10 +353,10 @@ __global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP 
     const int kt0 = blockIdx.y * kt_per_split;
     const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
 
-    typename AL::State sa;
-    typename BL::State sb;
-    al.init(sa, m0, tid);
-    bl.init(sb, n0, tid);
+    Stager<T, BM, AL> sa;
+    Stager<T, BN, BL> sb;
+    sa.init(al, m0, tid);
+    sb.init(bl, n0, tid);
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -285,66 +364,34 @@ __global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[SLA], rb[SLB];
-    auto gload = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < SLA; ++i) ra[i] = al.load(sa, i, kt * BK);
-#pragma unroll
-        for (int i = 0; i < SLB; ++i) rb[i] = bl.load(sb, i, kt * BK);
-    };
-    auto lstore = [&](int buf) {
-        T* ta = lds[buf];
-        T* tb = lds[buf] + BM * LDSK;
-#pragma unroll
-        for (int i = 0; i < SLA; ++i) {
-            if constexpr (!AL::MC) {
-                *reinterpret_cast<uint4*>(ta + ((tid >> 2) + 64 * i) * LDSK + (tid & 3) * VEC) = ra[i];
-            } else {
-                constexpr int CPR = BM / VEC;
-                const int c = tid + NTHREADS * i;
-                const int kl = c / CPR, r = (c % CPR) * VEC;
-                const T* e = reinterpret_cast<const T*>(&ra[i]);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) ta[(r + j) * LDSK + kl] = e[j];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < SLB; ++i) {
-            if constexpr (!BL::MC) {
-                *reinterpret_cast<uint4*>(tb + ((tid >> 2) + 64 * i) * LDSK + (tid & 3) * VEC) = rb[i];
-            } else {
-                constexpr int CPR = BN / VEC;
-                const int c = tid + NTHREADS * i;
-                const int kl = c / CPR, r = (c % CPR) * VEC;
-                const T* e = reinterpret_cast<const T*>(&rb[i]);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) tb[(r + j) * LDSK + kl] = e[j];
-            }
-        }
-    };
+    // fragment offsets of this lane inside the A / B images (row = wave offset + lane&15)
+    const int fa0 = ImgA::frag(wm * (BM / 2) + (lane & 15), lane);
+    const int fb0 = ImgB::frag(wn * (BN / 2) + (lane & 15), lane);
 
     if (kt0 < kt1) {
-        gload(kt0);
-        lstore(0);
+        sa.load(al, kt0 * BK);
+        sb.load(bl, kt0 * BK);
+        sa.store(lds[0], tid);
+        sb.store(lds[0] + BM * LDSK, tid);
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int buf = (kt - kt0) & 1;
-            if (kt + 1 < kt1) gload(kt + 1);
-            const T* ta = lds[buf] + (wm * (BM / 2) + (lane & 15)) * LDSK;
-            const T* tb = lds[buf] + (BM + wn * (BN / 2) + (lane & 15)) * LDSK;
+            if (kt + 1 < kt1) { sa.load(al, (kt + 1) * BK); sb.load(bl, (kt + 1) * BK); }
+            const T* ta = lds[buf] + fa0;
+            const T* tb = lds[buf] + BM * LDSK + fb0;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 typename Mma<T>::Frag fa[MT], fb[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = Mma<T>::load(ta + i * 16 * LDSK, lane, kk);
+                for (int i = 0; i < MT; ++i) fa[i] = Mma<T>::load(ta + i * 16 * ImgA::RS, kk);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[j] = Mma<T>::load(tb + j * 16 * LDSK, lane, kk);
+                for (int j = 0; j < NT; ++j) fb[j] = Mma<T>::load(tb + j * 16 * ImgB::RS, kk);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc[i][j] = Mma<T>::mma(fb[j], fa[i], acc[i][j]);
             }
-            if (kt + 1 < kt1) lstore(buf ^ 1);
+            if (kt + 1 < kt1) { sa.store(lds[buf ^ 1], tid); sb.store(lds[buf ^ 1] + BM * LDSK, tid); }
             __syncthreads();
         }
     }
