@@ -5,7 +5,7 @@
 
 One "step" = the reference's whole training-step body (scripts/pretrain_virtex.py:145-163):
 zero_grad -> forward (dropout 0.1 on) -> backward -> gradient all-reduce (N > 1) -> clip 10.0 ->
-SGD(m .9, per-tensor lr/wd) -> Lookahead(5, .5) -> LR schedule, on synthetic COCO-shaped batches
+SGD(m .9, per-tensor lr/wd) -> Lookahead(5, .5) -> LR schedule (fused HIP optimizer kernels), on synthetic COCO-shaped batches
 (224x224 fp32 images, 30-token captions) that are resident in HBM before the timed region.
 Workload at N=1 = BASELINE.json configs[1]: bf16 compute, 256 images per GPU.  For N > 1 the
 driver launches this file under torch.distributed.run, one rank per GPU (weak scaling).
@@ -107,7 +107,7 @@ def main():
     a = parse()
     from virtex_amd import distributed as vd
     import virtex_amd.factories as vf
-    from virtex_amd.optim import PretrainOptimizer
+    from virtex_amd.optim import FusedPretrainOptimizer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and a.gpus > 1:
@@ -126,7 +126,7 @@ def main():
     model = vf.build_bicaptioning_model(textual=a.textual, dropout=a.dropout, compute_dtype=dt).to(dev).train()
     vd.broadcast_parameters(model)
     buckets = vd.GradientBuckets(model)
-    opt = PretrainOptimizer(model, start_step=100)      # inside warm-up: non-zero learning rate
+    opt = FusedPretrainOptimizer(model, buckets, start_step=100)   # inside warm-up: non-zero LR
     batches = [device_batch(a.batch, dev, seed=1000 * rank + i) for i in range(2)]
 
     def step(i):

@@ -158,6 +158,18 @@ int vtx_add(int dtype, const void* a, const void* b, void* out, long n, void* st
 int vtx_gelu_bwd(int dtype, const void* h, const void* da, void* dh, long n, float p_drop, uint64_t seed,
                  void* stream);
 
+/* ---- fused optimizer tail over flat fp32 buffers (csrc/optim.hip) -----------------------
+ * Replaces clip_grad_norm_ + SGD(momentum, per-tensor lr / weight decay) + Lookahead of
+ * scripts/pretrain_virtex.py:157-162, virtex/factories.py:529-545, virtex/optim/lookahead.py:82-102.
+ * p/g/m/slow share one layout described by chunks (offset, length <= vtx_optim_chunk_elems(),
+ * segment id); seg_lr/seg_wd are per-parameter base learning rate and weight decay. */
+int vtx_optim_chunk_elems(void);
+int vtx_sumsq(const float* x, long n, float* partials /*>=1024 floats*/, float* out /*[1]*/, void* stream);
+int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float* slow, const long long* chunk_off,
+                           const int* chunk_len, const int* chunk_seg, int nchunks, const float* seg_lr,
+                           const float* seg_wd, float lr_mult, float momentum, float grad_scale,
+                           const float* sumsq, float max_norm, int do_lookahead, float alpha, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,24 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     }
 }
 
+
+// Sums the per-strip partials of 32 channels with 8 thread groups (block = 256 threads =
+// 32 channels x 8 groups); returns the totals to the group-0 threads.
+__device__ __forceinline__ void sum_partials(const float* __restrict__ sums, int C, int nparts, int c, int grp,
+                                             float& t0, float& t1) {
+    __shared__ float red[2][8][32];
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int p = grp; p < nparts; p += 8) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
+    red[0][grp][threadIdx.x & 31] = a; red[1][grp][threadIdx.x & 31] = b;
+    __syncthreads();
+    t0 = t1 = 0.f;
+    if (grp == 0) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+    }
+}
+
 template <class T>
 __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ mean,
@@ -79,11 +97,11 @@ __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __r
                                        float* __restrict__ shift, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, long long* __restrict__ nbt,
                                        int P, int C, float eps, float momentum, int nparts) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    float t0 = 0.f, t1 = 0.f;
-    for (int b = 0; b < nparts; ++b) { t0 += sums[(size_t)b * 2 * C + c]; t1 += sums[(size_t)b * 2 * C + C + c]; }
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    float t0, t1;
+    sum_partials(sums, C, nparts, c, grp, t0, t1);
+    if (c == 0 && grp == 0 && nbt) *nbt += 1;
+    if (c >= C || grp != 0) return;
     const float ms = t0 / (float)P;                   // mean of (x - x[0][c])
     float var = t1 / (float)P - ms * ms;
     var = var > 0.f ? var : 0.f;
@@ -130,10 +148,10 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, const flo
                                        const float* __restrict__ rstd, float* __restrict__ coef,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int P, int C,
                                        int nparts) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < nparts; ++b) { s1 += sums[(size_t)b * 2 * C + c]; s2 += sums[(size_t)b * 2 * C + C + c]; }
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    float s1, s2;
+    sum_partials(sums, C, nparts, c, grp, s1, s2);
+    if (c >= C || grp != 0) return;
     coef[c] = gamma[c] * rstd[c];
     coef[C + c] = s1 / (float)P;
     coef[2 * C + c] = s2 / (float)P;
@@ -213,10 +231,10 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
         hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta,
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, (const float*)x, sums, gamma, beta,
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const float*)x, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
@@ -247,7 +265,7 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     else
         hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, sums, P, C, rp.TX, rp.rows);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, 256)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
                        dgamma, dbeta, P, C, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,

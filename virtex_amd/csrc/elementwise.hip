@@ -35,12 +35,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
     }
 }
 
+// block = 32 columns x 8 groups of partials
 __global__ void colsum_finalize_kernel(const float* __restrict__ parts, float* __restrict__ out, int C, int nparts) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
     float s = 0.f;
-    for (int b = 0; b < nparts; ++b) s += parts[(size_t)b * C + c];
-    out[c] += s;
+    if (c < C)
+        for (int b = grp; b < nparts; b += 8) s += parts[(size_t)b * C + c];
+    red[grp][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x & 31];
+        out[c] += t;
+    }
 }
 
 template <class T>
@@ -99,7 +108,7 @@ extern "C" int vtx_colsum_acc(int dtype, const void* x, long ld, float* out, flo
         hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, workspace, R, C, TX, rows);
     else
         hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, workspace, R, C, TX, rows);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(vtx_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, workspace, out, C, gx);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(vtx_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, workspace, out, C, gx);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -324,3 +324,17 @@ def gelu_bwd(h, da, p_drop=0.0, seed=0):
     call("vtx_gelu_bwd", c_int(dtype_code(h.dtype)), ptr(h), ptr(da), ptr(dh), c_long(h.numel()), c_float(p_drop),
          c_u64(seed), stream_ptr(h))
     return dh
+
+
+# ---------------------------------------------------------------------------------------
+def sumsq(x, partials, out):
+    call("vtx_sumsq", ptr(x), c_long(x.numel()), ptr(partials), ptr(out), stream_ptr(x))
+    return out
+
+
+def sgd_lookahead_step(p, g, m, slow, chunk_off, chunk_len, chunk_seg, seg_lr, seg_wd, lr_mult, momentum,
+                       grad_scale, sumsq_buf, max_norm, do_lookahead, alpha):
+    call("vtx_sgd_lookahead_step", ptr(p), ptr(g), ptr(m), ptr(slow), ptr(chunk_off), ptr(chunk_len),
+         ptr(chunk_seg), c_int(chunk_off.numel()), ptr(seg_lr), ptr(seg_wd), c_float(lr_mult), c_float(momentum),
+         c_float(grad_scale), ptr(sumsq_buf), c_float(max_norm if max_norm else 0.0),
+         c_int(1 if do_lookahead else 0), c_float(alpha), stream_ptr(p))

@@ -79,3 +79,77 @@ class PretrainOptimizer:
             torch._foreach_copy_(self.slow, data)
         self.step_idx += 1
         self._set_lr()
+
+
+class FusedPretrainOptimizer:
+    """Same arithmetic as `PretrainOptimizer`, executed by two HIP kernels over flat buffers
+    (csrc/optim.hip): parameters, gradients (the data-parallel buckets), momentum and Lookahead slow
+    weights share one layout; per-parameter learning rate / weight decay come from a segment table.
+    No host synchronisation: the clip coefficient is computed on the device from the squared norm."""
+
+    def __init__(self, model: torch.nn.Module, buckets, cnn_lr=0.2, lr=0.001, weight_decay=1e-4, momentum=0.9,
+                 clip_norm=10.0, lookahead_k=5, lookahead_alpha=0.5, total_steps=500000, warmup_steps=10000,
+                 start_step=0, no_decay=NO_DECAY):
+        from . import _lib, ops
+
+        self.ops = ops
+        self.buckets = buckets
+        names = {p: n for n, p in model.named_parameters()}
+        params = buckets.params
+        dev = buckets.flat.device
+        lib = _lib.lib()
+        chunk = lib.vtx_optim_chunk_elems()
+        self.flat_p = torch.empty_like(buckets.flat)
+        offs, lens, segs, seg_lr, seg_wd = [], [], [], [], []
+        off = 0
+        with torch.no_grad():
+            for si, p in enumerate(params):
+                n = p.numel()
+                slot = self.flat_p[off: off + n]
+                if p.dim() == 4 and p.stride(1) == 1 and p.shape[1] > 1:     # (KO,R,S,C) physical
+                    O, I, R, S = p.shape
+                    view = slot.view(O, R, S, I).permute(0, 3, 1, 2)
+                else:
+                    view = slot.view(p.shape)
+                view.copy_(p.data)
+                p.data = view                      # the parameter now lives inside the flat buffer
+                name = names[p]
+                seg_lr.append(cnn_lr if "cnn" in name else lr)
+                seg_wd.append(0.0 if re.match(no_decay, name) else weight_decay)
+                for c0 in range(0, n, chunk):
+                    offs.append(off + c0); lens.append(min(chunk, n - c0)); segs.append(si)
+                off += n
+        self.chunk_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.chunk_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+        self.chunk_seg = torch.tensor(segs, dtype=torch.int32, device=dev)
+        self.seg_lr = torch.tensor(seg_lr, dtype=torch.float32, device=dev)
+        self.seg_wd = torch.tensor(seg_wd, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_slow = self.flat_p.clone()
+        self.partials = torch.empty(1024, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.momentum, self.clip_norm, self.k, self.alpha = momentum, clip_norm, lookahead_k, lookahead_alpha
+        self.kc, self.step_idx = 0, start_step
+        self.total_steps, self.warmup_steps = total_steps, warmup_steps
+
+    def zero_grad(self):
+        self.buckets.zero()
+
+    def grad_norm(self) -> torch.Tensor:
+        """Device tensor holding ||g||_2 of the last step (before grad_scale / clipping)."""
+        return self.sumsq.sqrt()
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0):
+        g = self.buckets.flat
+        if self.clip_norm:
+            self.ops.sumsq(g, self.partials, self.sumsq)
+        self.kc += 1
+        look = self.kc >= self.k
+        if look:
+            self.kc = 0
+        mult = lr_multiplier(self.step_idx, self.total_steps, self.warmup_steps)
+        self.ops.sgd_lookahead_step(self.flat_p, g, self.flat_m, self.flat_slow, self.chunk_off, self.chunk_len,
+                                    self.chunk_seg, self.seg_lr, self.seg_wd, mult, self.momentum, grad_scale,
+                                    self.sumsq, self.clip_norm, look, self.alpha)
+        self.step_idx += 1
