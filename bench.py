@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
 
 
@@ -84,23 +84,42 @@ def kernel_roofline(dtype):
             "avg_launch_us": round(dur * 1e6, 1), "flops_per_launch": flops}
 
 
-def cpu_baseline(batch, steps):
-    """Reference step (oracle port, torch CPU fp32, dropout 0.1) on the host cores."""
+def cpu_baseline(batch, steps, budget_s=40.0):
+    """Reference step (oracle port, torch CPU fp32, dropout 0.1) on the host cores.  The box reports
+    256 logical CPUs but the container's quota is smaller: more threads than the quota make torch's
+    CPU path slower, so the thread count is calibrated first (one step each) and the best one is used
+    for the timed sample; `cores` reports what was actually used."""
     from oracle import bicaptioning as port, synth
 
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     model = port.build_model(dropout=0.1).train()
     step = port.TrainStep(model, start_step=100)
     b = synth.synthetic_batch(batch, seed=0)
-    step(b)                                   # warm-up
+    ncpu = os.cpu_count() or 1
+    best_t, best_threads = None, 1
+    t_start = time.time()
+    for threads in (16, 32, 64, 128, 256):
+        if threads > ncpu or time.time() - t_start > budget_s / 2:
+            break
+        torch.set_num_threads(threads)
+        step(b)                                   # warm-up at this thread count
+        t0 = time.time()
+        step(b)
+        dt = time.time() - t0
+        if best_t is None or dt < best_t:
+            best_t, best_threads = dt, threads
+        elif dt > 1.5 * best_t:
+            break
+    torch.set_num_threads(best_threads)
+    step(b)
+    n = max(1, min(steps, int((budget_s / 2) / max(best_t, 1e-3))))
     t0 = time.time()
-    for _ in range(steps):
+    for _ in range(n):
         step(b)
     dt = time.time() - t0
-    return {"value": round(batch * steps / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{steps} steps of B={batch} (fp32, dropout 0.1, SGD+Lookahead+clip), oracle/bicaptioning.py"}
+    return {"value": round(batch * n / dt, 2), "unit": "images/sec", "cores": best_threads, "kind": "port",
+            "sample": f"{n} steps of B={batch} (fp32, dropout 0.1, SGD+Lookahead+clip), oracle/bicaptioning.py; "
+                      f"thread count calibrated over 16..{ncpu} logical CPUs"}
 
 
 def main():
