@@ -38,6 +38,8 @@ typedef enum {
 int vtx_version(void);
 const char* vtx_backend(void);    /* "hip:gfx950" (product) or "hipemu" (CPU test build) */
 const char* vtx_last_error(void); /* thread-local */
+/* 2 (default): LDS-DMA + transpose-read bf16 contraction kernel; 1: register-staged kernel (A/B tests) */
+int vtx_set_contraction_generation(int gen);
 
 /* ---- LayerNorm(x + dropout(y)) --------------------------------------------------------
  * Replaces aten::dropout + aten::add + aten::layer_norm of the post-norm decoder layer

@@ -60,28 +60,25 @@ __device__ __forceinline__ int fdiv(int n, int d, float inv) {
 template <class T, int SL> struct PlainKC {
     static constexpr bool MC = false;
     const T* p; long ld; int rows; int K;
-    struct State { const T* rp[SL]; int kc; };
-    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
-        s.kc = (tid & 3) * Elem<T>::VEC;
-#pragma unroll
-        for (int i = 0; i < SL; ++i) {
-            const int r = row0 + (tid >> 2) + 64 * i;
-            s.rp[i] = r < rows ? p + (long)r * ld + s.kc : nullptr;
-        }
+    struct State { const T* rp[SL]; int kc[SL]; };
+    // slot i of this thread stages the chunk (global row r, k = k0 + kc)
+    __device__ __forceinline__ void init_slot(State& s, int i, int r, int kc) const {
+        s.kc[i] = kc;
+        s.rp[i] = r < rows ? p + (long)r * ld + kc : nullptr;
     }
-    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
-        return (s.rp[i] && k0 + s.kc < K) ? ld16(s.rp[i] + k0) : zero16();
+    __device__ __forceinline__ const T* ptr(const State& s, int i, int k0) const {
+        return (s.rp[i] && k0 + s.kc[i] < K) ? s.rp[i] + k0 : nullptr;
     }
 };
 // K x rows view, rows contiguous: element (r,k) at p[k*ld + r]
 template <class T, int SL> struct PlainMC {
     static constexpr bool MC = true;
     const T* p; long ld; int rows; int K;
-    struct State { int r0; bool ok; };
-    // r0 = first of the VEC consecutive rows this thread stages; k = global k of the chunk
-    __device__ __forceinline__ void init(State& s, int r0) const { s.r0 = r0; s.ok = r0 < rows; }
-    __device__ __forceinline__ uint4 load(const State& s, int k) const {
-        return (s.ok && k < K) ? ld16(p + (long)k * ld + s.r0) : zero16();
+    struct State { int r0[SL < 2 ? 2 : SL]; };
+    // slot i stages VEC consecutive rows starting at global row r0 (r0 < 0: nothing), at global k
+    __device__ __forceinline__ void init_slot(State& s, int i, int r0) const { s.r0[i] = r0 < rows ? r0 : -1; }
+    __device__ __forceinline__ const T* ptr(const State& s, int i, int k) const {
+        return (s.r0[i] >= 0 && k < K) ? p + (long)k * ld + s.r0[i] : nullptr;
     }
 };
 
@@ -100,28 +97,24 @@ static inline int vtx_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return
 template <class T, int SL> struct ConvFwdA {
     static constexpr bool MC = false;
     const T* x; ConvGeo g; int rows; int K;
-    struct State { long base[SL]; int ih0[SL], iw0[SL]; bool ok[SL]; int kc; };
-    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
-        s.kc = (tid & 3) * Elem<T>::VEC;
-#pragma unroll
-        for (int i = 0; i < SL; ++i) {
-            const int m = row0 + (tid >> 2) + 64 * i;
-            s.ok[i] = m < rows;
-            const int mm = s.ok[i] ? m : 0;
-            const int n = mm / (g.OH * g.OW), rem = mm - n * g.OH * g.OW;
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            s.base[i] = (long)n * g.H * g.W * g.C;
-            s.ih0[i] = oh * g.stride - g.pad;
-            s.iw0[i] = ow * g.stride - g.pad;
-        }
+    struct State { long base[SL]; int ih0[SL], iw0[SL]; bool ok[SL]; int kc[SL]; };
+    __device__ __forceinline__ void init_slot(State& s, int i, int m, int kc) const {
+        s.kc[i] = kc;
+        s.ok[i] = m < rows;
+        const int mm = s.ok[i] ? m : 0;
+        const int n = mm / (g.OH * g.OW), rem = mm - n * g.OH * g.OW;
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        s.base[i] = (long)n * g.H * g.W * g.C;
+        s.ih0[i] = oh * g.stride - g.pad;
+        s.iw0[i] = ow * g.stride - g.pad;
     }
-    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
-        const int k = k0 + s.kc;
+    __device__ __forceinline__ const T* ptr(const State& s, int i, int k0) const {
+        const int k = k0 + s.kc[i];
         const int tap = k >> g.logC, ci = k & (g.C - 1);
         const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
         const int ih = s.ih0[i] + kh, iw = s.iw0[i] + kw;
         const bool ok = s.ok[i] && k < K && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-        return ok ? ld16(x + s.base[i] + ((long)ih * g.W + iw) * g.C + ci) : zero16();
+        return ok ? x + s.base[i] + ((long)ih * g.W + iw) * g.C + ci : nullptr;
     }
 };
 
@@ -129,23 +122,19 @@ template <class T, int SL> struct ConvFwdA {
 template <class T, int SL> struct ConvDgradA {
     static constexpr bool MC = false;
     const T* dy; ConvGeo g; int rows; int K;
-    struct State { long base[SL]; int ihp[SL], iwp[SL]; bool ok[SL]; int kc; };
-    __device__ __forceinline__ void init(State& s, int row0, int tid) const {
-        s.kc = (tid & 3) * Elem<T>::VEC;
-#pragma unroll
-        for (int i = 0; i < SL; ++i) {
-            const int m = row0 + (tid >> 2) + 64 * i;
-            s.ok[i] = m < rows;
-            const int mm = s.ok[i] ? m : 0;
-            const int n = mm / (g.H * g.W), rem = mm - n * g.H * g.W;
-            const int ih = rem / g.W, iw = rem - ih * g.W;
-            s.base[i] = (long)n * g.OH * g.OW * g.KO;
-            s.ihp[i] = ih + g.pad;
-            s.iwp[i] = iw + g.pad;
-        }
+    struct State { long base[SL]; int ihp[SL], iwp[SL]; bool ok[SL]; int kc[SL]; };
+    __device__ __forceinline__ void init_slot(State& s, int i, int m, int kc) const {
+        s.kc[i] = kc;
+        s.ok[i] = m < rows;
+        const int mm = s.ok[i] ? m : 0;
+        const int n = mm / (g.H * g.W), rem = mm - n * g.H * g.W;
+        const int ih = rem / g.W, iw = rem - ih * g.W;
+        s.base[i] = (long)n * g.OH * g.OW * g.KO;
+        s.ihp[i] = ih + g.pad;
+        s.iwp[i] = iw + g.pad;
     }
-    __device__ __forceinline__ uint4 load(const State& s, int i, int k0) const {
-        const int k = k0 + s.kc;
+    __device__ __forceinline__ const T* ptr(const State& s, int i, int k0) const {
+        const int k = k0 + s.kc[i];
         const int tap = k >> g.logKO, co = k & (g.KO - 1);
         const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
         const int th = s.ihp[i] - kh, tw = s.iwp[i] - kw;
@@ -153,7 +142,7 @@ template <class T, int SL> struct ConvDgradA {
         const int oh = th >> g.logStride, ow = tw >> g.logStride;
         const bool ok = s.ok[i] && k < K && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 &&
                         oh < g.OH && ow < g.OW;
-        return ok ? ld16(dy + s.base[i] + ((long)oh * g.OW + ow) * g.KO + co) : zero16();
+        return ok ? dy + s.base[i] + ((long)oh * g.OW + ow) * g.KO + co : nullptr;
     }
 };
 
@@ -161,21 +150,20 @@ template <class T, int SL> struct ConvDgradA {
 template <class T, int SL> struct ConvWgradB {
     static constexpr bool MC = true;
     const T* x; ConvGeo g; int rows; int K;  // rows = R*S*C, K = N*OH*OW
-    struct State { int kh, kw, ci; bool ok; };
-    __device__ __forceinline__ void init(State& s, int r0) const {
-        s.ok = r0 < rows;
+    struct State { int kh[SL < 2 ? 2 : SL], kw[SL < 2 ? 2 : SL], ci[SL < 2 ? 2 : SL]; };
+    __device__ __forceinline__ void init_slot(State& s, int i, int r0) const {
         const int tap = r0 >> g.logC;
-        s.ci = r0 & (g.C - 1);
-        s.kh = (tap * g.rcpS) >> 16;
-        s.kw = tap - s.kh * g.S;
+        s.ci[i] = r0 < rows ? (r0 & (g.C - 1)) : -1;
+        s.kh[i] = (tap * g.rcpS) >> 16;
+        s.kw[i] = tap - s.kh[i] * g.S;
     }
-    __device__ __forceinline__ uint4 load(const State& s, int pix) const {
+    __device__ __forceinline__ const T* ptr(const State& s, int i, int pix) const {
         const int ohow = g.OH * g.OW;
         const int n = fdiv(pix, ohow, g.inv_ohow), rem = pix - n * ohow;
         const int oh = fdiv(rem, g.OW, g.inv_ow), ow = rem - oh * g.OW;
-        const int ih = oh * g.stride - g.pad + s.kh, iw = ow * g.stride - g.pad + s.kw;
-        const bool ok = s.ok && pix < K && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
-        return ok ? ld16(x + (((long)n * g.H + ih) * g.W + iw) * g.C + s.ci) : zero16();
+        const int ih = oh * g.stride - g.pad + s.kh[i], iw = ow * g.stride - g.pad + s.kw[i];
+        const bool ok = s.ci[i] >= 0 && pix < K && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        return ok ? x + (((long)n * g.H + ih) * g.W + iw) * g.C + s.ci[i] : nullptr;
     }
 };
 
@@ -276,25 +264,29 @@ template <class T, int ROWS, class L> struct Stager {
     bool active;
 
     __device__ __forceinline__ void init(const L& l, int row0, int tid) {
-        if constexpr (!MC) { l.init(st, row0, tid); active = true; rc = kq = 0; }
-        else if constexpr (PACK) {             // thread = (k pair kq in 0..15, row chunk rc), kq fastest
+        if constexpr (!MC) {                   // chunk (row = tid/4 + 64 i, k chunk = tid%4)
+            active = true; rc = kq = 0;
+#pragma unroll
+            for (int i = 0; i < SL; ++i) l.init_slot(st, i, row0 + (tid >> 2) + 64 * i, (tid & 3) * VEC);
+        } else if constexpr (PACK) {           // thread = (k pair kq in 0..15, row chunk rc), kq fastest
             kq = tid & 15; rc = tid >> 4; active = rc < CPR;
-            l.init(st, row0 + (active ? rc : 0) * VEC);
+            l.init_slot(st, 0, active ? row0 + rc * VEC : (1 << 30));
         } else {                               // fp32: chunk c = tid + 256*i -> (k = c / CPR, rc = c % CPR)
             rc = tid % CPR; kq = tid / CPR; active = true;
-            l.init(st, row0 + rc * VEC);
+            l.init_slot(st, 0, row0 + rc * VEC);
         }
     }
+    __device__ static __forceinline__ uint4 fetch(const T* p) { return p ? ld16(p) : zero16(); }
     __device__ __forceinline__ void load(const L& l, int k0) {
         if constexpr (!MC) {
 #pragma unroll
-            for (int i = 0; i < SL; ++i) r[i] = l.load(st, i, k0);
+            for (int i = 0; i < SL; ++i) r[i] = fetch(l.ptr(st, i, k0));
         } else if constexpr (PACK) {
-            r[0] = active ? l.load(st, k0 + 2 * kq) : zero16();
-            r[1] = active ? l.load(st, k0 + 2 * kq + 1) : zero16();
+            r[0] = fetch(l.ptr(st, 0, k0 + 2 * kq));
+            r[1] = fetch(l.ptr(st, 0, k0 + 2 * kq + 1));
         } else {
 #pragma unroll
-            for (int i = 0; i < SL; ++i) r[i] = l.load(st, k0 + kq + (NTHREADS / CPR) * i);
+            for (int i = 0; i < SL; ++i) r[i] = fetch(l.ptr(st, 0, k0 + kq + (NTHREADS / CPR) * i));
         }
     }
     __device__ __forceinline__ void store(T* tile, int tid) const {
@@ -404,6 +396,170 @@ __global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP 
                acc[i][j]);
 }
 
+// ------------------------------------------------------------------ bf16 kernel, generation 2
+// Same tiling and epilogues, different staging: both operands go HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB per wave-instruction, no VGPR round trip, no
+// ds_write), the next tile's DMA is in flight under the current tile's MFMAs.
+//  * KC operands: image [row][32 k] (64-byte rows); the DMA destination is lane-linear, so the
+//    XOR swizzle of the four 16-byte k-slots is applied on the SOURCE address (lane (row, slot s')
+//    fetches chunk s' ^ SWZ(row)); fragments = ds_read_b128.
+//  * MC operands: image [k][rows] exactly as in HBM (k-major), row-chunk index XOR-swizzled by k
+//    on the source side; fragments = 2 x ds_read_b64_tr_b16 (the gfx950 LDS transpose read: within a
+//    16-lane group lane i receives element (i%4) of the 8 bytes addressed by lane 4j + i/4, j = 0..3),
+//    so the weight-gradient GEMMs need no transposition work at all.
+static __device__ const uint32_t vtx_zero_page[4] = {0u, 0u, 0u, 0u};
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+template <int ROWS> __device__ __forceinline__ int swz_mc(int chunk, int k) {
+    if constexpr (ROWS == 128) return chunk ^ (((k & 3) << 1) | (((k >> 3) & 1) << 3));
+    else return chunk ^ ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
+}
+
+template <int ROWS, class L> struct DmaStager {
+    static constexpr bool MC = L::MC;
+    static constexpr int NI = ROWS / 64;        // wave-instructions (1 KiB each) per wave per tile
+    static constexpr int CH = ROWS / 8;         // 16-byte row chunks per k (MC image)
+    static constexpr int KPI = 64 / CH;         // k rows per wave-instruction (MC image)
+    typename L::State st;
+    int kl[NI];                                 // MC: local k of each slot
+
+    __device__ __forceinline__ void init(const L& l, int row0, int wave, int lane) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int q = wave + 4 * i;         // which 1 KiB piece of the tile image
+            if constexpr (!MC) {
+                const int row = 16 * q + (lane >> 2);
+                l.init_slot(st, i, row0 + row, 8 * swz_slot(lane & 3, row));
+            } else {
+                kl[i] = q * KPI + lane / CH;
+                l.init_slot(st, i, row0 + 8 * swz_mc<ROWS>(lane % CH, kl[i]));
+            }
+        }
+    }
+    __device__ __forceinline__ void issue(const L& l, int k0, bf16_t* tile, int wave) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bf16_t* src;
+            if constexpr (!MC) src = l.ptr(st, i, k0);
+            else src = l.ptr(st, i, k0 + kl[i]);
+            if (!src) src = reinterpret_cast<const bf16_t*>(vtx_zero_page);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + (wave + 4 * i) * 512),
+                                             16, 0, 0);
+        }
+    }
+    // element offset (inside the tile image) of this lane's fragment source for fragment rows r0..r0+15
+    __device__ static __forceinline__ int frag_off(int r0, int lane) {
+        if constexpr (!MC) { const int row = r0 + (lane & 15); return row * 32 + swz_slot(lane >> 4, row) * 8; }
+        else return 0;
+    }
+    __device__ static __forceinline__ bf16x8_t frag(const bf16_t* tile, int r0, int lane) {
+        if constexpr (!MC) {
+            return *reinterpret_cast<const bf16x8_t*>(tile + frag_off(r0, lane));
+        } else {
+            const int w = lane & 15, ka = 8 * (lane >> 4) + (w >> 2), rr = r0 + 4 * (w & 3);
+            const bf16_t* pa = tile + ka * ROWS + swz_mc<ROWS>(rr >> 3, ka) * 8 + (rr & 7);
+            const bf16_t* pb = tile + (ka + 4) * ROWS + swz_mc<ROWS>(rr >> 3, ka + 4) * 8 + (rr & 7);
+            const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)pa);
+            const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)pb);
+            return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+};
+
+template <int BM, int BN, class AL, class BL, class EP>
+__global__ __launch_bounds__(NTHREADS) void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
+                                                                  int kt_per_split, int abl) {
+    constexpr int BK = 32, MT = BM / 32, NT = BN / 32;
+    constexpr int TILE = (BM + BN) * BK;       // elements per stage
+    constexpr int STAGES = 3;                  // 3 x 16 KiB (128x128): tile kt+2 is in flight under tile kt
+    constexpr int NDMA = BM / 64 + BN / 64;    // DMA instructions per wave per tile
+    __shared__ __attribute__((aligned(1024))) bf16_t lds[STAGES * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int nkt = (K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * kt_per_split;
+    const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
+
+    DmaStager<BM, AL> sa;
+    DmaStager<BN, BL> sb;
+    sa.init(al, m0, wave, lane);
+    sb.init(bl, n0, wave, lane);
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8]); only vmcnt waits
+    constexpr int WAIT_ONE_TILE_LEFT = (NDMA & 0xF) | ((NDMA >> 4) << 14) | (0x7 << 4) | (0xF << 8);
+    constexpr int WAIT_ALL = 0 | (0x7 << 4) | (0xF << 8);
+
+    // Pipeline: three LDS stages, one s_barrier per K step, the DMA of tile kt+2 is issued right after
+    // the barrier of step kt (into the stage tile kt-1 occupied) and has two MFMA phases to land.
+    // (Measured alternative: reading the fragments one step ahead into a second register set was SLOWER,
+    //  540 vs 615 TF/s on 7680x4096x1024 -- see DESIGN.md section 6.)
+    if (kt0 < kt1) {
+        sa.issue(al, kt0 * BK, lds, wave);
+        sb.issue(bl, kt0 * BK, lds + BM * BK, wave);
+        if (kt0 + 1 < kt1) {
+            sa.issue(al, (kt0 + 1) * BK, lds + TILE, wave);
+            sb.issue(bl, (kt0 + 1) * BK, lds + TILE + BM * BK, wave);
+        }
+        int stage = 0;                          // stage holding tile kt
+        for (int kt = kt0; kt < kt1; ++kt) {
+            if (!(abl & 8)) {
+            // this wave's pieces of tile kt have landed (tile kt+1 may still be in flight) ...
+            if (kt + 1 < kt1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_TILE_LEFT);
+            else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            // ... and after the barrier so have everybody's; all waves are also done reading the stage
+            // that held tile kt-1, which is the one tile kt+2 is DMA'd into next.
+            __builtin_amdgcn_s_barrier();
+            }
+            const bf16_t* cur = lds + stage * TILE;
+            if (kt + 2 < kt1 && !(abl & 4)) {
+                const int s2 = stage + 2 >= STAGES ? stage + 2 - STAGES : stage + 2;
+                sa.issue(al, (kt + 2) * BK, lds + s2 * TILE, wave);
+                sb.issue(bl, (kt + 2) * BK, lds + s2 * TILE + BM * BK, wave);
+            }
+            bf16x8_t fa[MT], fb[NT];
+            if (!(abl & 2) || kt == kt0) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = DmaStager<BM, AL>::frag(cur, wm * (BM / 2) + i * 16, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = DmaStager<BN, BL>::frag(cur + BM * BK, wn * (BN / 2) + j * 16, lane);
+            }
+            if (!(abl & 1)) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(fb[j]));
+            }
+            stage = stage + 1 >= STAGES ? 0 : stage + 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            ep(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4),
+               acc[i][j]);
+}
+
+extern int g_vtx_contraction_generation;
+extern int g_vtx_ablate;   // measurement only: bit0 no MFMA, bit1 no fragment reads, bit2 no DMA, bit3 no barrier   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
+
 // ------------------------------------------------------------------ host-side launch
 template <class T, int BM, int BN, class AL, class BL, class EP>
 inline void launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k,
@@ -416,6 +572,13 @@ inline void launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, 
     const int per = vtx_cdiv(nkt, split_k);
     split_k = vtx_cdiv(nkt, per);
     dim3 grid(tiles_m * tiles_n, split_k), block(NTHREADS);
+    if constexpr (sizeof(T) == 2) {
+        if (g_vtx_contraction_generation >= 2) {
+            hipLaunchKernelGGL((contraction_v2_kernel<BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K,
+                               tiles_n, per, g_vtx_ablate);
+            return;
+        }
+    }
     hipLaunchKernelGGL((contraction_kernel<T, BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K,
                        tiles_n, per);
 }
