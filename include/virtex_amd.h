@@ -40,6 +40,8 @@ const char* vtx_backend(void);    /* "hip:gfx950" (product) or "hipemu" (CPU tes
 const char* vtx_last_error(void); /* thread-local */
 /* 2 (default): LDS-DMA + transpose-read bf16 contraction kernel; 1: register-staged kernel (A/B tests) */
 int vtx_set_contraction_generation(int gen);
+int vtx_set_ablation(int bits);        /* measurement only (tools/ablate_gemm.py) */
+int vtx_set_tile_override(int cand);   /* tests: force a block tile; -1 = automatic */
 
 /* ---- LayerNorm(x + dropout(y)) --------------------------------------------------------
  * Replaces aten::dropout + aten::add + aten::layer_norm of the post-norm decoder layer
@@ -64,12 +66,14 @@ int vtx_layernorm_residual_bwd(int dtype, const void* x, const void* y, const fl
  *   out_f32 != 0: C/residual/preact are fp32 even when dtype is bf16 (vocabulary logits).
  * vtx_gemm_tn_acc : C[M][N] (fp32) += alpha * A[K][M]^T . B[K][N]   (weight gradients;
  *   replaces the mm inside aten::linear_backward / 1x1 convolution_backward).  split_k <= 0
- *   lets the library choose; partial sums are combined with fp32 atomics. */
+ *   lets the library choose; slices write partial tiles into `workspace` ([split_k][M][N] fp32, may be
+ *   NULL => one slice) which a reduce kernel adds into C; deterministic (no atomics). */
 int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                 void* C, long ldc, const float* bias, const void* residual, long ldr, void* preact,
                 int act, float alpha, float p_drop, uint64_t seed, int out_f32, void* stream);
 int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
-                    float* C, long ldc, float alpha, int split_k, void* stream);
+                    float* C, long ldc, float alpha, int split_k, float* workspace, long workspace_floats,
+                    void* stream);
 
 /* ---- NHWC convolutions (im2col-free implicit GEMM on MFMA; csrc/conv_*.hip) -------------
  * Replace aten::convolution / convolution_backward of the torchvision ResNet reached from
@@ -83,7 +87,8 @@ int vtx_conv2d_dgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S
                      const void* dy, const void* wt, void* dx, const void* residual /*nullable: dx += */,
                      void* stream);
 int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
-                     const void* x, const void* dy, float* dw, int split_k, void* stream);
+                     const void* x, const void* dy, float* dw, int split_k, float* workspace,
+                     long workspace_floats, void* stream);
 
 /* ---- BatchNorm2d (training) + ReLU + residual on NHWC, x viewed as [P=N*H*W][C] ---------
  * Replaces aten::batch_norm/relu_/add_ (+backward) of torchvision's Bottleneck

@@ -207,6 +207,10 @@ inline hipemu_f32x16 hipemu_mfma_32x32x2_f32(float a, float b, hipemu_f32x16 c) 
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(x) ((void)0)   /* loads and LDS-DMA are synchronous in the emulator */
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
+/* wave_barrier is only a scheduling fence on hardware (a wave runs in lockstep); the fibres of a wave do not */
+#define __builtin_amdgcn_wave_barrier() do { int z_ = 0; (void)hipemu::wave_exchange(&z_, sizeof(z_)); } while (0)
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_nontemporal_load(p) (*(p))

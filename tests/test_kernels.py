@@ -332,3 +332,45 @@ def test_small_helpers(backend, dtype):
     hr = h.float().requires_grad_()
     F.gelu(hr).backward(da.float())
     assert rel_err(ops.gelu_bwd(h.to(dev), da.to(dev)).float().cpu(), hr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5])
+def test_contraction_tile_variants_bf16(backend, cand):
+    """Every block-tile configuration of the generation-2 bf16 kernel (256x256 ... 64x64), on all
+    loader kinds: row-major, k-major (transpose-read) and the three conv gathers."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(cand)
+    try:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
+        M, N, K = 300, 520, 96
+        a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
+        bias = torch.randn(N, generator=g); res = torch.randn(M, N, generator=g).to(dt)
+        out = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), res.to(dev), act=ops.ACT_GELU)
+        ref = F.gelu(a.float() @ b.float().t() + bias) + res.float()
+        assert rel_err(out.float().cpu(), ref) < 1e-2
+        out32 = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_f32=True)
+        assert rel_err(out32.cpu(), a.float() @ b.float().t() + bias) < 1e-2
+        at = torch.randn(200, 264, generator=g).to(dt); bt = torch.randn(200, 520, generator=g).to(dt)
+        c0 = torch.randn(264, 520, generator=g)
+        acc = ops.gemm_tn_acc(at.to(dev), bt.to(dev), c0.clone().to(dev), split_k=2)
+        assert rel_err(acc.cpu(), c0 + at.float().t() @ bt.float()) < 1e-2
+        # convs: 3x3 stride 1 and stride 2
+        for (stride, H) in ((1, 9), (2, 10)):
+            x = torch.randn(3, H, H, 32, generator=g).to(dt)
+            w = (torch.randn(64, 3, 3, 32, generator=g) / 17).to(dt)
+            xr = x.float().permute(0, 3, 1, 2).requires_grad_(); wr = w.float().permute(0, 3, 1, 2).requires_grad_()
+            yr = F.conv2d(xr, wr, stride=stride, padding=1)
+            dy = torch.randn(yr.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dt)
+            yr.backward(dy.float().permute(0, 3, 1, 2))
+            y = ops.conv2d_fwd(x.to(dev), w.to(dev), stride, 1)
+            assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < 1e-2
+            dx = ops.conv2d_dgrad(dy.to(dev), w.permute(3, 1, 2, 0).contiguous().to(dev), x.shape, stride, 1)
+            assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < 1e-2
+            dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), torch.zeros(64, 3, 3, 32, device=dev), stride, 1)
+            assert rel_err(dw.cpu(), wr.grad.permute(0, 2, 3, 1)) < 2e-2
+    finally:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))

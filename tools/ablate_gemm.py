@@ -14,7 +14,9 @@ def t():
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 20 * 1e3
 names = {0: "full", 1: "no MFMA", 2: "no frag reads", 4: "no DMA", 8: "no barrier/wait", 3: "no MFMA+no reads", 6: "no reads+no DMA", 7: "only barrier", 14: "only MFMA", 15: "nothing"}
-for bits, n in names.items():
-    _lib.lib().vtx_set_ablation(ctypes.c_int(bits))
-    us = t()
-    print(f"abl {bits:2d} {n:22s}: {us:7.1f} us  ({2*M*N*K/us/1e6:7.1f} TF/s equiv)", flush=True)
+for cand, cn in ((0, "256x256"), (1, "256x128"), (2, "128x128")):
+    _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
+    for bits, n in names.items():
+        _lib.lib().vtx_set_ablation(ctypes.c_int(bits))
+        us = t()
+        print(f"{cn} abl {bits:2d} {n:22s}: {us:7.1f} us  ({2*M*N*K/us/1e6:7.1f} TF/s equiv)", flush=True)

@@ -9,6 +9,10 @@
 
 using namespace vtxg;
 
+vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
+void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
+int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats);
+
 namespace {
 
 template <class T, class TO>
@@ -25,11 +29,12 @@ int gemm_nt_t(int M, int N, int K, const void* A, long lda, const void* B, long 
 
 template <class T>
 int gemm_tn_t(int M, int N, int K, const void* A, long lda, const void* B, long ldb, float* C, long ldc,
-              float alpha, int split_k, hipStream_t st) {
-    EpiAtomic ep{C, ldc, alpha, M, N};
+              float alpha, int split_k, float* ws, hipStream_t st) {
+    EpiStore<float> ep = vtx_splitk_epilogue(C, ldc, alpha, M, N, split_k, ws);
     launch_auto<T, PlainMC, PlainMC>(
         [&](auto& a) { a.p = (const T*)A; a.ld = lda; a.rows = M; a.K = K; },
         [&](auto& b) { b.p = (const T*)B; b.ld = ldb; b.rows = N; b.K = K; }, ep, M, N, K, split_k, st);
+    if (split_k > 1) vtx_splitk_reduce(ws, split_k, M, N, C, ldc, st);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -38,13 +43,58 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-int vtx_pick_split_k(int M, int N, int K, int bk) {
+vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
+void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
+
+// Split-K policy for the weight-gradient GEMMs: enough slices to give every CU ~2 blocks, never fewer
+// than 8 K-steps per slice, bounded by the workspace ([slices][M][N] fp32 partial sums).
+int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
     const long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
     const int nkt = vtx_cdiv(K, bk);
-    long s = (1024 + tiles - 1) / tiles;
-    if (s > nkt / 4) s = nkt / 4;
+    long s = (512 + tiles - 1) / tiles;
+    if (s > nkt / 8) s = nkt / 8;
+    const long cap = ws_floats / ((long)M * N);
+    if (s > cap) s = cap;
     if (s < 1) s = 1;
-    return (int)s;
+    // the launch code rounds the slice length up; make the slice count exact
+    const int per = vtx_cdiv(nkt, (int)s);
+    return vtx_cdiv(nkt, per);
+}
+
+namespace {
+// C[m][n] += sum_s ws[s][m][n]      (alpha already applied by the GEMM epilogue)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long MN, int N,
+                                                            float* __restrict__ C, long ldc) {
+    const long nv = MN / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float4 a = reinterpret_cast<const float4*>(ws)[i];
+        for (int s2 = 1; s2 < S; ++s2) {
+            const float4 b = reinterpret_cast<const float4*>(ws + (long)s2 * MN)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const long e = i * 4, m = e / N, n = e - m * N;      // N % 4 == 0: a float4 never straddles rows
+        float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+        float4 c = *dst;
+        c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+        *dst = c;
+    }
+}
+}  // namespace
+
+vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws) {
+    using namespace vtxg;
+    if (split_k > 1)   // slices write plain partial tiles into the workspace
+        return EpiStore<float>{ws, (long)N, nullptr, nullptr, 0, nullptr, ACT_NONE, alpha, make_dropout(0.f, 0), M, N,
+                               (long)M * N};
+    // one slice: read-modify-write of the fp32 gradient itself (tiles are disjoint: no atomics needed)
+    return EpiStore<float>{C, ldc, nullptr, C, ldc, nullptr, ACT_NONE, alpha, make_dropout(0.f, 0), M, N, 0};
+}
+
+void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st) {
+    const long MN = (long)M * N;
+    long g = (MN / 4 + 255) / 256;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
 }
 
 extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
@@ -70,7 +120,8 @@ extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long l
 }
 
 extern "C" int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
-                               long ldb, float* C, long ldc, float alpha, int split_k, void* stream) {
+                               long ldb, float* C, long ldc, float alpha, int split_k, float* workspace,
+                               long workspace_floats, void* stream) {
     VTX_CHECK(A && B && C, VTX_ERR_ARG, "gemm_tn_acc: null pointer");
     VTX_CHECK(M > 0 && N > 0 && K >= 0, VTX_ERR_ARG, "gemm_tn_acc: bad shape %dx%dx%d", M, N, K);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
@@ -78,9 +129,18 @@ extern "C" int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, lo
     VTX_CHECK(M % vec == 0 && N % vec == 0 && lda % vec == 0 && ldb % vec == 0, VTX_ERR_SHAPE,
               "gemm_tn_acc: M/N/lda/ldb must be multiples of %d (M=%d N=%d K=%d)", vec, M, N, K);
     VTX_CHECK(aligned16(A) && aligned16(B), VTX_ERR_SHAPE, "gemm_tn_acc: operands must be 16-byte aligned");
+    VTX_CHECK(N % 4 == 0 && ldc % 4 == 0 && aligned16(C), VTX_ERR_SHAPE, "gemm_tn_acc: N and ldc must be multiples of 4, C 16-byte aligned");
     if (K == 0) return VTX_OK;
-    if (split_k <= 0) split_k = vtx_pick_split_k(M, N, K, 4 * vec);
+    const long wsf = workspace ? workspace_floats : 0;
+    if (split_k <= 0) split_k = vtx_pick_split_k(M, N, K, 4 * vec, wsf);
+    else {
+        const int nkt = vtx_cdiv(K, 4 * vec);
+        if (split_k > nkt) split_k = nkt;
+        split_k = vtx_cdiv(nkt, vtx_cdiv(nkt, split_k));
+    }
+    VTX_CHECK(split_k == 1 || (long)split_k * M * N <= wsf, VTX_ERR_WORKSPACE,
+              "gemm_tn_acc: split_k=%d needs %ld workspace floats, got %ld", split_k, (long)split_k * M * N, wsf);
     if (dtype == VTX_BF16)
-        return gemm_tn_t<bf16_t>(M, N, K, A, lda, B, ldb, C, ldc, alpha, split_k, (hipStream_t)stream);
-    return gemm_tn_t<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, split_k, (hipStream_t)stream);
+        return gemm_tn_t<bf16_t>(M, N, K, A, lda, B, ldb, C, ldc, alpha, split_k, workspace, (hipStream_t)stream);
+    return gemm_tn_t<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, split_k, workspace, (hipStream_t)stream);
 }

@@ -188,10 +188,77 @@ template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float* 
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
 }
 
+template <class T> __device__ __forceinline__ void st4v(T* p, f32x4_t v);
+template <> __device__ __forceinline__ void st4v<float>(float* p, f32x4_t v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void st4v<bf16_t>(bf16_t* p, f32x4_t v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
+                                              (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+}
+__device__ __forceinline__ uint32_t bf2_add(uint32_t a, uint32_t b) {   // two packed bf16 + two packed bf16
+    const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
+    const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+template <class T> __device__ __forceinline__ uint4 add16(uint4 a, uint4 b);
+template <> __device__ __forceinline__ uint4 add16<bf16_t>(uint4 a, uint4 b) {
+    return make_uint4(bf2_add(a.x, b.x), bf2_add(a.y, b.y), bf2_add(a.z, b.z), bf2_add(a.w, b.w));
+}
+template <> __device__ __forceinline__ uint4 add16<float>(uint4 a, uint4 b) {
+    return make_uint4(__float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x)),
+                      __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y)),
+                      __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z)),
+                      __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w)));
+}
+
 // out = dropout(act(acc*alpha + bias)) + residual ; optional copy of the pre-activation
 template <class T> struct EpiStore {
+    static constexpr bool STAGED = true;   // generation-2 kernel: 16-byte stores via a wave-private LDS strip
+    typedef T Out;
     T* out; long ldc; const float* bias; const T* residual; long ldr; T* preact; int act;
     float alpha; Dropout drop; int M, N;
+    long split_stride = 0;   // split-K: slice blockIdx.y writes its partial result at out + blockIdx.y*split_stride
+    // per-lane part (4 consecutive n of one m): everything except the residual add and the store
+    __device__ __forceinline__ f32x4_t transform(int m, int n, f32x4_t v) const {
+        if (m >= M || n >= N) return v;
+        v *= alpha;
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        const long o = (long)m * ldc + n;
+        if (preact) st4v<T>(preact + o, v);
+        if (act == ACT_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+        } else if (act == ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        if (drop.thresh) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = drop.apply(v[j], (uint64_t)(o + j));
+        }
+        return v;
+    }
+    // 16 bytes (8 bf16 / 4 fp32) of row m starting at column n: + residual, store.  N is a multiple of 4,
+    // so a chunk is either entirely inside the row, or (bf16 only) its first half is.
+    __device__ __forceinline__ void store_wide(int m, int n, uint4 w) const {
+        if (m >= M || n >= N) return;
+        constexpr int EPV = 16 / (int)sizeof(T);
+        const long o = (long)m * ldc + n + (long)blockIdx.y * split_stride;
+        const bool full = n + EPV <= N;
+        if (residual) {
+            if (full) w = add16<T>(w, *reinterpret_cast<const uint4*>(residual + (long)m * ldr + n));
+            else {
+                const uint2 r = *reinterpret_cast<const uint2*>(residual + (long)m * ldr + n);
+                w = add16<T>(w, make_uint4(r.x, r.y, 0u, 0u));
+            }
+        }
+        if (full) *reinterpret_cast<uint4*>(out + o) = w;
+        else *reinterpret_cast<uint2*>(out + o) = make_uint2(w.x, w.y);   // bf16: 4 elements
+    }
     __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
         if (m >= M || n >= N) return;
         float v[4] = {acc[0] * alpha, acc[1] * alpha, acc[2] * alpha, acc[3] * alpha};
@@ -199,7 +266,7 @@ template <class T> struct EpiStore {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += bias[n + j];
         }
-        const long o = (long)m * ldc + n;
+        const long o = (long)m * ldc + n + (long)blockIdx.y * split_stride;
         if (preact) st4<T>(preact + o, v);
         if (act == ACT_GELU) {
 #pragma unroll
@@ -222,7 +289,11 @@ template <class T> struct EpiStore {
 };
 // out(fp32) += alpha * acc     (split-K partial sums and "+=" gradient accumulation)
 struct EpiAtomic {
+    static constexpr bool STAGED = false;
+    typedef float Out;
     float* out; long ldc; float alpha; int M, N;
+    __device__ __forceinline__ f32x4_t transform(int, int, f32x4_t v) const { return v; }
+    __device__ __forceinline__ void store_wide(int, int, uint4) const {}
     __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
         if (m >= M || n >= N) return;
         float* o = out + (long)m * ldc + n;
@@ -411,26 +482,27 @@ static __device__ const uint32_t vtx_zero_page[4] = {0u, 0u, 0u, 0u};
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 
 template <int ROWS> __device__ __forceinline__ int swz_mc(int chunk, int k) {
-    if constexpr (ROWS == 128) return chunk ^ (((k & 3) << 1) | (((k >> 3) & 1) << 3));
+    if constexpr (ROWS >= 128) return chunk ^ (((k & 3) << 1) | (((k >> 3) & 1) << 3));
     else return chunk ^ ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
 }
 
-template <int ROWS, class L> struct DmaStager {
+template <int ROWS, int NW, class L> struct DmaStager {
     static constexpr bool MC = L::MC;
-    static constexpr int NI = ROWS / 64;        // wave-instructions (1 KiB each) per wave per tile
+    static constexpr int NI = ROWS / (16 * NW); // wave-instructions (1 KiB each) per wave per tile
     static constexpr int CH = ROWS / 8;         // 16-byte row chunks per k (MC image)
-    static constexpr int KPI = 64 / CH;         // k rows per wave-instruction (MC image)
+    static constexpr int KPI = 64 / CH > 0 ? 64 / CH : 1;   // k rows per wave-instruction (MC image)
+    static_assert(NI >= 1, "tile too small for this many waves");
     typename L::State st;
     int kl[NI];                                 // MC: local k of each slot
 
     __device__ __forceinline__ void init(const L& l, int row0, int wave, int lane) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int q = wave + 4 * i;         // which 1 KiB piece of the tile image
+            const int q = wave + NW * i;        // which 1 KiB piece of the tile image
             if constexpr (!MC) {
                 const int row = 16 * q + (lane >> 2);
                 l.init_slot(st, i, row0 + row, 8 * swz_slot(lane & 3, row));
-            } else {
+            } else if constexpr (CH <= 64) {
                 kl[i] = q * KPI + lane / CH;
                 l.init_slot(st, i, row0 + 8 * swz_mc<ROWS>(lane % CH, kl[i]));
             }
@@ -444,18 +516,14 @@ template <int ROWS, class L> struct DmaStager {
             else src = l.ptr(st, i, k0 + kl[i]);
             if (!src) src = reinterpret_cast<const bf16_t*>(vtx_zero_page);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + (wave + 4 * i) * 512),
+                                             (__attribute__((address_space(3))) void*)(tile + (wave + NW * i) * 512),
                                              16, 0, 0);
         }
     }
-    // element offset (inside the tile image) of this lane's fragment source for fragment rows r0..r0+15
-    __device__ static __forceinline__ int frag_off(int r0, int lane) {
-        if constexpr (!MC) { const int row = r0 + (lane & 15); return row * 32 + swz_slot(lane >> 4, row) * 8; }
-        else return 0;
-    }
     __device__ static __forceinline__ bf16x8_t frag(const bf16_t* tile, int r0, int lane) {
         if constexpr (!MC) {
-            return *reinterpret_cast<const bf16x8_t*>(tile + frag_off(r0, lane));
+            const int row = r0 + (lane & 15);
+            return *reinterpret_cast<const bf16x8_t*>(tile + row * 32 + swz_slot(lane >> 4, row) * 8);
         } else {
             const int w = lane & 15, ka = 8 * (lane >> 4) + (w >> 2), rr = r0 + 4 * (w & 3);
             const bf16_t* pa = tile + ka * ROWS + swz_mc<ROWS>(rr >> 3, ka) * 8 + (rr & 7);
@@ -467,26 +535,31 @@ template <int ROWS, class L> struct DmaStager {
     }
 };
 
-template <int BM, int BN, class AL, class BL, class EP>
-__global__ __launch_bounds__(NTHREADS) void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
-                                                                  int kt_per_split, int abl) {
-    constexpr int BK = 32, MT = BM / 32, NT = BN / 32;
+// Block = WM x WN waves; block tile BM x BN; wave tile (BM/WM) x (BN/WN).  Large tiles matter for the
+// L2 -> LDS bandwidth, not only for LDS: a 128x128 tile needs 2*(128+128)*64 B per 2*128*128*32 flop
+// = 64 flop/B, i.e. 39 TB/s of cache bandwidth at the MFMA peak (L2 delivers ~34); 256x256 needs half.
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+__global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
+                                                                      int kt_per_split, int abl) {
+    constexpr int NW = WM * WN, BK = 32, WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int TILE = (BM + BN) * BK;       // elements per stage
-    constexpr int STAGES = 3;                  // 3 x 16 KiB (128x128): tile kt+2 is in flight under tile kt
-    constexpr int NDMA = BM / 64 + BN / 64;    // DMA instructions per wave per tile
-    __shared__ __attribute__((aligned(1024))) bf16_t lds[STAGES * TILE];
+    constexpr int STAGES = 3;
+    typedef DmaStager<BM, NW, AL> SA;
+    typedef DmaStager<BN, NW, BL> SB;
+    constexpr int NDMA = SA::NI + SB::NI;      // DMA instructions per wave per tile
+    HIP_DYNAMIC_SHARED(bf16_t, lds)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int tile = blockIdx.x;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nkt = (K + BK - 1) / BK;
     const int kt0 = blockIdx.y * kt_per_split;
     const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
 
-    DmaStager<BM, AL> sa;
-    DmaStager<BN, BL> sb;
+    SA sa;
+    SB sb;
     sa.init(al, m0, wave, lane);
     sb.init(bl, n0, wave, lane);
 
@@ -502,8 +575,6 @@ __global__ __launch_bounds__(NTHREADS) void contraction_v2_kernel(AL al, BL bl, 
 
     // Pipeline: three LDS stages, one s_barrier per K step, the DMA of tile kt+2 is issued right after
     // the barrier of step kt (into the stage tile kt-1 occupied) and has two MFMA phases to land.
-    // (Measured alternative: reading the fragments one step ahead into a second register set was SLOWER,
-    //  540 vs 615 TF/s on 7680x4096x1024 -- see DESIGN.md section 6.)
     if (kt0 < kt1) {
         sa.issue(al, kt0 * BK, lds, wave);
         sb.issue(bl, kt0 * BK, lds + BM * BK, wave);
@@ -514,12 +585,12 @@ __global__ __launch_bounds__(NTHREADS) void contraction_v2_kernel(AL al, BL bl, 
         int stage = 0;                          // stage holding tile kt
         for (int kt = kt0; kt < kt1; ++kt) {
             if (!(abl & 8)) {
-            // this wave's pieces of tile kt have landed (tile kt+1 may still be in flight) ...
-            if (kt + 1 < kt1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_TILE_LEFT);
-            else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
-            // ... and after the barrier so have everybody's; all waves are also done reading the stage
-            // that held tile kt-1, which is the one tile kt+2 is DMA'd into next.
-            __builtin_amdgcn_s_barrier();
+                // this wave's pieces of tile kt have landed (tile kt+1 may still be in flight) ...
+                if (kt + 1 < kt1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_TILE_LEFT);
+                else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+                // ... and after the barrier so have everybody's; all waves are also done reading the
+                // stage that held tile kt-1, which is the one tile kt+2 is DMA'd into next.
+                __builtin_amdgcn_s_barrier();
             }
             const bf16_t* cur = lds + stage * TILE;
             if (kt + 2 < kt1 && !(abl & 4)) {
@@ -530,16 +601,16 @@ __global__ __launch_bounds__(NTHREADS) void contraction_v2_kernel(AL al, BL bl, 
             bf16x8_t fa[MT], fb[NT];
             if (!(abl & 2) || kt == kt0) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = DmaStager<BM, AL>::frag(cur, wm * (BM / 2) + i * 16, lane);
+                for (int i = 0; i < MT; ++i) fa[i] = SA::frag(cur, wm * WTM + i * 16, lane);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = DmaStager<BN, BL>::frag(cur + BM * BK, wn * (BN / 2) + j * 16, lane);
+                for (int j = 0; j < NT; ++j) fb[j] = SB::frag(cur + BM * BK, wn * WTN + j * 16, lane);
             }
             if (!(abl & 1)) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
@@ -549,21 +620,49 @@ __global__ __launch_bounds__(NTHREADS) void contraction_v2_kernel(AL al, BL bl, 
             stage = stage + 1 >= STAGES ? 0 : stage + 1;
         }
     }
+    // D = Btile x Atile  =>  lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
+    if constexpr (!EP::STAGED) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            ep(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4),
-               acc[i][j]);
+            for (int j = 0; j < NT; ++j)
+                ep(m0 + wm * WTM + i * 16 + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j]);
+    } else {
+        // Wide epilogue: 16 rows at a time go through a wave-private LDS strip so that every global
+        // access is 16 bytes per lane and 8 (bf16) / 4 (fp32) full 128/256-byte row segments per
+        // wave-instruction instead of sixteen 32-byte ones.
+        typedef typename EP::Out TO;
+        constexpr int ROWB = WTN * (int)sizeof(TO) + 16;          // padded strip row (bytes)
+        constexpr int CPR = WTN * (int)sizeof(TO) / 16;           // 16-byte chunks per row
+        constexpr int EPV = 16 / (int)sizeof(TO);                 // elements per chunk
+        __syncthreads();                                          // every wave is done with the stages
+        char* strip = reinterpret_cast<char*>(lds) + wave * (16 * ROWB);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mrow = m0 + wm * WTM + i * 16;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4_t v = ep.transform(mrow + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j]);
+                st4v<TO>(reinterpret_cast<TO*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = lane; c < 16 * CPR; c += 64) {
+                const int r = c / CPR, ch = c % CPR;
+                const uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
+                ep.store_wide(mrow + r, n0 + wn * WTN + ch * EPV, w);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
 }
 
-extern int g_vtx_contraction_generation;
-extern int g_vtx_ablate;   // measurement only: bit0 no MFMA, bit1 no fragment reads, bit2 no DMA, bit3 no barrier   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
+extern int g_vtx_contraction_generation;   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
+extern int g_vtx_ablate;   // measurement only: bit0 no MFMA, bit1 no fragment reads, bit2 no DMA, bit3 no barrier
 
 // ------------------------------------------------------------------ host-side launch
 template <class T, int BM, int BN, class AL, class BL, class EP>
-inline void launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k,
-                        hipStream_t st) {
+inline void launch_v1(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
     constexpr int BK = 4 * Elem<T>::VEC;
     const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
     const int nkt = vtx_cdiv(K, BK);
@@ -572,33 +671,87 @@ inline void launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, 
     const int per = vtx_cdiv(nkt, split_k);
     split_k = vtx_cdiv(nkt, per);
     dim3 grid(tiles_m * tiles_n, split_k), block(NTHREADS);
-    if constexpr (sizeof(T) == 2) {
-        if (g_vtx_contraction_generation >= 2) {
-            hipLaunchKernelGGL((contraction_v2_kernel<BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K,
-                               tiles_n, per, g_vtx_ablate);
+    hipLaunchKernelGGL((contraction_kernel<T, BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K, tiles_n, per);
+}
+
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+inline void launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
+    constexpr int BK = 32;
+    const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
+    const int nkt = vtx_cdiv(K, BK);
+    if (split_k < 1) split_k = 1;
+    if (split_k > nkt) split_k = nkt;
+    const int per = vtx_cdiv(nkt, split_k);
+    split_k = vtx_cdiv(nkt, per);
+    constexpr size_t lds_bytes = 3 * (size_t)(BM + BN) * BK * 2;
+    auto kern = contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP>;
+    static bool attr_set = false;
+    if (lds_bytes > 65536 && !attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    dim3 grid(tiles_m * tiles_n, split_k), block(64 * WM * WN);
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
+}
+
+// Tile choice.  Score = (tile efficiency) x (wave quantisation of the grid over 256 CUs) x (padding
+// efficiency); candidates with BN > what N needs are skipped.
+struct TileCand { int bm, bn, resident; float eff; };
+extern int g_vtx_tile_override;   // tests: force a candidate (-1 = automatic)
+inline int pick_tile(int M, int N, int splits, bool allow256) {
+    if (g_vtx_tile_override >= 0 && (allow256 || g_vtx_tile_override >= 2)) return g_vtx_tile_override;
+    // eff = measured relative throughput on a large NT GEMM (tools/ablate_gemm.py: 256x128 806 TF/s,
+    // 128x128 680, 256x256 567 -- one resident block per CU cannot hide its own epilogue)
+    static const TileCand cands[6] = {{256, 256, 1, 0.70f}, {256, 128, 2, 1.00f}, {128, 128, 3, 0.84f},
+                                      {128, 64, 4, 0.55f}, {64, 128, 4, 0.55f}, {64, 64, 4, 0.35f}};
+    int best = 5; float best_score = -1.f;
+    for (int c = 0; c < 6; ++c) {
+        const TileCand& t = cands[c];
+        if (!allow256 && t.bm == 256) continue;
+        if (t.bn > 64 && N <= 64) continue;
+        if (t.bn > 128 && N <= 128) continue;
+        if (t.bm > 64 && M <= 64) continue;
+        const long tm = vtx_cdiv(M, t.bm), tn = vtx_cdiv(N, t.bn);
+        const long blocks = tm * tn * (splits < 1 ? 1 : splits);
+        const long slots = 256L * t.resident;
+        const float quant = (float)blocks / (float)(((blocks + slots - 1) / slots) * slots);
+        const float pad = ((float)M * (float)N) / ((float)(tm * t.bm) * (float)(tn * t.bn));
+        const float score = t.eff * quant * pad;
+        if (score > best_score) { best_score = score; best = c; }
+    }
+    return best;
+}
+
+template <class T, template <class, int> class ALT, template <class, int> class BLT, class EP, class FA, class FB>
+inline void launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
+    constexpr bool BF = sizeof(T) == 2;
+    const bool v2 = BF && g_vtx_contraction_generation >= 2;
+    const int c = pick_tile(M, N, split_k, v2);
+#define VTX_V1(BM_, BN_, SA_, SB_)                                                          \
+    { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v1<T, BM_, BN_>(a, b, ep, M, N, K, split_k, st); }
+#define VTX_V2(BM_, BN_, WM_, WN_, SA_, SB_)                                                \
+    { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v2<BM_, BN_, WM_, WN_>(a, b, ep, M, N, K, split_k, st); }
+    if constexpr (BF) {
+        if (v2) {
+            switch (c) {
+                case 0: VTX_V2(256, 256, 2, 4, 2, 2) break;
+                case 1: VTX_V2(256, 128, 4, 2, 2, 1) break;
+                case 2: VTX_V2(128, 128, 2, 2, 2, 2) break;
+                case 3: VTX_V2(128, 64, 2, 2, 2, 1) break;
+                case 4: VTX_V2(64, 128, 2, 2, 1, 2) break;
+                default: VTX_V2(64, 64, 2, 2, 1, 1) break;
+            }
             return;
         }
     }
-    hipLaunchKernelGGL((contraction_kernel<T, BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K,
-                       tiles_n, per);
-}
-
-// Tile choice: 128x128 by default; narrower N tile for N <= 64; smaller M tile when M is tiny
-// or when the grid would not fill the 256 CUs.
-template <class T, template <class, int> class ALT, template <class, int> class BLT, class EP, class FA, class FB>
-inline void launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
-    const bool n64 = N <= 64;
-    const long blocks128 = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, n64 ? 64 : 128) * (split_k < 1 ? 1 : split_k);
-    const bool m64 = M <= 64 || blocks128 < 256;
-    if (m64) {
-        ALT<T, 1> a; make_a(a);
-        if (n64 || blocks128 < 128) { BLT<T, 1> b; make_b(b); launch_tile<T, 64, 64>(a, b, ep, M, N, K, split_k, st); }
-        else { BLT<T, 2> b; make_b(b); launch_tile<T, 64, 128>(a, b, ep, M, N, K, split_k, st); }
-    } else {
-        ALT<T, 2> a; make_a(a);
-        if (n64) { BLT<T, 1> b; make_b(b); launch_tile<T, 128, 64>(a, b, ep, M, N, K, split_k, st); }
-        else { BLT<T, 2> b; make_b(b); launch_tile<T, 128, 128>(a, b, ep, M, N, K, split_k, st); }
+    switch (c) {
+        case 2: VTX_V1(128, 128, 2, 2) break;
+        case 3: VTX_V1(128, 64, 2, 1) break;
+        case 4: VTX_V1(64, 128, 1, 2) break;
+        default: VTX_V1(64, 64, 1, 1) break;
     }
+#undef VTX_V1
+#undef VTX_V2
 }
 
 }  // namespace vtxg

@@ -76,6 +76,19 @@ def gemm_nt(a, b, bias=None, residual=None, act=ACT_NONE, want_preact=False, alp
     return (out, pre) if want_preact else out
 
 
+_splitk_ws = {}
+SPLITK_WS_FLOATS = 32 * 1024 * 1024      # 128 MB of fp32 partial sums per device
+
+
+def splitk_workspace(device):
+    ws = _splitk_ws.get(device)
+    if ws is None:
+        n = SPLITK_WS_FLOATS if device.type == "cuda" else 4 * 1024 * 1024
+        ws = torch.empty(n, dtype=torch.float32, device=device)
+        _splitk_ws[device] = ws
+    return ws
+
+
 def gemm_tn_acc(a, b, out, alpha=1.0, split_k=0):
     """out[M,N] (fp32) += alpha * a[K,M]^T @ b[K,N]."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -83,9 +96,10 @@ def gemm_tn_acc(a, b, out, alpha=1.0, split_k=0):
     N = b.shape[1]
     assert b.shape[0] == K and b.dtype == a.dtype and out.dtype == torch.float32
     assert out.dim() == 2 and out.stride(1) == 1 and out.shape == (M, N)
+    ws = splitk_workspace(a.device)
     call("vtx_gemm_tn_acc", c_int(dtype_code(a.dtype)), c_int(M), c_int(N), c_int(K), ptr(a),
          c_long(a.stride(0)), ptr(b), c_long(b.stride(0)), ptr(out), c_long(out.stride(0)),
-         c_float(alpha), c_int(split_k), stream_ptr(a))
+         c_float(alpha), c_int(split_k), ptr(ws), c_long(ws.numel()), stream_ptr(a))
     return out
 
 
@@ -124,8 +138,10 @@ def conv2d_wgrad(x, dy, dw, stride, pad, split_k=0):
     KO, R, S, C2 = dw.shape
     assert C2 == C and dy.shape[-1] == KO and dw.dtype == torch.float32
     _chk(x, "x"); _chk(dy, "dy", x.dtype); _chk(dw, "dw")
+    ws = splitk_workspace(x.device)
     call("vtx_conv2d_wgrad", c_int(dtype_code(x.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
-         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(x), ptr(dy), ptr(dw), c_int(split_k), stream_ptr(x))
+         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(x), ptr(dy), ptr(dw), c_int(split_k), ptr(ws),
+         c_long(ws.numel()), stream_ptr(x))
     return dw
 
 
