@@ -54,8 +54,9 @@ int vtx_layernorm_residual_fwd(int dtype, const void* x, const void* y, const fl
                                int H, float eps, float p_drop, uint64_t seed, void* stream);
 int vtx_layernorm_residual_bwd(int dtype, const void* x, const void* y, const float* gamma,
                                const float* mean, const float* rstd, const void* dout, void* dz,
-                               void* dy, float* dgamma, float* dbeta, int rows, int H,
+                               void* dy, float* dgamma, float* dbeta, float* workspace, int rows, int H,
                                float p_drop, uint64_t seed, void* stream);
+long vtx_layernorm_workspace_floats(int H);   /* scratch for the per-block dgamma/dbeta partials */
 
 /* ---- GEMMs (MFMA; csrc/gemm_kernel.h) --------------------------------------------------
  * vtx_gemm_nt : C[M][N] = dropout(act(alpha * A[M][K] . B[N][K]^T + bias[N])) + residual
@@ -105,6 +106,7 @@ int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamm
                float* save_mean, float* save_rstd, float* workspace, int P, int C, float eps,
                float momentum, int relu, void* stream);
 int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, const float* gamma,
+               const float* relu_beta /* non-NULL: ReLU mask recomputed as xhat*gamma+beta > 0, ymask must be NULL */,
                const float* save_mean, const float* save_rstd, void* dx, void* dz_out, float* dgamma,
                float* dbeta, float* workspace, int P, int C, void* stream);
 

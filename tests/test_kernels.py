@@ -175,6 +175,11 @@ def test_batchnorm(backend, dtype, N, H, W, C, relu, res):
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     dx, dz = ops.bn_bwd(x.to(dev), dy.to(dev), y if relu else None, gamma.to(dev), mean, rstd, dg, db,
                         want_dz=True)
+    if relu and not res:   # same result with the mask recomputed from x instead of read from y
+        dg2, db2 = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx2 = ops.bn_bwd(x.to(dev), dy.to(dev), None, gamma.to(dev), mean, rstd, dg2, db2, relu_beta=beta.to(dev))
+        assert rel_err(dx2.float().cpu(), dx.float().cpu()) < (1e-6 if dtype == torch.float32 else 2e-2)
+        assert rel_err(dg2.cpu(), dg.cpu()) < (1e-6 if dtype == torch.float32 else 2e-2)
     assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < (2e-4 if dtype == torch.float32 else 2e-2)
     assert rel_err(dg.cpu(), gr.grad) < (2e-4 if dtype == torch.float32 else 2e-2)
     assert rel_err(db.cpu(), br.grad) < (2e-4 if dtype == torch.float32 else 2e-2)

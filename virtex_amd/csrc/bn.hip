@@ -19,16 +19,19 @@ namespace {
 template <class T, bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ ymask,
-    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ sums,
-    int P, int C, int TX, int rows_per_block) {
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ sums, int P, int C, int TX, int rows_per_block) {
     constexpr int VEC = Elem<T>::VEC;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
     const int c0 = (blockIdx.y * TX + tx) * VEC;
     const int p0 = blockIdx.x * rows_per_block;
     const int p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
-    float a[VEC], b[VEC], mu[VEC], rs[VEC];
+    float a[VEC], b[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC];
+    const bool remask = BWD && beta != nullptr;   // ReLU mask recomputed from x: y = xhat*gamma + beta > 0
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
+        ga[j] = remask ? gamma[c0 + j] : 0.f;
+        be[j] = remask ? beta[c0 + j] : 0.f;
         a[j] = b[j] = 0.f;
         // forward: shift by the channel's first sample (shifted-data variance: no catastrophic
         // cancellation in E[x^2]-E[x]^2 when |mean| >> std); backward: the saved statistics
@@ -46,7 +49,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
                 for (int j = 0; j < VEC; ++j) g.v[j] = m.v[j] > 0.f ? g.v[j] : 0.f;
             }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { a[j] += g.v[j]; b[j] += g.v[j] * (xv.v[j] - mu[j]) * rs[j]; }
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (xv.v[j] - mu[j]) * rs[j];
+                if (remask) g.v[j] = xh * ga[j] + be[j] > 0.f ? g.v[j] : 0.f;
+                a[j] += g.v[j]; b[j] += g.v[j] * xh;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { const float d = xv.v[j] - mu[j]; a[j] += d; b[j] += d * d; }
@@ -163,7 +170,8 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ ymask,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
-    T* __restrict__ dx, T* __restrict__ dz_out, long nvec, int C) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ dx, T* __restrict__ dz_out,
+    long nvec, int C) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
@@ -173,6 +181,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             Vec16<T> m; m.load(ymask + i * VEC);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) g.v[j] = m.v[j] > 0.f ? g.v[j] : 0.f;
+        }
+        if (beta) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (xv.v[j] - mean[c0 + j]) * rstd[c0 + j];
+                g.v[j] = xh * gamma[c0 + j] + beta[c0 + j] > 0.f ? g.v[j] : 0.f;
+            }
         }
         if (dz_out) g.store(dz_out + i * VEC);
         Vec16<T> o;
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
-constexpr int VTX_BN_MAX_PARTS = 512;
+constexpr int VTX_BN_MAX_PARTS = 256;
 struct ReducePlan { int TX, gy, gx, rows; };
 static ReducePlan plan_reduce(int P, int C, int vec) {
     ReducePlan r;
@@ -226,10 +241,10 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     const long nvec = (long)P * C / vec;
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     else
         hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
@@ -248,10 +263,11 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
 
 // workspace: same buffer / layout as vtx_bn_fwd (vtx_bn_workspace_floats(C) floats)
 extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, const float* gamma,
-                          const float* save_mean, const float* save_rstd, void* dx, void* dz_out,
+                          const float* relu_beta, const float* save_mean, const float* save_rstd, void* dx, void* dz_out,
                           float* dgamma, float* dbeta, float* workspace, int P, int C, void* stream) {
     VTX_CHECK(x && dy && gamma && save_mean && save_rstd && dx && dgamma && dbeta && workspace, VTX_ERR_ARG,
               "bn_bwd: null pointer");
+    VTX_CHECK(!(ymask && relu_beta), VTX_ERR_ARG, "bn_bwd: pass either ymask or relu_beta, not both");
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_bwd: bad dtype %d", dtype);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_bwd: C=%d must be vec*2^k, P=%d > 0", C, P);
@@ -261,19 +277,19 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     const long nvec = (long)P * C / vec;
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, sums, P, C, rp.TX, rp.rows);
+                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
     else
         hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
-                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, sums, P, C, rp.TX, rp.rows);
+                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
                        dgamma, dbeta, P, C, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, coef, (bf16_t*)dx,
+                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, coef, gamma, relu_beta, (bf16_t*)dx,
                            (bf16_t*)dz_out, nvec, C);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
-                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, coef, (float*)dx,
+                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, coef, gamma, relu_beta, (float*)dx,
                            (float*)dz_out, nvec, C);
     VTX_LAUNCH_CHECK();
     return VTX_OK;

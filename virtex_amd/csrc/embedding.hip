@@ -199,7 +199,7 @@ extern "C" int vtx_embedding_bwd(int dtype, const long long* tokens, const float
     if (B == 0) return VTX_OK;
     hipStream_t st = (hipStream_t)stream;
     int gy = vtx_cdiv(B, 4);
-    if (gy > 32) gy = 32;
+    if (gy > 8) gy = 8;      // T*gy blocks add into dgamma/dbeta: keep the atomic fan-in small
     dim3 grid(T, gy), block(256);
     Dropout d = make_dropout(p_drop, seed);
     if (dtype == VTX_BF16)

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
     const T* __restrict__ dout, T* __restrict__ dz, T* __restrict__ dy,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int H, Dropout drop) {
+    float* __restrict__ partials, int rows, int H, Dropout drop) {
     constexpr int VEC = Elem<T>::VEC;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float ag[NV][VEC], ab[NV][VEC];
@@ -141,16 +141,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
             for (int j = 0; j < VEC; ++j) red[wv][lane * VEC + j] = pass ? ab[i][j] : ag[i][j];
             __syncthreads();
             if (wv == 0 && col < H) {
+                // per-block partial (no atomics: a thousand blocks adding into the same 2*H addresses
+                // serialise in L2); summed by ln_bwd_finalize_kernel
+                float* dst = partials + ((size_t)blockIdx.x * 2 + pass) * H;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    const float t = red[0][lane * VEC + j] + red[1][lane * VEC + j] +
-                                    red[2][lane * VEC + j] + red[3][lane * VEC + j];
-                    atomicAdd((pass ? dbeta : dgamma) + col + j, t);
-                }
+                for (int j = 0; j < VEC; ++j)
+                    dst[col + j] = red[0][lane * VEC + j] + red[1][lane * VEC + j] + red[2][lane * VEC + j] +
+                                   red[3][lane * VEC + j];
             }
         }
     }
 }
+
+// dgamma[c] += sum_b partials[b][0][c] ; dbeta[c] += sum_b partials[b][1][c]   (32 columns x 8 groups)
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partials, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int H, int nparts) {
+    __shared__ float red[2][8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    float a = 0.f, b = 0.f;
+    if (c < H)
+        for (int p = grp; p < nparts; p += 8) { a += partials[((size_t)p * 2) * H + c]; b += partials[((size_t)p * 2 + 1) * H + c]; }
+    red[0][grp][threadIdx.x & 31] = a; red[1][grp][threadIdx.x & 31] = b;
+    __syncthreads();
+    if (grp == 0 && c < H) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+        dgamma[c] += t0; dbeta[c] += t1;
+    }
+}
+
+constexpr int VTX_LN_MAX_PARTS = 512;
 
 template <class T>
 int ln_fwd_t(const void* x, const void* y, const float* gamma, const float* beta, void* out,
@@ -172,22 +193,22 @@ int ln_fwd_t(const void* x, const void* y, const float* gamma, const float* beta
 
 template <class T>
 int ln_bwd_t(const void* x, const void* y, const float* gamma, const float* mean, const float* rstd,
-             const void* dout, void* dz, void* dy, float* dgamma, float* dbeta, int rows, int H,
-             Dropout d, hipStream_t st) {
+             const void* dout, void* dz, void* dy, float* dgamma, float* dbeta, float* partials, int rows,
+             int H, Dropout d, hipStream_t st) {
     constexpr int VEC = Elem<T>::VEC;
     const int nv = vtx_cdiv(H, 64 * VEC);
     int nblk = vtx_cdiv(rows, 4);
-    if (nblk > 1024) nblk = 1024;
+    if (nblk > VTX_LN_MAX_PARTS) nblk = VTX_LN_MAX_PARTS;
     dim3 grid(nblk), block(256);
 #define VTX_LN_BWD(NV)                                                                          \
     hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)y,    \
-                       gamma, mean, rstd, (const T*)dout, (T*)dz, (T*)dy, dgamma, dbeta, rows,  \
-                       H, d)
+                       gamma, mean, rstd, (const T*)dout, (T*)dz, (T*)dy, partials, rows, H, d)
     if (nv <= 1) VTX_LN_BWD(1);
     else if (nv <= 2) VTX_LN_BWD(2);
     else if (nv <= 4) VTX_LN_BWD(4);
     else VTX_LN_BWD(8);
 #undef VTX_LN_BWD
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(vtx_cdiv(H, 32)), dim3(256), 0, st, partials, dgamma, dbeta, H, nblk);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -212,20 +233,22 @@ extern "C" int vtx_layernorm_residual_fwd(int dtype, const void* x, const void* 
     VTX_CHECK(false, VTX_ERR_DTYPE, "layernorm_fwd: bad dtype %d", dtype);
 }
 
+extern "C" long vtx_layernorm_workspace_floats(int H) { return (long)VTX_LN_MAX_PARTS * 2 * H; }
+
 extern "C" int vtx_layernorm_residual_bwd(int dtype, const void* x, const void* y,
                                           const float* gamma, const float* mean, const float* rstd,
                                           const void* dout, void* dz, void* dy, float* dgamma,
-                                          float* dbeta, int rows, int H, float p_drop,
+                                          float* dbeta, float* workspace, int rows, int H, float p_drop,
                                           uint64_t seed, void* stream) {
-    VTX_CHECK(x && gamma && mean && rstd && dout && dz && dgamma && dbeta, VTX_ERR_ARG,
+    VTX_CHECK(x && gamma && mean && rstd && dout && dz && dgamma && dbeta && workspace, VTX_ERR_ARG,
               "layernorm_bwd: null pointer");
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(H > 0 && H % vec == 0 && H <= 64 * vec * 8, VTX_ERR_SHAPE, "layernorm_bwd: bad H=%d", H);
     if (rows == 0) return VTX_OK;
     Dropout d = make_dropout(y ? p_drop : 0.f, seed);
     if (dtype == VTX_BF16)
-        return ln_bwd_t<bf16_t>(x, y, gamma, mean, rstd, dout, dz, dy, dgamma, dbeta, rows, H, d, (hipStream_t)stream);
+        return ln_bwd_t<bf16_t>(x, y, gamma, mean, rstd, dout, dz, dy, dgamma, dbeta, workspace, rows, H, d, (hipStream_t)stream);
     if (dtype == VTX_F32)
-        return ln_bwd_t<float>(x, y, gamma, mean, rstd, dout, dz, dy, dgamma, dbeta, rows, H, d, (hipStream_t)stream);
+        return ln_bwd_t<float>(x, y, gamma, mean, rstd, dout, dz, dy, dgamma, dbeta, workspace, rows, H, d, (hipStream_t)stream);
     VTX_CHECK(false, VTX_ERR_DTYPE, "layernorm_bwd: bad dtype %d", dtype);
 }

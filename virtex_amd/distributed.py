@@ -122,6 +122,8 @@ class GradientBuckets:
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self.enabled = self.world > 1
         if self.enabled:
+            # fires once per parameter per backward, also when the backward function accumulated into
+            # p.grad itself and returned None (virtex_amd/gradsink.py)
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
         self.begin()

@@ -20,7 +20,7 @@ import itertools
 import torch
 from torch import nn
 
-from .. import ops
+from .. import gradsink, ops
 
 _seed_counter = itertools.count(1)
 
@@ -220,6 +220,7 @@ class _DecoderFn(torch.autograd.Function):
                                      seeds=seeds, cw=cw, P=P))
             x = x3
         ctx.head, ctx.p, ctx.dims = head, p, (B, T, S, H, A)
+        ctx.layer_params = [list(params[2 + 18 * li: 2 + 18 * (li + 1)]) for li in range(head.num_layers)]
         ctx.saved_layers, ctx.mem, ctx.mem_in, ctx.Wv_t, ctx.lengths = saved_layers, mem, mem_in, Wv_t, lengths
         ctx.vshape = visual_features.shape
         ctx.needs_vis_grad = visual_features.requires_grad
@@ -240,56 +241,65 @@ class _DecoderFn(torch.autograd.Function):
         def zeros(*shape):
             return torch.zeros(*shape, dtype=torch.float32, device=dev)
 
-        def linear_grads(inp, dout, w32_shape):
-            """dW (fp32, [out,in]) and dbias for y = inp @ W^T + b."""
-            dW = zeros(*w32_shape)
+        def sink(p):
+            """(buffer to accumulate into, value to return to autograd)"""
+            t = gradsink.target(p)
+            if t is not None:
+                return t, None
+            z = torch.zeros_like(p, dtype=torch.float32)
+            return z, z
+
+        def linear_grads(inp, dout, wp, bp):
+            """dW ([out,in]) and dbias of y = inp @ W^T + b, accumulated into sinks."""
+            dW, rW = sink(wp)
             ops.gemm_tn_acc(dout, inp, dW)
-            db = zeros(w32_shape[0])
+            db, rb = sink(bp)
             ops.colsum_acc(dout, db)
-            return dW, db
+            return rW, rb
 
         for li in reversed(range(head.num_layers)):
             L = ctx.saved_layers[li]
             (Win, bin_, Wo, bo, g1, b1, Win2, bin2, Wo2, bo2, g2, b2, W1, bf1, W2, bf2, g3, b3) = L["P"]
+            PP = ctx.layer_params[li]     # the nn.Parameters, same order
             cw, seeds = L["cw"], L["seeds"]
             # ---- FFN block: x3 = LN3(x2 + drop(y3))
-            dg3, db3 = zeros(H), zeros(H)
+            (dg3, rdg3), (db3, rdb3) = sink(PP[16]), sink(PP[17])
             dz3, dy3 = ops.layernorm_residual_bwd(L["x2"], L["y3"], g3, L["m3"], L["r3"], dx, dg3, db3, p, seeds[5])
-            dW2, dbf2 = linear_grads(L["a"], dy3, W2.shape)
+            dW2, dbf2 = linear_grads(L["a"], dy3, PP[14], PP[15])
             da = ops.gemm_nt(dy3, cw["W2"][1])                                  # (B*T, F)
             dh = ops.gelu_bwd(L["hpre"], da, p, seeds[4])
-            dW1, dbf1 = linear_grads(L["x2"], dh, W1.shape)
+            dW1, dbf1 = linear_grads(L["x2"], dh, PP[12], PP[13])
             dx2 = ops.gemm_nt(dh, cw["W1"][1], residual=dz3)                    # + residual path
             # ---- cross-attention block: x2 = LN2(x1 + drop(y2))
-            dg2, db2 = zeros(H), zeros(H)
+            (dg2, rdg2), (db2, rdb2) = sink(PP[10]), sink(PP[11])
             dz2, dy2 = ops.layernorm_residual_bwd(L["x1"], L["y2"], g2, L["m2"], L["r2"], dx2, dg2, db2, p, seeds[3])
-            dWo2, dbo2 = linear_grads(L["o2"], dy2, Wo2.shape)
+            dWo2, dbo2 = linear_grads(L["o2"], dy2, PP[8], PP[9])
             do2 = ops.gemm_nt(dy2, cw["Wo2"][1])
             dq2 = torch.empty_like(L["q2"])
             dkv2 = torch.empty_like(L["kv2"])
             ops.attention_bwd(L["q2"], L["kv2"][:, :H], L["kv2"][:, H:], do2, dq2, dkv2[:, :H], dkv2[:, H:],
                               B, A, T, S, False, None, p, seeds[2])
-            dWin2 = zeros(*Win2.shape)
+            dWin2, rWin2 = sink(PP[6])
             ops.gemm_tn_acc(dq2, L["x1"], dWin2[:H])
             ops.gemm_tn_acc(dkv2, ctx.mem, dWin2[H:])
-            dbin2 = zeros(3 * H)
+            dbin2, rbin2 = sink(PP[7])
             ops.colsum_acc(dq2, dbin2[:H])
             ops.colsum_acc(dkv2, dbin2[H:])
             dx1 = ops.gemm_nt(dq2, _wt_cols(cw["Win2"][1], 0, H), residual=dz2)
             dmem = ops.gemm_nt(dkv2, _wt_cols(cw["Win2"][1], H, 3 * H), residual=dmem)
             # ---- self-attention block: x1 = LN1(x + drop(y1))
-            dg1, db1 = zeros(H), zeros(H)
+            (dg1, rdg1), (db1, rdb1) = sink(PP[4]), sink(PP[5])
             dz1, dy1 = ops.layernorm_residual_bwd(L["x"], L["y1"], g1, L["m1"], L["r1"], dx1, dg1, db1, p, seeds[1])
-            dWo, dbo = linear_grads(L["o1"], dy1, Wo.shape)
+            dWo, dbo = linear_grads(L["o1"], dy1, PP[2], PP[3])
             do1 = ops.gemm_nt(dy1, cw["Wo"][1])
             qkv = L["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], do1, dqkv[:, :H], dqkv[:, H:2 * H],
                               dqkv[:, 2 * H:], B, A, T, T, head.mask_future_positions, ctx.lengths, p, seeds[0])
-            dWin, dbin = linear_grads(L["x"], dqkv, Win.shape)
+            dWin, dbin = linear_grads(L["x"], dqkv, PP[0], PP[1])
             dx = ops.gemm_nt(dqkv, cw["Win"][1], residual=dz1)
-            pgrads = [dWin, dbin, dWo, dbo, dg1, db1, dWin2, dbin2, dWo2, dbo2, dg2, db2, dW1, dbf1, dW2, dbf2,
-                      dg3, db3] + pgrads
+            pgrads = [dWin, dbin, dWo, dbo, rdg1, rdb1, rWin2, rbin2, dWo2, dbo2, rdg2, rdb2, dW1, dbf1, dW2, dbf2,
+                      rdg3, rdb3] + pgrads
         # ---- visual projection
         Cv = ctx.mem_in.shape[1]
         dWv = zeros(H, Cv)

@@ -18,7 +18,7 @@ from typing import List
 import torch
 from torch import nn
 
-from .. import ops
+from .. import gradsink, ops
 
 RESNET_BLOCKS = {"resnet50": ((3, 4, 6, 3), 64), "resnet101": ((3, 4, 23, 3), 64),
                  "wide_resnet50_2": ((3, 4, 6, 3), 128)}
@@ -179,12 +179,16 @@ def _conv_dgrad(u: _Unit, dy, wt, x_shape, residual=None):
 
 
 def _conv_wgrad(u: _Unit, x, dy):
-    """Returns the gradient in the master weight's logical (KO,C,R,S) shape."""
-    dw = torch.zeros(u.cout, u.k, u.k, u.cin_pad, dtype=torch.float32, device=x.device)
+    """Accumulates into the parameter's own gradient buffer when it has a suitable one (returns None),
+    otherwise returns the gradient in the master weight's logical (KO,C,R,S) shape."""
+    sink = gradsink.target(u.conv.weight, (u.cout, u.k, u.k, u.cin_pad)) if u.cin_pad == u.cin else None
+    dw = sink if sink is not None else torch.zeros(u.cout, u.k, u.k, u.cin_pad, dtype=torch.float32, device=x.device)
     if u.is_gemm:
         ops.gemm_tn_acc(dy.view(-1, u.cout), x.view(-1, u.cin_pad), dw.view(u.cout, u.cin_pad))
     else:
         ops.conv2d_wgrad(x, dy, dw, u.stride, u.pad)
+    if sink is not None:
+        return None
     if u.cin_pad != u.cin:
         dw = dw[..., :u.cin].contiguous()
     return dw.permute(0, 3, 1, 2)
@@ -248,12 +252,16 @@ class _ResNetFn(torch.autograd.Function):
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
         grads = {}
 
-        def bn_back(u: _Unit, s: _Saved, dy, masked, want_dz=False):
-            dg = torch.zeros(u.cout, dtype=torch.float32, device=dev)
-            db = torch.zeros(u.cout, dtype=torch.float32, device=dev)
-            out = ops.bn_bwd(s.x, dy, s.y if masked else None, u.bn.weight.detach(), s.mean, s.rstd, dg, db,
-                             want_dz=want_dz)
-            grads[u] = [None, dg, db]
+        def bn_back(u: _Unit, s: _Saved, dy, masked, want_dz=False, residual=False):
+            sg, sb = gradsink.target(u.bn.weight), gradsink.target(u.bn.bias)
+            dg = sg if sg is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+            db = sb if sb is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+            # BN directly followed by ReLU: the mask is recomputed from x (one tensor less to read);
+            # BN + residual + ReLU: the mask is the saved block output
+            out = ops.bn_bwd(s.x, dy, s.y if (masked and residual) else None, u.bn.weight.detach(), s.mean, s.rstd,
+                             dg, db, want_dz=want_dz,
+                             relu_beta=u.bn.bias.detach() if (masked and not residual) else None)
+            grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
             return out
 
         # index of each unit's saved record, in forward execution order
@@ -264,7 +272,7 @@ class _ResNetFn(torch.autograd.Function):
 
         for (u1, u2, u3, ud) in reversed(blocks):
             s1, s2, s3 = rec[u1], rec[u2], rec[u3]
-            dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True)      # dz: gradient of the identity path
+            dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True, residual=True)      # dz: gradient of the identity path
             grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
             dy2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape)
             dx2 = bn_back(u2, s2, dy2, True)

@@ -34,6 +34,9 @@ def layernorm_residual_fwd(x, y, gamma, beta, eps, p_drop=0.0, seed=0):
     return out, mean, rstd
 
 
+_ln_ws = {}
+
+
 def layernorm_residual_bwd(x, y, gamma, mean, rstd, dout, dgamma, dbeta, p_drop=0.0, seed=0):
     """Returns (dz, dy); dgamma/dbeta (fp32) are accumulated in place."""
     H = x.shape[-1]
@@ -41,8 +44,12 @@ def layernorm_residual_bwd(x, y, gamma, mean, rstd, dout, dgamma, dbeta, p_drop=
     _chk(x, "x"); _chk(y, "y", x.dtype); _chk(dout, "dout", x.dtype)
     dz = torch.empty_like(x)
     dy = torch.empty_like(x) if (y is not None and p_drop > 0.0) else None
+    ws = _ln_ws.get(x.device)
+    if ws is None or ws.numel() < 1024 * H:
+        ws = torch.empty(1024 * max(H, 2048), dtype=torch.float32, device=x.device)
+        _ln_ws[x.device] = ws
     call("vtx_layernorm_residual_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(y), ptr(gamma),
-         ptr(mean), ptr(rstd), ptr(dout), ptr(dz), ptr(dy), ptr(dgamma), ptr(dbeta), c_int(rows),
+         ptr(mean), ptr(rstd), ptr(dout), ptr(dz), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(rows),
          c_int(H), c_float(p_drop), c_u64(seed), stream_ptr(x))
     return dz, (dy if dy is not None else dz)
 
@@ -178,14 +185,16 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.
     return y, mean, rstd
 
 
-def bn_bwd(x, dy, ymask, gamma, mean, rstd, dgamma, dbeta, want_dz=False):
+def bn_bwd(x, dy, ymask, gamma, mean, rstd, dgamma, dbeta, want_dz=False, relu_beta=None):
+    """ymask: the post-ReLU output (needed when a residual was added before the ReLU); relu_beta: instead,
+    recompute the mask from x (BN directly followed by ReLU) and skip reading the output tensor."""
     C = x.shape[-1]
     P = x.numel() // C
     _chk(x, "x"); _chk(dy, "dy", x.dtype); _chk(ymask, "ymask", x.dtype)
     ws = bn_workspace(x.device, C)
     dx = torch.empty_like(x)
     dz = torch.empty_like(x) if want_dz else None
-    call("vtx_bn_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(dy), ptr(ymask), ptr(gamma), ptr(mean),
+    call("vtx_bn_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(dy), ptr(ymask), ptr(gamma), ptr(relu_beta), ptr(mean),
          ptr(rstd), ptr(dx), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(P), c_int(C), stream_ptr(x))
     return (dx, dz) if want_dz else dx
 
