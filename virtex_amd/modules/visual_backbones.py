@@ -194,6 +194,51 @@ def _conv_wgrad(u: _Unit, x, dy):
     return dw.permute(0, 3, 1, 2)
 
 
+_side_streams = {}
+
+
+class wgrad_stream:
+    """Context manager: run weight-gradient GEMMs (off the critical path of backward: nothing downstream
+    reads them until the optimizer) on a side HIP stream, concurrently with the input-gradient chain.
+    Inputs are fenced with an event; their memory is kept alive for the side stream with record_stream;
+    `join()` makes the main stream wait for everything issued so far."""
+    enabled = True
+
+    def __init__(self, device, *inputs):
+        self.device, self.inputs = device, inputs
+        self.active = wgrad_stream.enabled and device.type == "cuda"
+
+    @staticmethod
+    def side(device):
+        st = _side_streams.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            _side_streams[device] = st
+        return st
+
+    def __enter__(self):
+        if self.active:
+            side = wgrad_stream.side(self.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            side.wait_event(ev)
+            for t in self.inputs:
+                t.record_stream(side)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+    @staticmethod
+    def join(device):
+        if wgrad_stream.enabled and device.type == "cuda" and device in _side_streams:
+            torch.cuda.current_stream(device).wait_stream(_side_streams[device])
+
+
 class _Saved:
     __slots__ = ("a", "x", "y", "mean", "rstd", "wt")
 
@@ -273,17 +318,21 @@ class _ResNetFn(torch.autograd.Function):
         for (u1, u2, u3, ud) in reversed(blocks):
             s1, s2, s3 = rec[u1], rec[u2], rec[u3]
             dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True, residual=True)      # dz: gradient of the identity path
-            grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
+            with wgrad_stream(dev, s3.a, dx3):
+                grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
             dy2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape)
             dx2 = bn_back(u2, s2, dy2, True)
-            grads[u2][0] = _conv_wgrad(u2, s2.a, dx2)
+            with wgrad_stream(dev, s2.a, dx2):
+                grads[u2][0] = _conv_wgrad(u2, s2.a, dx2)
             dy1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape)
             dx1 = bn_back(u1, s1, dy1, True)
-            grads[u1][0] = _conv_wgrad(u1, s1.a, dx1)
+            with wgrad_stream(dev, s1.a, dx1):
+                grads[u1][0] = _conv_wgrad(u1, s1.a, dx1)
             if ud is not None:
                 sd = rec[ud]
                 dxd = bn_back(ud, sd, dz, False)
-                grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
+                with wgrad_stream(dev, sd.a, dxd):
+                    grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
                 dmain = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape)
                 dcur = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape, residual=dmain)
             else:
@@ -291,7 +340,9 @@ class _ResNetFn(torch.autograd.Function):
         s0 = rec[stem]
         dstem = ops.maxpool_bwd(dcur, ctx.argmax, ctx.stem_out_shape)
         dx0 = bn_back(stem, s0, dstem, True)
-        grads[stem][0] = _conv_wgrad(stem, s0.a, dx0)      # no input gradient for the image
+        with wgrad_stream(dev, s0.a, dx0):
+            grads[stem][0] = _conv_wgrad(stem, s0.a, dx0)  # no input gradient for the image
+        wgrad_stream.join(dev)
 
         out = [None, None]
         for u in units:

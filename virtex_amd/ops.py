@@ -88,11 +88,14 @@ SPLITK_WS_FLOATS = 32 * 1024 * 1024      # 128 MB of fp32 partial sums per devic
 
 
 def splitk_workspace(device):
-    ws = _splitk_ws.get(device)
+    """One scratch buffer per (device, stream): weight-gradient GEMMs may run on a side stream
+    concurrently with the main stream's (virtex_amd/modules: `wgrad_stream`)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = _splitk_ws.get(key)
     if ws is None:
         n = SPLITK_WS_FLOATS if device.type == "cuda" else 4 * 1024 * 1024
         ws = torch.empty(n, dtype=torch.float32, device=device)
-        _splitk_ws[device] = ws
+        _splitk_ws[key] = ws
     return ws
 
 
