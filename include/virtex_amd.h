@@ -65,13 +65,17 @@ long vtx_layernorm_workspace_floats(int H);   /* scratch for the per-block dgamm
  *   weight.  A,B,C,residual,preact: dtype; bias fp32; act: 0 none, 1 GELU(erf), 2 ReLU.
  *   preact (optional) receives alpha*A.B^T+bias before the activation (GELU backward).
  *   out_f32 != 0: C/residual/preact are fp32 even when dtype is bf16 (vocabulary logits).
+ *   bn_parts (optional): the epilogue also emits BatchNorm statistics of the output -- per (row strip,
+ *   channel) sums of (value - bn_shift[n]) and squares, [strips][2][N] fp32; *bn_strips receives the
+ *   number of strips (0 if this build/dtype did not produce them: use the stand-alone reduction).
  * vtx_gemm_tn_acc : C[M][N] (fp32) += alpha * A[K][M]^T . B[K][N]   (weight gradients;
  *   replaces the mm inside aten::linear_backward / 1x1 convolution_backward).  split_k <= 0
  *   lets the library choose; slices write partial tiles into `workspace` ([split_k][M][N] fp32, may be
  *   NULL => one slice) which a reduce kernel adds into C; deterministic (no atomics). */
 int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                 void* C, long ldc, const float* bias, const void* residual, long ldr, void* preact,
-                int act, float alpha, float p_drop, uint64_t seed, int out_f32, void* stream);
+                int act, float alpha, float p_drop, uint64_t seed, int out_f32, float* bn_parts,
+                const float* bn_shift, int* bn_strips, void* stream);
 int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                     float* C, long ldc, float alpha, int split_k, float* workspace, long workspace_floats,
                     void* stream);
@@ -83,7 +87,8 @@ int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, con
  * ACCUMULATED.  C and KO must be powers of two >= 16 bytes worth of elements (the 3-channel
  * stem input is zero-padded to 8 channels by vtx_image_to_nhwc).  OH = (H+2p-R)/s+1. */
 int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
-                   const void* x, const void* w, void* y, void* stream);
+                   const void* x, const void* w, void* y, float* bn_parts, const float* bn_shift,
+                   int* bn_strips, void* stream);
 int vtx_conv2d_dgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
                      const void* dy, const void* wt, void* dx, const void* residual /*nullable: dx += */,
                      void* stream);
@@ -95,6 +100,8 @@ int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S
  * Replaces aten::batch_norm/relu_/add_ (+backward) of torchvision's Bottleneck
  * (visual_backbones.py:68-74): y = act(gamma*(x-mean)*rstd + beta (+ residual)), running
  * stats updated with `momentum` and the unbiased variance, num_batches_tracked += 1.
+ * pre_partials/pre_nparts/pre_shift: statistics already produced by the convolution epilogue (see
+ * vtx_gemm_nt bn_parts); NULL/0/NULL = reduce here.
  * workspace: vtx_bn_workspace_floats(C) fp32 scratch (per-strip partial sums; no zeroing needed;
  * may be shared by all calls issued on one stream).
  * bwd: dz = dy * (ymask > 0) (ymask = the post-ReLU tensor, NULL if no ReLU follows);
@@ -104,7 +111,8 @@ long vtx_bn_workspace_floats(int C);
 int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamma, const float* beta,
                float* running_mean, float* running_var, long long* num_batches_tracked, void* y,
                float* save_mean, float* save_rstd, float* workspace, int P, int C, float eps,
-               float momentum, int relu, void* stream);
+               float momentum, int relu, const float* pre_partials, int pre_nparts, const float* pre_shift,
+               void* stream);
 int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, const float* gamma,
                const float* relu_beta /* non-NULL: ReLU mask recomputed as xhat*gamma+beta > 0, ymask must be NULL */,
                const float* save_mean, const float* save_rstd, void* dx, void* dz_out, float* dgamma,

@@ -379,3 +379,33 @@ def test_contraction_tile_variants_bf16(backend, cand):
             assert rel_err(dw.cpu(), wr.grad.permute(0, 2, 3, 1)) < 2e-2
     finally:
         _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(2, 9, 9, 16, 32, 3, 1, 1), (3, 8, 8, 64, 256, 1, 1, 0), (2, 10, 10, 16, 64, 3, 2, 1)])
+def test_batchnorm_statistics_fused_in_conv_epilogue(backend, case):
+    """bf16: the convolution epilogue emits per-strip sums of (y - shift), (y - shift)^2; BN forward fed
+    with them must agree with BN forward that reduces the stored tensor itself."""
+    dev = select(backend)
+    N, H, W, C, KO, k, stride, pad = case
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, H, W, C, generator=g).to(dt).to(dev)
+    w = (torch.randn(KO, k, k, C, generator=g) / (k * k * C) ** 0.5).to(dt).to(dev)
+    gamma = (0.5 + torch.rand(KO, generator=g)).to(dev); beta = (0.1 * torch.randn(KO, generator=g)).to(dev)
+    shift = (0.3 * torch.randn(KO, generator=g)).to(dev)        # e.g. the running mean
+    if k == 1 and stride == 1:
+        y, st = ops.gemm_nt(x.view(-1, C), w.view(KO, C), bn_shift=shift)
+        y = y.view(N, H, W, KO)
+    else:
+        y, st = ops.conv2d_fwd(x, w, stride, pad, bn_shift=shift)
+    assert st is not None and st.strips > 0
+    rm1, rv1 = shift.clone(), torch.ones(KO, device=dev)
+    out1, mean1, rstd1 = ops.bn_fwd(y, gamma, beta, rm1, rv1, None, stats=st)
+    rm2, rv2 = shift.clone(), torch.ones(KO, device=dev)
+    out2, mean2, rstd2 = ops.bn_fwd(y, gamma, beta, rm2, rv2, None)
+    # fused statistics see the fp32 accumulators, the stand-alone pass the bf16-rounded tensor
+    assert torch.allclose(mean1.cpu(), mean2.cpu(), atol=5e-3, rtol=1e-2)
+    assert torch.allclose(rstd1.cpu(), rstd2.cpu(), rtol=1e-2)
+    assert rel_err(out1.float().cpu(), out2.float().cpu()) < 2e-2
+    assert torch.allclose(rm1.cpu(), rm2.cpu(), atol=1e-3) and torch.allclose(rv1.cpu(), rv2.cpu(), rtol=1e-2)

@@ -97,8 +97,30 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ sums, int
     }
 }
 
+// Folds many statistics strips into few: block (x = 32-channel group, y = chunk of `per` strips) writes
+// one compact strip.  Used when the convolution epilogue produced thousands of strips (M = 800k rows).
+__global__ void bn_compact_parts_kernel(const float* __restrict__ sums, float* __restrict__ out, int C, int nparts,
+                                        int per) {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    const int p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
+    __shared__ float red[2][8][32];
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int p = p0 + grp; p < p1; p += 8) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
+    red[0][grp][threadIdx.x & 31] = a; red[1][grp][threadIdx.x & 31] = b;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+        out[(size_t)blockIdx.y * 2 * C + c] = t0;
+        out[(size_t)blockIdx.y * 2 * C + C + c] = t1;
+    }
+}
+
 template <class T>
-__global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
+__global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __restrict__ pre_shift,
+                                       const float* __restrict__ sums, const float* __restrict__ gamma,
                                        const float* __restrict__ beta, float* __restrict__ mean,
                                        float* __restrict__ rstd, float* __restrict__ scale,
                                        float* __restrict__ shift, float* __restrict__ running_mean,
@@ -112,7 +134,9 @@ __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __r
     const float ms = t0 / (float)P;                   // mean of (x - x[0][c])
     float var = t1 / (float)P - ms * ms;
     var = var > 0.f ? var : 0.f;
-    const float m = Elem<T>::ld(x + c) + ms;
+    // the sums are of (x - shift): shift = the channel's first sample (stand-alone reduction) or the
+    // caller's per-channel shift (statistics produced by the convolution epilogue)
+    const float m = (pre_shift ? pre_shift[c] : Elem<T>::ld(x + c)) + ms;
     const float r = rsqrtf(var + eps);
     mean[c] = m; rstd[c] = r;
     const float sc = gamma[c] * r;
@@ -230,7 +254,8 @@ extern "C" long vtx_bn_workspace_floats(int C) { return (long)(2 * VTX_BN_MAX_PA
 extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamma,
                           const float* beta, float* running_mean, float* running_var,
                           long long* num_batches_tracked, void* y, float* save_mean, float* save_rstd,
-                          float* workspace, int P, int C, float eps, float momentum, int relu, void* stream) {
+                          float* workspace, int P, int C, float eps, float momentum, int relu,
+                          const float* pre_partials, int pre_nparts, const float* pre_shift, void* stream) {
     VTX_CHECK(x && gamma && beta && y && save_mean && save_rstd && workspace, VTX_ERR_ARG, "bn_fwd: null pointer");
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_fwd: bad dtype %d", dtype);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
@@ -239,17 +264,29 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     float* scale = workspace; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(P, C, vec);
     const long nvec = (long)P * C / vec;
-    if (dtype == VTX_BF16)
+    const bool fused = pre_partials != nullptr && pre_nparts > 0;   // statistics came with the conv epilogue
+    VTX_CHECK(!fused || pre_shift, VTX_ERR_ARG, "bn_fwd: fused statistics need the shift vector they were taken against");
+    if (fused) {
+        const float* parts = pre_partials;
+        int np = pre_nparts;
+        if (np > 512) {             // thousands of strips: fold them 128:1 first (keeps the finalize short)
+            const int per = 128, ny = vtx_cdiv(np, per);
+            hipLaunchKernelGGL(bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, C, np, per);
+            parts = sums; np = ny;
+        }
+        sums = const_cast<float*>(parts); rp.gx = np;
+    }
+    else if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     else
         hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const bf16_t*)x, sums, gamma, beta,
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const float*)x, sums, gamma, beta,
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,

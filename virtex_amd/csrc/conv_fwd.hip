@@ -9,22 +9,32 @@ using namespace vtxg;
 
 template <class T>
 static int conv_fwd_t(const ConvGeo& g, const void* x, const void* w, void* y, const void* residual,
-                      int act, hipStream_t st) {
+                      int act, float* stat_parts, const float* stat_shift, int* stat_strips, hipStream_t st) {
     const int M = g.N * g.OH * g.OW, Kd = g.R * g.S * g.C;
-    EpiStore<T> ep{(T*)y, g.KO, nullptr, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
-    launch_auto<T, ConvFwdA, PlainKC>(
-        [&](auto& a) { a.x = (const T*)x; a.g = g; a.rows = M; a.K = Kd; },
-        [&](auto& b) { b.p = (const T*)w; b.ld = Kd; b.rows = g.KO; b.K = Kd; }, ep, M, g.KO, Kd, 1, st);
+    int strips = 0;
+    auto mk_a = [&](auto& a) { a.x = (const T*)x; a.g = g; a.rows = M; a.K = Kd; };
+    auto mk_b = [&](auto& b) { b.p = (const T*)w; b.ld = Kd; b.rows = g.KO; b.K = Kd; };
+    if (stat_parts && sizeof(T) == 2) {
+        EpiStore<T, true> ep{(T*)y, g.KO, nullptr, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
+        ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
+        strips = launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
+    } else {
+        EpiStore<T> ep{(T*)y, g.KO, nullptr, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
+        launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
+    }
+    if (stat_strips) *stat_strips = strips;
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
 
 extern "C" int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride,
-                              int pad, const void* x, const void* w, void* y, void* stream) {
+                              int pad, const void* x, const void* w, void* y, float* bn_parts,
+                              const float* bn_shift, int* bn_strips, void* stream) {
     VTX_CHECK(x && w && y, VTX_ERR_ARG, "conv2d_fwd: null pointer");
     ConvGeo g;
     int rc = make_geo("conv2d_fwd", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
     if (rc) return rc;
-    if (dtype == VTX_BF16) return conv_fwd_t<bf16_t>(g, x, w, y, nullptr, ACT_NONE, (hipStream_t)stream);
-    return conv_fwd_t<float>(g, x, w, y, nullptr, ACT_NONE, (hipStream_t)stream);
+    if (bn_strips) *bn_strips = 0;
+    if (dtype == VTX_BF16) return conv_fwd_t<bf16_t>(g, x, w, y, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
+    return conv_fwd_t<float>(g, x, w, y, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
 }

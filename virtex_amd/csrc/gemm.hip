@@ -18,11 +18,19 @@ namespace {
 template <class T, class TO>
 int gemm_nt_t(int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C, long ldc,
               const float* bias, const void* residual, long ldr, void* preact, int act, float alpha,
-              Dropout drop, hipStream_t st) {
-    EpiStore<TO> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
-    launch_auto<T, PlainKC, PlainKC>(
-        [&](auto& a) { a.p = (const T*)A; a.ld = lda; a.rows = M; a.K = K; },
-        [&](auto& b) { b.p = (const T*)B; b.ld = ldb; b.rows = N; b.K = K; }, ep, M, N, K, 1, st);
+              Dropout drop, float* stat_parts, const float* stat_shift, int* stat_strips, hipStream_t st) {
+    int strips = 0;
+    auto mk_a = [&](auto& a) { a.p = (const T*)A; a.ld = lda; a.rows = M; a.K = K; };
+    auto mk_b = [&](auto& b) { b.p = (const T*)B; b.ld = ldb; b.rows = N; b.K = K; };
+    if (stat_parts && sizeof(T) == 2 && sizeof(TO) == 2) {
+        EpiStore<TO, true> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
+        ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
+        strips = launch_auto<T, PlainKC, PlainKC>(mk_a, mk_b, ep, M, N, K, 1, st);
+    } else {
+        EpiStore<TO> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
+        launch_auto<T, PlainKC, PlainKC>(mk_a, mk_b, ep, M, N, K, 1, st);
+    }
+    if (stat_strips) *stat_strips = strips;
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -100,7 +108,7 @@ void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc,
 extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
                            long ldb, void* C, long ldc, const float* bias, const void* residual,
                            long ldr, void* preact, int act, float alpha, float p_drop, uint64_t seed,
-                           int out_f32, void* stream) {
+                           int out_f32, float* bn_parts, const float* bn_shift, int* bn_strips, void* stream) {
     VTX_CHECK(A && B && C, VTX_ERR_ARG, "gemm_nt: null pointer");
     VTX_CHECK(M >= 0 && N > 0 && K > 0, VTX_ERR_ARG, "gemm_nt: bad shape %dx%dx%d", M, N, K);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
@@ -110,13 +118,14 @@ extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long l
               VTX_ERR_SHAPE, "gemm_nt: K/lda/ldb must be multiples of %d, N/ldc/ldr of 4 (M=%d N=%d K=%d)",
               vec, M, N, K);
     VTX_CHECK(aligned16(A) && aligned16(B) && aligned16(C), VTX_ERR_SHAPE, "gemm_nt: operands must be 16-byte aligned");
+    if (bn_strips) *bn_strips = 0;
     if (M == 0) return VTX_OK;
     Dropout d = make_dropout(p_drop, seed);
     if (dtype == VTX_BF16 && out_f32)
-        return gemm_nt_t<bf16_t, float>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
+        return gemm_nt_t<bf16_t, float>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
     if (dtype == VTX_BF16)
-        return gemm_nt_t<bf16_t, bf16_t>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
-    return gemm_nt_t<float, float>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, (hipStream_t)stream);
+        return gemm_nt_t<bf16_t, bf16_t>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
+    return gemm_nt_t<float, float>(M, N, K, A, lda, B, ldb, C, ldc, bias, residual, ldr, preact, act, alpha, d, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
 }
 
 extern "C" int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, const void* B,

@@ -213,12 +213,18 @@ template <> __device__ __forceinline__ uint4 add16<float>(uint4 a, uint4 b) {
 }
 
 // out = dropout(act(acc*alpha + bias)) + residual ; optional copy of the pre-activation
-template <class T> struct EpiStore {
+template <class T, bool WITH_STATS = false> struct EpiStore {
     static constexpr bool STAGED = true;   // generation-2 kernel: 16-byte stores via a wave-private LDS strip
+    static constexpr bool STATS = WITH_STATS;   // compile-time: the statistics code costs ~48 VGPRs
     typedef T Out;
     T* out; long ldc; const float* bias; const T* residual; long ldr; T* preact; int act;
     float alpha; Dropout drop; int M, N;
     long split_stride = 0;   // split-K: slice blockIdx.y writes its partial result at out + blockIdx.y*split_stride
+    // Fused BatchNorm statistics (generation-2 kernel only): per (row-strip, channel) partial sums of
+    // (value - stat_shift[n]) and its square are written to stat_parts[strip][2][N]; the strips are the
+    // wave rows of the grid (strip = tile_m * WM + wm), summed by the BN finalize kernel.
+    float* stat_parts = nullptr;
+    const float* stat_shift = nullptr;
     // per-lane part (4 consecutive n of one m): everything except the residual add and the store
     __device__ __forceinline__ f32x4_t transform(int m, int n, f32x4_t v) const {
         if (m >= M || n >= N) return v;
@@ -290,8 +296,11 @@ template <class T> struct EpiStore {
 // out(fp32) += alpha * acc     (split-K partial sums and "+=" gradient accumulation)
 struct EpiAtomic {
     static constexpr bool STAGED = false;
+    static constexpr bool STATS = false;
     typedef float Out;
     float* out; long ldc; float alpha; int M, N;
+    float* stat_parts = nullptr;
+    const float* stat_shift = nullptr;
     __device__ __forceinline__ f32x4_t transform(int, int, f32x4_t v) const { return v; }
     __device__ __forceinline__ void store_wide(int, int, uint4) const {}
     __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
@@ -637,6 +646,19 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
         constexpr int EPV = 16 / (int)sizeof(TO);                 // elements per chunk
         __syncthreads();                                          // every wave is done with the stages
         char* strip = reinterpret_cast<char*>(lds) + wave * (16 * ROWB);
+        constexpr bool stats = EP::STATS;
+        f32x4_t ssum[stats ? NT : 1], ssq[stats ? NT : 1], shift[stats ? NT : 1];
+        if constexpr (stats) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                ssum[j] = ssq[j] = shift[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const int n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4);
+                if (ep.stat_shift && n < ep.N) {
+                    const float4 sh = *reinterpret_cast<const float4*>(ep.stat_shift + n);
+                    shift[j] = f32x4_t{sh.x, sh.y, sh.z, sh.w};
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mrow = m0 + wm * WTM + i * 16;
@@ -644,6 +666,12 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
             for (int j = 0; j < NT; ++j) {
                 const f32x4_t v = ep.transform(mrow + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j]);
                 st4v<TO>(reinterpret_cast<TO*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
+                if constexpr (stats) {
+                    if (mrow + (lane & 15) < ep.M) {
+                        const f32x4_t d = v - shift[j];
+                        ssum[j] += d; ssq[j] += d * d;
+                    }
+                }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -653,6 +681,20 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
                 ep.store_wide(mrow + r, n0 + wn * WTN + ch * EPV, w);
             }
             __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (stats) {   // reduce over the 16 lanes that share a column quad, one partial row per wave row
+            float* dst = ep.stat_parts + ((size_t)((tile / tiles_n) * WM + wm) * 2) * ep.N;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float a = ssum[j][t], b = ssq[j][t];
+#pragma unroll
+                    for (int msk = 1; msk < 16; msk <<= 1) { a += __shfl_xor(a, msk, 64); b += __shfl_xor(b, msk, 64); }
+                    const int n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4) + t;
+                    if ((lane & 15) == 0 && n < ep.N) { dst[n] = a; dst[ep.N + n] = b; }
+                }
+            }
         }
     }
 }
@@ -675,7 +717,7 @@ inline void launch_v1(const AL& al, const BL& bl, const EP& ep, int M, int N, in
 }
 
 template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
-inline void launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
+inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
     constexpr int BK = 32;
     const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
     const int nkt = vtx_cdiv(K, BK);
@@ -692,6 +734,7 @@ inline void launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, in
     }
     dim3 grid(tiles_m * tiles_n, split_k), block(64 * WM * WN);
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
+    return tiles_m * WM;    // number of statistics strips (rows of waves) this launch produced
 }
 
 // Tile choice.  Score = (tile efficiency) x (wave quantisation of the grid over 256 CUs) x (padding
@@ -722,15 +765,18 @@ inline int pick_tile(int M, int N, int splits, bool allow256) {
     return best;
 }
 
+// Returns the number of BatchNorm-statistics strips written (0 when the kernel generation that ran
+// does not produce them: the caller then falls back to the stand-alone reduction).
 template <class T, template <class, int> class ALT, template <class, int> class BLT, class EP, class FA, class FB>
-inline void launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
+inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
     constexpr bool BF = sizeof(T) == 2;
     const bool v2 = BF && g_vtx_contraction_generation >= 2;
     const int c = pick_tile(M, N, split_k, v2);
 #define VTX_V1(BM_, BN_, SA_, SB_)                                                          \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v1<T, BM_, BN_>(a, b, ep, M, N, K, split_k, st); }
 #define VTX_V2(BM_, BN_, WM_, WN_, SA_, SB_)                                                \
-    { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v2<BM_, BN_, WM_, WN_>(a, b, ep, M, N, K, split_k, st); }
+    { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); strips = launch_v2<BM_, BN_, WM_, WN_>(a, b, ep, M, N, K, split_k, st); }
+    int strips = 0;
     if constexpr (BF) {
         if (v2) {
             switch (c) {
@@ -741,7 +787,7 @@ inline void launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K,
                 case 4: VTX_V2(64, 128, 2, 2, 1, 2) break;
                 default: VTX_V2(64, 64, 2, 2, 1, 1) break;
             }
-            return;
+            return EP::STATS ? strips : 0;
         }
     }
     switch (c) {
@@ -752,6 +798,7 @@ inline void launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K,
     }
 #undef VTX_V1
 #undef VTX_V2
+    return 0;
 }
 
 }  // namespace vtxg

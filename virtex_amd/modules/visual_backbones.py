@@ -163,11 +163,14 @@ def _prep_weight(u: _Unit, dtype, need_wt: bool):
     return w, wt
 
 
-def _conv_fwd(u: _Unit, x, w):
+def _conv_fwd(u: _Unit, x, w, bn_shift=None):
+    """Returns (y, stats): `stats` are the BatchNorm statistics of y emitted by the convolution's own
+    epilogue (None if the kernel that ran does not produce them -> stand-alone reduction)."""
     if u.is_gemm:
         N, H, W, C = x.shape
-        return ops.gemm_nt(x.view(-1, C), w.view(u.cout, C)).view(N, H, W, u.cout)
-    return ops.conv2d_fwd(x, w, u.stride, u.pad)
+        y, st = ops.gemm_nt(x.view(-1, C), w.view(u.cout, C), bn_shift=bn_shift)
+        return y.view(N, H, W, u.cout), st
+    return ops.conv2d_fwd(x, w, u.stride, u.pad, bn_shift=bn_shift)
 
 
 def _conv_dgrad(u: _Unit, dy, wt, x_shape, residual=None):
@@ -256,15 +259,16 @@ class _ResNetFn(torch.autograd.Function):
 
         def run(u: _Unit, a, relu, residual=None, first=False):
             w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
-            x = _conv_fwd(u, a, w)
             bn = u.bn
+            # the conv epilogue also produces the batch statistics (taken against the running mean)
+            x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean)
             if not train:
                 raise RuntimeError("eval-mode (running-statistics) BatchNorm is not part of the "
                                    "pretraining hot path yet (SURVEY.md 8f row f3)")
             y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                        bn.num_batches_tracked, eps=bn.eps,
                                        momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
-                                       residual=residual)
+                                       residual=residual, stats=stats)
             s = _Saved()
             s.a, s.x, s.y, s.mean, s.rstd, s.wt = a, x, y, mean, rstd, wt
             saved.append(s)

@@ -59,8 +59,37 @@ ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 c_long = _lib.ctypes.c_long
 
 
+_stat_ws = {}
+STAT_WS_FLOATS = 8 * 1024 * 1024
+
+
+def stat_workspace(device):
+    ws = _stat_ws.get(device)
+    if ws is None:
+        ws = torch.empty(STAT_WS_FLOATS if device.type == "cuda" else 1 << 20, dtype=torch.float32, device=device)
+        _stat_ws[device] = ws
+    return ws
+
+
+class BnStats:
+    """Handle to BatchNorm statistics emitted by a convolution epilogue (valid until the next one)."""
+
+    def __init__(self, parts, strips, shift):
+        self.parts, self.strips, self.shift = parts, strips, shift
+
+
+def _stat_args(out_rows, N, bn_shift, device):
+    """(parts ptr, shift ptr, strips int*, parts tensor) -- NULLs unless statistics are requested and fit."""
+    if bn_shift is None:
+        return ptr(None), ptr(None), None, None
+    ws = stat_workspace(device)
+    if ((out_rows + 63) // 64 + 4) * 2 * N > ws.numel():
+        return ptr(None), ptr(None), None, None
+    return ptr(ws), ptr(bn_shift), c_int(0), ws
+
+
 def gemm_nt(a, b, bias=None, residual=None, act=ACT_NONE, want_preact=False, alpha=1.0,
-            p_drop=0.0, seed=0, out=None, out_f32=False):
+            p_drop=0.0, seed=0, out=None, out_f32=False, bn_shift=None):
     """C[M,N] = dropout(act(alpha * a[M,K] @ b[N,K]^T + bias)) + residual.
     a, b: 2-D (row stride may exceed the row length).  Returns C (and preact if asked)."""
     assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
@@ -75,11 +104,15 @@ def gemm_nt(a, b, bias=None, residual=None, act=ACT_NONE, want_preact=False, alp
     _chk(bias, "bias", torch.float32)
     if residual is not None:
         assert residual.dim() == 2 and residual.stride(1) == 1 and residual.dtype == odt
+    sp, ss, strips, ws = _stat_args(M, N, bn_shift, a.device)
     call("vtx_gemm_nt", c_int(dtype_code(a.dtype)), c_int(M), c_int(N), c_int(K), ptr(a),
          c_long(a.stride(0)), ptr(b), c_long(b.stride(0)), ptr(out), c_long(out.stride(0)), ptr(bias),
          ptr(residual), c_long(residual.stride(0) if residual is not None else 0), ptr(pre),
          c_int(act), c_float(alpha), c_float(p_drop), c_u64(seed), c_int(1 if out_f32 else 0),
-         stream_ptr(a))
+         sp, ss, (_lib.ctypes.byref(strips) if strips is not None else ptr(None)), stream_ptr(a))
+    if bn_shift is not None:
+        st = BnStats(ws, strips.value, bn_shift) if (strips is not None and strips.value > 0) else None
+        return out, st
     return (out, pre) if want_preact else out
 
 
@@ -119,15 +152,19 @@ def _conv_out(H, W, R, S, stride, pad):
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
 
-def conv2d_fwd(x, w, stride, pad):
+def conv2d_fwd(x, w, stride, pad, bn_shift=None):
     N, H, W, C = x.shape
     KO, R, S, C2 = w.shape
     assert C2 == C and w.dtype == x.dtype
     _chk(x, "x"); _chk(w, "w")
     OH, OW = _conv_out(H, W, R, S, stride, pad)
     y = torch.empty(N, OH, OW, KO, dtype=x.dtype, device=x.device)
+    sp, ss, strips, ws = _stat_args(N * OH * OW, KO, bn_shift, x.device)
     call("vtx_conv2d_fwd", c_int(dtype_code(x.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
-         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(x), ptr(w), ptr(y), stream_ptr(x))
+         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(x), ptr(w), ptr(y), sp, ss,
+         (_lib.ctypes.byref(strips) if strips is not None else ptr(None)), stream_ptr(x))
+    if bn_shift is not None:
+        return y, (BnStats(ws, strips.value, bn_shift) if (strips is not None and strips.value > 0) else None)
     return y
 
 
@@ -174,7 +211,7 @@ def bn_workspace(device, C):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, relu=True,
-           residual=None):
+           residual=None, stats=None):
     C = x.shape[-1]
     P = x.numel() // C
     _chk(x, "x"); _chk(residual, "residual", x.dtype)
@@ -184,7 +221,9 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
     call("vtx_bn_fwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(residual), ptr(gamma), ptr(beta),
          ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mean), ptr(rstd), ptr(ws), c_int(P),
-         c_int(C), c_float(eps), c_float(momentum), c_int(1 if relu else 0), stream_ptr(x))
+         c_int(C), c_float(eps), c_float(momentum), c_int(1 if relu else 0),
+         ptr(stats.parts if stats else None), c_int(stats.strips if stats else 0),
+         ptr(stats.shift if stats else None), stream_ptr(x))
     return y, mean, rstd
 
 
