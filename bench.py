@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--textual", default="transdec_postnorm::L1_H1024_A16_F4096")
+    ap.add_argument("--visual", default="torchvision::resnet50")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -142,7 +143,8 @@ def main():
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = vf.build_bicaptioning_model(textual=a.textual, dropout=a.dropout, compute_dtype=dt).to(dev).train()
+    model = vf.build_bicaptioning_model(visual=a.visual, textual=a.textual, dropout=a.dropout,
+                                        compute_dtype=dt).to(dev).train()
     vd.broadcast_parameters(model)
     buckets = vd.GradientBuckets(model)
     opt = FusedPretrainOptimizer(model, buckets, start_step=100)   # inside warm-up: non-zero LR
@@ -179,14 +181,15 @@ def main():
         ips = a.batch * world * a.steps / elapsed
         arch = a.textual.split("::")[1]
         key = "_".join(arch.split("_")[:2])
-        gflop = GFLOP_PER_IMG.get(key)
+        cnn = a.visual.split("::")[1]
+        gflop = GFLOP_PER_IMG.get(key) if cnn == "resnet50" else (81.35 if (cnn, key) == ("resnet101", "L1_H2048") else None)
         peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
         rec = {
             "metric": "pretrain images/sec", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic",
-            "config": {"workload": f"bicaptioning_R_50_{key} {a.dtype}, bs={a.batch}/GPU, 224x224 synthetic images + "
+            "config": {"workload": f"bicaptioning_{cnn}_{key} {a.dtype}, bs={a.batch}/GPU, 224x224 synthetic images + "
                                    "30-tok captions, full step (fwd+bwd+clip+SGD+Lookahead), dropout "
                                    f"{a.dropout}", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},

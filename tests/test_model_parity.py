@@ -170,3 +170,26 @@ def test_direct_gradient_accumulation_matches_autograd_path(backend):
     worst = max((rel_err(p.grad.cpu(), ref[n].cpu()), n) for n, p in model.named_parameters())
     assert worst[0] < 1e-4, worst
     assert all(p.grad.data_ptr() >= buckets.flat.data_ptr() for p in model.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("visual,textual", [("torchvision::resnet50", "transdec_postnorm::L4_H1024_A16_F4096"),
+                                            ("torchvision::resnet101", "transdec_postnorm::L1_H2048_A32_F8192")])
+def test_other_baseline_configs_fp32_gpu(visual, textual):
+    """BASELINE.json configs 4 and 5 (depth ablation L4, ResNet-101 + H2048): loss and every text-side
+    gradient against the oracle at B=2, fp32 (the backbone gradients are covered by the calibrated test)."""
+    dev = select("gpu")
+    kw = dict(visual=visual, textual=textual, vocab_size=10000)
+    oracle_model = synth.seeded_model(port.build_model, seed=0, dropout=0.0, **kw).train()
+    model = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=torch.float32, **kw)
+    model.load_state_dict(oracle_model.state_dict())
+    model = model.to(dev)
+    batch = synth.synthetic_batch(2, seed=5, ragged=True)
+    oo = oracle_model(batch)
+    oo["loss"].backward()
+    out = _run(model, batch, dev)
+    assert abs(out["loss"].item() - oo["loss"].item()) < 1e-5 * abs(oo["loss"].item())
+    worst = max((rel_err(p.grad.cpu(), q.grad), n) for (n, p), (_, q) in
+                zip(model.named_parameters(), oracle_model.named_parameters()) if "cnn" not in n)
+    assert worst[0] < 1e-3, worst
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())

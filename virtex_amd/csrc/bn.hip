@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
-constexpr int VTX_BN_MAX_PARTS = 1024;
+constexpr int VTX_BN_MAX_PARTS = 512;
 struct ReducePlan { int TX, gy, gx, rows; };
 static ReducePlan plan_reduce(int P, int C, int vec) {
     ReducePlan r;
