@@ -28,25 +28,59 @@ struct AttnArgs {
     Dropout drop;
 };
 
+// rows x 64 tile, global (dtype, 16-byte vector loads: head columns start at multiples of 64 elements and
+// row strides are multiples of 8, so every chunk is aligned) -> LDS fp32
 template <class T> __device__ __forceinline__ void load_tile(float* dst, int dstride, const T* src, long ld,
                                                              int rows, int tid) {
-    for (int i = tid; i < rows * D; i += 256) {
-        const int r = i / D, c = i % D;
-        dst[r * dstride + c] = Elem<T>::ld(src + (long)r * ld + c);
+    constexpr int VEC = Elem<T>::VEC, CPR = D / VEC;
+    for (int i = tid; i < rows * CPR; i += 256) {
+        const int r = i / CPR, c = (i % CPR) * VEC;
+        Vec16<T> v; v.load(src + (long)r * ld + c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[r * dstride + c + j] = v.v[j];
+    }
+}
+// out[r][c..c+VEC) = sum_{k<n} coef(r,k) * mat[k*mstride + c..]  -> global dtype with 16-byte stores.
+// (k outer, VEC accumulators inner: every coefficient is read from LDS once per chunk)
+template <class T, class F> __device__ __forceinline__ void matmul_store(T* dst, long ld, int rows, int tid, int n,
+                                                                         const float* mat, int mstride, F coef) {
+    constexpr int VEC = Elem<T>::VEC, CPR = D / VEC;
+    for (int i = tid; i < rows * CPR; i += 256) {
+        const int r = i / CPR, c = (i % CPR) * VEC;
+        Vec16<T> v;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v.v[j] = 0.f;
+        for (int k = 0; k < n; ++k) {
+            const float w = coef(r, k);
+            const float* m = mat + k * mstride + c;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v.v[j] += w * m[j];
+        }
+        v.store(dst + (long)r * ld + c);
     }
 }
 
 // scores -> P (pre-dropout softmax) in sP[T][SMAX]
 __device__ __forceinline__ void scores_softmax(const float* sQ, const float* sK, float* sP, const AttnArgs& a,
                                                int len, int tid) {
-    for (int idx = tid; idx < a.T * a.S; idx += 256) {
-        const int i = idx / a.S, j = idx % a.S;
-        float s = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < D; ++d) s += sQ[i * D + d] * sK[j * KP + d];
-        s *= a.scale;
-        if ((a.causal && j > i) || j >= len) s = -INFINITY;
-        sP[i * SMAX + j] = s;
+    // one query x four keys per thread: each Q value is read from LDS once per four products
+    const int S4 = (a.S + 3) / 4;
+    for (int idx = tid; idx < a.T * S4; idx += 256) {
+        const int i = idx / S4, j0 = (idx % S4) * 4;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* q = sQ + i * D;
+        const float* k0 = sK + j0 * KP;     // rows beyond S are inside the SMAX-row buffer (never stored)
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+            const float qv = q[d];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] += qv * k0[t * KP + d];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + t;
+            if (j < a.S) sP[i * SMAX + j] = ((a.causal && j > i) || j >= len) ? -INFINITY : s[t] * a.scale;
+        }
     }
     __syncthreads();
     const int lane = tid & 63, wv = tid >> 6;
@@ -72,12 +106,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, T* __restrict
     const int len = a.lengths ? (int)a.lengths[b] : a.S;
     scores_softmax(sQ, sK, sP, a, len, tid);
     const uint64_t pbase = (uint64_t)blockIdx.x * (TMAX * SMAX);
-    for (int idx = tid; idx < a.T * D; idx += 256) {
-        const int i = idx / D, d = idx % D;
-        float acc = 0.f;
-        for (int j = 0; j < a.S; ++j) acc += a.drop.apply(sP[i * SMAX + j], pbase + i * SMAX + j) * sV[j * KP + d];
-        Elem<T>::st(o + ((long)b * a.T + i) * a.ldo + h * D + d, acc);
+    // apply the attention dropout once, in place, then O = Pd V with 16-byte stores
+    if (a.drop.thresh) {
+        for (int idx = tid; idx < a.T * a.S; idx += 256) {
+            const int i = idx / a.S, j = idx % a.S;
+            sP[i * SMAX + j] = a.drop.apply(sP[i * SMAX + j], pbase + i * SMAX + j);
+        }
+        __syncthreads();
     }
+    matmul_store<T>(o + (long)b * a.T * a.ldo + h * D, a.ldo, a.T, tid, a.S, sV, KP,
+                    [&](int i, int j) { return sP[i * SMAX + j]; });
 }
 
 template <class T>
@@ -96,19 +134,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, const T* __re
     scores_softmax(sQ, sK, sP, a, len, tid);
     const uint64_t pbase = (uint64_t)blockIdx.x * (TMAX * SMAX);
     // dV[j][d] = sum_i Pd[i][j] dO[i][d]
-    for (int idx = tid; idx < a.S * D; idx += 256) {
-        const int j = idx / D, d = idx % D;
-        float acc = 0.f;
-        for (int i = 0; i < a.T; ++i) acc += a.drop.apply(sP[i * SMAX + j], pbase + i * SMAX + j) * sO[i * D + d];
-        Elem<T>::st(dv + ((long)b * a.S + j) * lddv + h * D + d, acc);
-    }
+    matmul_store<T>(dv + (long)b * a.S * lddv + h * D, lddv, a.S, tid, a.T, sO, D,
+                    [&](int j, int i) { return a.drop.apply(sP[i * SMAX + j], pbase + i * SMAX + j); });
     // dP[i][j] = dropout'( sum_d dO[i][d] V[j][d] )
-    for (int idx = tid; idx < a.T * a.S; idx += 256) {
-        const int i = idx / a.S, j = idx % a.S;
-        float acc = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < D; ++d) acc += sO[i * D + d] * sV[j * KP + d];
-        sG[i * SMAX + j] = a.drop.apply(acc, pbase + i * SMAX + j);
+    const int S4 = (a.S + 3) / 4;
+    for (int idx = tid; idx < a.T * S4; idx += 256) {
+        const int i = idx / S4, j0 = (idx % S4) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* go = sO + i * D;
+        const float* v0 = sV + j0 * KP;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+            const float gv = go[d];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += gv * v0[t * KP + d];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (j0 + t < a.S) sG[i * SMAX + j0 + t] = a.drop.apply(acc[t], pbase + i * SMAX + j0 + t);
     }
     __syncthreads();
     // dS = P * (dP - rowsum(dP * P)) * scale   (written over sG)
@@ -120,18 +163,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, const T* __re
         if (lane < a.S) sG[i * SMAX + lane] = p * (g - dot) * a.scale;
     }
     __syncthreads();
-    for (int idx = tid; idx < a.T * D; idx += 256) {
-        const int i = idx / D, d = idx % D;
-        float acc = 0.f;
-        for (int j = 0; j < a.S; ++j) acc += sG[i * SMAX + j] * sK[j * KP + d];
-        Elem<T>::st(dq + ((long)b * a.T + i) * lddq + h * D + d, acc);
-    }
-    for (int idx = tid; idx < a.S * D; idx += 256) {
-        const int j = idx / D, d = idx % D;
-        float acc = 0.f;
-        for (int i = 0; i < a.T; ++i) acc += sG[i * SMAX + j] * sQ[i * D + d];
-        Elem<T>::st(dk + ((long)b * a.S + j) * lddk + h * D + d, acc);
-    }
+    matmul_store<T>(dq + (long)b * a.T * lddq + h * D, lddq, a.T, tid, a.S, sK, KP,
+                    [&](int i, int j) { return sG[i * SMAX + j]; });
+    matmul_store<T>(dk + (long)b * a.S * lddk + h * D, lddk, a.S, tid, a.T, sQ, D,
+                    [&](int j, int i) { return sG[i * SMAX + j]; });
 }
 
 static int check(const char* who, int dtype, int B, int heads, int T, int S, int head_dim) {
