@@ -20,12 +20,41 @@ static int conv_dgrad_t(const ConvGeo& g, const void* dy, const void* wt, void* 
     return VTX_OK;
 }
 
+// stride 2, even H and W: four dense parity-class GEMMs (no zero taps), rows scattered in the epilogue
+template <class T>
+static int conv_dgrad_s2_t(const ConvGeo& g, const void* dy, const void* wt, void* dx, const void* residual,
+                           hipStream_t st) {
+    const int M = g.N * (g.H / 2) * (g.W / 2);
+    for (int pa = 0; pa < 2; ++pa)
+        for (int pb = 0; pb < 2; ++pb) {
+            TapList taps; taps.n = 0;
+            for (int t = 0; t < 4; ++t) taps.kh[t] = taps.kw[t] = 0;
+            for (int kh = (pa + g.pad) & 1; kh < g.R; kh += 2)
+                for (int kw = (pb + g.pad) & 1; kw < g.S; kw += 2)
+                    if (taps.n < 4) { taps.kh[taps.n] = kh; taps.kw[taps.n] = kw; ++taps.n; }
+            const int Kd = taps.n * g.KO;
+            EpiStore<T> ep{(T*)dx, g.C, nullptr, (const T*)residual, g.C, nullptr, ACT_NONE, 1.f, make_dropout(0.f, 0), M, g.C};
+            ep.map_on = 1; ep.map_H = g.H; ep.map_W = g.W; ep.map_pa = pa; ep.map_pb = pb;
+            launch_auto<T, ConvDgradS2A, TapKC>(
+                [&](auto& a) { a.dy = (const T*)dy; a.g = g; a.rows = M; a.K = Kd; a.pa = pa; a.pb = pb; a.taps = taps; },
+                [&](auto& b) { b.p = (const T*)wt; b.ld = (long)g.R * g.S * g.KO; b.rows = g.C; b.K = Kd; b.logKO = g.logKO;
+                               b.S = g.S; b.taps = taps; },
+                ep, M, g.C, Kd, 1, st);
+        }
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
 extern "C" int vtx_conv2d_dgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride,
                                 int pad, const void* dy, const void* wt, void* dx, const void* residual, void* stream) {
     VTX_CHECK(dy && wt && dx, VTX_ERR_ARG, "conv2d_dgrad: null pointer");
     ConvGeo g;
     int rc = make_geo("conv2d_dgrad", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
     if (rc) return rc;
+    if (stride == 2 && H % 2 == 0 && W % 2 == 0 && R <= 4 && S <= 4) {
+        if (dtype == VTX_BF16) return conv_dgrad_s2_t<bf16_t>(g, dy, wt, dx, residual, (hipStream_t)stream);
+        return conv_dgrad_s2_t<float>(g, dy, wt, dx, residual, (hipStream_t)stream);
+    }
     if (dtype == VTX_BF16) return conv_dgrad_t<bf16_t>(g, dy, wt, dx, residual, (hipStream_t)stream);
     return conv_dgrad_t<float>(g, dy, wt, dx, residual, (hipStream_t)stream);
 }

@@ -146,6 +146,52 @@ template <class T, int SL> struct ConvDgradA {
     }
 };
 
+// stride-2 input gradient, one PARITY CLASS (pa,pb) of the input pixels at a time: pixel (2*ih2+pa,
+// 2*iw2+pb) only receives taps with kh = (pa+p) mod 2 (+2, ...), so the class is a dense GEMM over its
+// own tap list (1, 2 or 4 taps for a 3x3) instead of a 9-tap gather that is 3/4 zeros.
+struct TapList { int n; int kh[4], kw[4]; };
+template <class T, int SL> struct ConvDgradS2A {
+    static constexpr bool MC = false;
+    const T* dy; ConvGeo g; int rows; int K; int pa, pb; TapList taps;   // rows = N*(H/2)*(W/2), K = taps.n*KO
+    struct State { long base[SL]; int ihp[SL], iwp[SL]; bool ok[SL]; int kc[SL]; };
+    __device__ __forceinline__ void init_slot(State& s, int i, int m, int kc) const {
+        s.kc[i] = kc;
+        s.ok[i] = m < rows;
+        const int mm = s.ok[i] ? m : 0;
+        const int h2 = g.H >> 1, w2 = g.W >> 1;
+        const int n = mm / (h2 * w2), rem = mm - n * h2 * w2;
+        const int ih2 = rem / w2, iw2 = rem - ih2 * w2;
+        s.base[i] = (long)n * g.OH * g.OW * g.KO;
+        s.ihp[i] = 2 * ih2 + pa + g.pad;
+        s.iwp[i] = 2 * iw2 + pb + g.pad;
+    }
+    __device__ __forceinline__ const T* ptr(const State& s, int i, int k0) const {
+        const int k = k0 + s.kc[i];
+        const int t = k >> g.logKO, co = k & (g.KO - 1);
+        const int tt = t < 4 ? t : 3;
+        const int oh = (s.ihp[i] - taps.kh[tt]) >> 1, ow = (s.iwp[i] - taps.kw[tt]) >> 1;
+        const bool ok = s.ok[i] && k < K && (unsigned)oh < (unsigned)g.OH && (unsigned)ow < (unsigned)g.OW;
+        return ok ? dy + s.base[i] + ((long)oh * g.OW + ow) * g.KO + co : nullptr;
+    }
+};
+// B operand of the above: rows = input channels of wt[C][R][S][KO], k = (tap index, co)
+template <class T, int SL> struct TapKC {
+    static constexpr bool MC = false;
+    const T* p; long ld; int rows; int K; int logKO; int S; TapList taps;
+    struct State { const T* rp[SL]; int kc[SL]; };
+    __device__ __forceinline__ void init_slot(State& s, int i, int r, int kc) const {
+        s.kc[i] = kc;
+        s.rp[i] = r < rows ? p + (long)r * ld : nullptr;
+    }
+    __device__ __forceinline__ const T* ptr(const State& s, int i, int k0) const {
+        const int k = k0 + s.kc[i];
+        if (!s.rp[i] || k >= K) return nullptr;
+        const int t = k >> logKO, co = k & ((1 << logKO) - 1);
+        const int tt = t < 4 ? t : 3;
+        return s.rp[i] + ((long)(taps.kh[tt] * S + taps.kw[tt]) << logKO) + co;
+    }
+};
+
 // weight gradient: B(r,k): r = (kh,kw,ci), k = (n,oh,ow) -> x[n][oh*s-p+kh][ow*s-p+kw][ci]
 template <class T, int SL> struct ConvWgradB {
     static constexpr bool MC = true;
@@ -225,6 +271,16 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
     // wave rows of the grid (strip = tile_m * WM + wm), summed by the BN finalize kernel.
     float* stat_parts = nullptr;
     const float* stat_shift = nullptr;
+    // Row scatter for the parity-decomposed stride-2 input gradient: GEMM row m = (n, ih2, iw2) is output
+    // pixel (n, 2*ih2+map_pa, 2*iw2+map_pb) of an H x W image.  map_on = 0: identity.
+    int map_on = 0, map_H = 0, map_W = 0, map_pa = 0, map_pb = 0;
+    __device__ __forceinline__ long out_row(int m) const {
+        if (!map_on) return m;
+        const int h2 = map_H >> 1, w2 = map_W >> 1;
+        const int n = m / (h2 * w2), rem = m - n * h2 * w2;
+        const int ih2 = rem / w2, iw2 = rem - ih2 * w2;
+        return ((long)n * map_H + 2 * ih2 + map_pa) * map_W + 2 * iw2 + map_pb;
+    }
     // per-lane part (4 consecutive n of one m): everything except the residual add and the store
     __device__ __forceinline__ f32x4_t transform(int m, int n, f32x4_t v) const {
         if (m >= M || n >= N) return v;
@@ -253,12 +309,13 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
     __device__ __forceinline__ void store_wide(int m, int n, uint4 w) const {
         if (m >= M || n >= N) return;
         constexpr int EPV = 16 / (int)sizeof(T);
-        const long o = (long)m * ldc + n + (long)blockIdx.y * split_stride;
+        const long mr = out_row(m);
+        const long o = mr * ldc + n + (long)blockIdx.y * split_stride;
         const bool full = n + EPV <= N;
         if (residual) {
-            if (full) w = add16<T>(w, *reinterpret_cast<const uint4*>(residual + (long)m * ldr + n));
+            if (full) w = add16<T>(w, *reinterpret_cast<const uint4*>(residual + mr * ldr + n));
             else {
-                const uint2 r = *reinterpret_cast<const uint2*>(residual + (long)m * ldr + n);
+                const uint2 r = *reinterpret_cast<const uint2*>(residual + mr * ldr + n);
                 w = add16<T>(w, make_uint4(r.x, r.y, 0u, 0u));
             }
         }
@@ -272,7 +329,8 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += bias[n + j];
         }
-        const long o = (long)m * ldc + n + (long)blockIdx.y * split_stride;
+        const long mr = out_row(m);
+        const long o = mr * ldc + n + (long)blockIdx.y * split_stride;
         if (preact) st4<T>(preact + o, v);
         if (act == ACT_GELU) {
 #pragma unroll
@@ -286,7 +344,7 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
             for (int j = 0; j < 4; ++j) v[j] = drop.apply(v[j], (uint64_t)(o + j));
         }
         if (residual) {
-            float r[4]; ld4<T>(residual + (long)m * ldr + n, r);
+            float r[4]; ld4<T>(residual + mr * ldr + n, r);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += r[j];
         }
@@ -709,9 +767,9 @@ inline void launch_v1(const AL& al, const BL& bl, const EP& ep, int M, int N, in
     const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
     const int nkt = vtx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
-    if (split_k > nkt) split_k = nkt;
-    const int per = vtx_cdiv(nkt, split_k);
-    split_k = vtx_cdiv(nkt, per);
+    if (split_k > nkt) split_k = nkt > 0 ? nkt : 1;
+    const int per = vtx_cdiv(nkt, split_k);       // K == 0: no K steps, the epilogue alone runs
+    split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
     dim3 grid(tiles_m * tiles_n, split_k), block(NTHREADS);
     hipLaunchKernelGGL((contraction_kernel<T, BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K, tiles_n, per);
 }
@@ -722,9 +780,9 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int
     const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
     const int nkt = vtx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
-    if (split_k > nkt) split_k = nkt;
-    const int per = vtx_cdiv(nkt, split_k);
-    split_k = vtx_cdiv(nkt, per);
+    if (split_k > nkt) split_k = nkt > 0 ? nkt : 1;
+    const int per = vtx_cdiv(nkt, split_k);       // K == 0: no K steps, the epilogue alone runs
+    split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
     constexpr size_t lds_bytes = 3 * (size_t)(BM + BN) * BK * 2;
     auto kern = contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP>;
     static bool attr_set = false;
