@@ -619,7 +619,14 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int tile = blockIdx.x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch policy; a speed assumption
+    // only).  Give every XCD a contiguous range of tiles so that the tiles sharing an A panel (same
+    // tile_m, consecutive tile ids) hit the same private L2 instead of eight different ones.
+    int tile;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nkt = (K + BK - 1) / BK;
     const int kt0 = blockIdx.y * kt_per_split;
