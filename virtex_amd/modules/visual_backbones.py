@@ -13,6 +13,7 @@ hand-scheduled sequence of C-ABI kernel launches (virtex_amd/ops.py) on the call
 stream -- NHWC implicit-GEMM convolutions on MFMA, fused BatchNorm+ReLU(+residual), maxpool.
 torch supplies device memory and the autograd edge only.
 """
+import os
 from typing import List
 
 import torch
@@ -23,6 +24,10 @@ from .. import gradsink, ops
 RESNET_BLOCKS = {"resnet50": ((3, 4, 6, 3), 64), "resnet101": ((3, 4, 23, 3), 64),
                  "wide_resnet50_2": ((3, 4, 6, 3), 128)}
 STEM_CPAD = 8  # the 3 input channels are zero-padded to 8 (one 16-byte bf16 vector)
+# BatchNorm statistics from the convolution epilogue: implemented and tested (ops.conv2d_fwd(bn_shift=...)),
+# but measured SLOWER than the stand-alone reduction on this step (43.8 vs 42.1 ms: the extra ~48 VGPRs of
+# the statistics epilogue cost the GEMMs more than the saved 5.7 GB read) -> off by default.
+FUSE_BN_STATS = os.environ.get("VIRTEX_AMD_FUSE_BN_STATS", "0") != "0"
 
 
 # ----------------------------------------------------------------------------------------
@@ -165,11 +170,15 @@ def _prep_weight(u: _Unit, dtype, need_wt: bool):
 
 def _conv_fwd(u: _Unit, x, w, bn_shift=None):
     """Returns (y, stats): `stats` are the BatchNorm statistics of y emitted by the convolution's own
-    epilogue (None if the kernel that ran does not produce them -> stand-alone reduction)."""
+    epilogue (None if not requested or the kernel that ran does not produce them -> stand-alone reduction)."""
     if u.is_gemm:
         N, H, W, C = x.shape
+        if bn_shift is None:
+            return ops.gemm_nt(x.view(-1, C), w.view(u.cout, C)).view(N, H, W, u.cout), None
         y, st = ops.gemm_nt(x.view(-1, C), w.view(u.cout, C), bn_shift=bn_shift)
         return y.view(N, H, W, u.cout), st
+    if bn_shift is None:
+        return ops.conv2d_fwd(x, w, u.stride, u.pad), None
     return ops.conv2d_fwd(x, w, u.stride, u.pad, bn_shift=bn_shift)
 
 
@@ -205,7 +214,7 @@ class wgrad_stream:
     reads them until the optimizer) on a side HIP stream, concurrently with the input-gradient chain.
     Inputs are fenced with an event; their memory is kept alive for the side stream with record_stream;
     `join()` makes the main stream wait for everything issued so far."""
-    enabled = True
+    enabled = os.environ.get("VIRTEX_AMD_WGRAD_STREAM", "1") != "0"
 
     def __init__(self, device, *inputs):
         self.device, self.inputs = device, inputs
@@ -261,7 +270,7 @@ class _ResNetFn(torch.autograd.Function):
             w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
             bn = u.bn
             # the conv epilogue also produces the batch statistics (taken against the running mean)
-            x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean)
+            x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean if FUSE_BN_STATS else None)
             if not train:
                 raise RuntimeError("eval-mode (running-statistics) BatchNorm is not part of the "
                                    "pretraining hot path yet (SURVEY.md 8f row f3)")
