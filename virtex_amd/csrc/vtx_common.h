@@ -58,14 +58,29 @@ template <> struct Elem<bf16_t> {
 
 // 16-byte vector of T unpacked to / packed from fp32 registers.
 template <class T> struct Vec16;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// streaming (non-temporal) 16-byte accesses.  Measured on the BatchNorm apply kernels: SLOWER (43.9 vs 42.2
+// ms/step) -- the producer's output is still in the Infinity Cache when the next kernel reads it, and nt
+// bypasses it.  Kept for kernels whose inputs really are cold.
+__device__ __forceinline__ u32x4_t ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+__device__ __forceinline__ void st16_nt(void* p, u32x4_t v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p)); }
+
 template <> struct Vec16<float> {
     float v[4];
     __device__ __forceinline__ void load(const float* p) {
         float4 t = *reinterpret_cast<const float4*>(p);
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
+    __device__ __forceinline__ void load_nt(const float* p) {
+        const u32x4_t t = ld16_nt(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(t[i]);
+    }
     __device__ __forceinline__ void store(float* p) const {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    __device__ __forceinline__ void store_nt(float* p) const {
+        st16_nt(p, u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
     }
 };
 template <> struct Vec16<bf16_t> {
@@ -79,11 +94,25 @@ template <> struct Vec16<bf16_t> {
             v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
         }
     }
+    __device__ __forceinline__ void load_nt(const bf16_t* p) {
+        const u32x4_t t = ld16_nt(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(t[i] << 16);
+            v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+        }
+    }
     __device__ __forceinline__ void store(bf16_t* p) const {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ __forceinline__ void store_nt(bf16_t* p) const {
+        u32x4_t w;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+        st16_nt(p, w);
     }
 };
 
