@@ -38,25 +38,41 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
         mu[j] = BWD ? mean[c0 + j] : Elem<T>::ld(x + c0 + j);
         rs[j] = BWD ? rstd[c0 + j] : 0.f;
     }
-    for (int p = p0 + ty; p < p1; p += TY) {
-        const size_t off = (size_t)p * C + c0;
-        Vec16<T> xv; xv.load(x + off);
-        if (BWD) {
-            Vec16<T> g; g.load(dy + off);
-            if (ymask) {
-                Vec16<T> m; m.load(ymask + off);
+    // UNR rows per trip, all loads issued before any use: one 16-byte load per wave in flight cannot cover
+    // the HBM latency with <= 512 blocks on 256 CUs (measured 2.9 TB/s before)
+    constexpr int UNR = BWD ? 2 : 4;
+    for (int pb = p0 + ty; pb < p1; pb += UNR * TY) {
+        Vec16<T> xv[UNR], g[UNR], m[UNR];
+        bool ok[UNR];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) g.v[j] = m.v[j] > 0.f ? g.v[j] : 0.f;
+        for (int u = 0; u < UNR; ++u) {
+            const int p = pb + u * TY;
+            ok[u] = p < p1;
+            const size_t off = (size_t)(ok[u] ? p : p0) * C + c0;
+            xv[u].load(x + off);
+            if (BWD) {
+                g[u].load(dy + off);
+                if (ymask) m[u].load(ymask + off);
             }
+        }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float xh = (xv.v[j] - mu[j]) * rs[j];
-                if (remask) g.v[j] = xh * ga[j] + be[j] > 0.f ? g.v[j] : 0.f;
-                a[j] += g.v[j]; b[j] += g.v[j] * xh;
+        for (int u = 0; u < UNR; ++u) {
+            if (!ok[u]) continue;
+            if (BWD) {
+                if (ymask) {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) g[u].v[j] = m[u].v[j] > 0.f ? g[u].v[j] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float xh = (xv[u].v[j] - mu[j]) * rs[j];
+                    if (remask) g[u].v[j] = xh * ga[j] + be[j] > 0.f ? g[u].v[j] : 0.f;
+                    a[j] += g[u].v[j]; b[j] += g[u].v[j] * xh;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { const float d = xv[u].v[j] - mu[j]; a[j] += d; b[j] += d * d; }
             }
-        } else {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) { const float d = xv.v[j] - mu[j]; a[j] += d; b[j] += d * d; }
         }
     }
     __shared__ float red[2][256 * VEC];
@@ -80,20 +96,31 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
 }
 
 
-// Sums the per-strip partials of 32 channels with 8 thread groups (block = 256 threads =
-// 32 channels x 8 groups); returns the totals to the group-0 threads.
+// Sums the per-strip partials of FIN_CH channels with FIN_GR thread groups (block = 256 threads); returns the
+// totals to the group-0 threads.  Latency-bound (the partials sit in the Infinity Cache, ~1 us away): many
+// short chains with four independent loads per trip, not a few long ones (22 us -> see DESIGN.md 6).
+constexpr int FIN_CH = 16, FIN_GR = 16;
 __device__ __forceinline__ void sum_partials(const float* __restrict__ sums, int C, int nparts, int c, int grp,
                                              float& t0, float& t1) {
-    __shared__ float red[2][8][32];
+    __shared__ float red[2][FIN_GR][FIN_CH];
     float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int p = grp; p < nparts; p += 8) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
-    red[0][grp][threadIdx.x & 31] = a; red[1][grp][threadIdx.x & 31] = b;
+    if (c < C) {
+        int p = grp;
+        for (; p + 3 * FIN_GR < nparts; p += 4 * FIN_GR) {
+            const float* q = sums + (size_t)p * 2 * C + c;
+            const size_t st = (size_t)FIN_GR * 2 * C;
+            const float a0 = q[0], a1 = q[st], a2 = q[2 * st], a3 = q[3 * st];
+            const float b0 = q[C], b1 = q[st + C], b2 = q[2 * st + C], b3 = q[3 * st + C];
+            a += (a0 + a1) + (a2 + a3); b += (b0 + b1) + (b2 + b3);
+        }
+        for (; p < nparts; p += FIN_GR) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
+    }
+    red[0][grp][threadIdx.x % FIN_CH] = a; red[1][grp][threadIdx.x % FIN_CH] = b;
     __syncthreads();
     t0 = t1 = 0.f;
     if (grp == 0) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+        for (int g = 0; g < FIN_GR; ++g) { t0 += red[0][g][threadIdx.x % FIN_CH]; t1 += red[1][g][threadIdx.x % FIN_CH]; }
     }
 }
 
@@ -126,7 +153,7 @@ __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __r
                                        float* __restrict__ shift, float* __restrict__ running_mean,
                                        float* __restrict__ running_var, long long* __restrict__ nbt,
                                        int P, int C, float eps, float momentum, int nparts) {
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, grp = threadIdx.x / FIN_CH;
     float t0, t1;
     sum_partials(sums, C, nparts, c, grp, t0, t1);
     if (c == 0 && grp == 0 && nbt) *nbt += 1;
@@ -179,7 +206,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ sums, const flo
                                        const float* __restrict__ rstd, float* __restrict__ coef,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int P, int C,
                                        int nparts) {
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, grp = threadIdx.x / FIN_CH;
     float s1, s2;
     sum_partials(sums, C, nparts, c, grp, s1, s2);
     if (c >= C || grp != 0) return;
@@ -283,10 +310,10 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
         hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
@@ -318,7 +345,7 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     else
         hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, 32)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
                        dgamma, dbeta, P, C, rp.gx);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,

@@ -70,21 +70,47 @@ int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
 }
 
 namespace {
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
 // C[m][n] += sum_s ws[s][m][n]      (alpha already applied by the GEMM epilogue)
+// Block = (256/G float4 columns) x (G slice groups): a small weight matrix split hundreds of ways (the 1x1
+// convolutions of stage 1: K = 802,816) would otherwise be a handful of threads walking a serial chain of
+// dependent loads.  Each group sums its slices four loads at a time; LDS folds the groups.
+template <int G>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long MN, int N,
                                                             float* __restrict__ C, long ldc) {
+    constexpr int COLS = 256 / G;
+    __shared__ float4 red[G > 1 ? 256 : 1];
+    const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
     const long nv = MN / 4;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-        float4 a = reinterpret_cast<const float4*>(ws)[i];
-        for (int s2 = 1; s2 < S; ++s2) {
-            const float4 b = reinterpret_cast<const float4*>(ws + (long)s2 * MN)[i];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    for (long i0 = (long)blockIdx.x * COLS; i0 < nv; i0 += (long)gridDim.x * COLS) {
+        const long i = i0 + col;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nv) {
+            int s2 = grp;
+            for (; s2 + 3 * G < S; s2 += 4 * G) {
+                const float4 b0 = reinterpret_cast<const float4*>(ws + (long)s2 * MN)[i];
+                const float4 b1 = reinterpret_cast<const float4*>(ws + (long)(s2 + G) * MN)[i];
+                const float4 b2 = reinterpret_cast<const float4*>(ws + (long)(s2 + 2 * G) * MN)[i];
+                const float4 b3 = reinterpret_cast<const float4*>(ws + (long)(s2 + 3 * G) * MN)[i];
+                a = f4add(a, f4add(f4add(b0, b1), f4add(b2, b3)));
+            }
+            for (; s2 < S; s2 += G) a = f4add(a, reinterpret_cast<const float4*>(ws + (long)s2 * MN)[i]);
         }
-        const long e = i * 4, m = e / N, n = e - m * N;      // N % 4 == 0: a float4 never straddles rows
-        float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
-        float4 c = *dst;
-        c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
-        *dst = c;
+        if (G > 1) {
+            __syncthreads();
+            red[threadIdx.x] = a;
+            __syncthreads();
+            if (grp == 0) {
+#pragma unroll
+                for (int g = 1; g < G; ++g) a = f4add(a, red[g * COLS + col]);
+            }
+        }
+        if (grp == 0 && i < nv) {
+            const long e = i * 4, m = e / N, n = e - m * N;      // N % 4 == 0: a float4 never straddles rows
+            float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+            *dst = f4add(*dst, a);
+        }
     }
 }
 }  // namespace
@@ -99,10 +125,15 @@ vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M
 }
 
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st) {
-    const long MN = (long)M * N;
-    long g = (MN / 4 + 255) / 256;
+    const long MN = (long)M * N, nv = MN / 4;
+    // widen over the slices until the launch has ~1k blocks (or the slices run out)
+    int G = 1;
+    while (G < 16 && G * 4 <= S && (nv * G + 255) / 256 < 1024) G *= 4;
+    long g = (nv * G + 255) / 256;
     if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
+    if (G == 1) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
+    else if (G == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
 }
 
 extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,

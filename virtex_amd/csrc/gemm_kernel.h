@@ -812,7 +812,11 @@ inline int pick_tile(int M, int N, int splits, bool allow256) {
     // 128x128 680, 256x256 567 -- one resident block per CU cannot hide its own epilogue)
     static const TileCand cands[6] = {{256, 256, 1, 0.70f}, {256, 128, 2, 1.00f}, {128, 128, 3, 0.84f},
                                       {128, 64, 4, 0.55f}, {64, 128, 4, 0.55f}, {64, 64, 4, 0.35f}};
-    int best = 5; float best_score = -1.f;
+    // cost model: every CU works through ceil(blocks / 256) tiles (co-resident blocks share the CU, so
+    // residency changes overlap, not the amount of work); a tile costs its area over the measured relative
+    // throughput, and a CU that only ever holds one block loses the epilogue/main-loop overlap (~10 %).
+    // Validated against tools/sweep_tiles.py on every GEMM-shaped op of the step.
+    int best = 5; float best_cost = 3.4e38f;
     for (int c = 0; c < 6; ++c) {
         const TileCand& t = cands[c];
         if (!allow256 && t.bm == 256) continue;
@@ -821,11 +825,10 @@ inline int pick_tile(int M, int N, int splits, bool allow256) {
         if (t.bm > 64 && M <= 64) continue;
         const long tm = vtx_cdiv(M, t.bm), tn = vtx_cdiv(N, t.bn);
         const long blocks = tm * tn * (splits < 1 ? 1 : splits);
-        const long slots = 256L * t.resident;
-        const float quant = (float)blocks / (float)(((blocks + slots - 1) / slots) * slots);
-        const float pad = ((float)M * (float)N) / ((float)(tm * t.bm) * (float)(tn * t.bn));
-        const float score = t.eff * quant * pad;
-        if (score > best_score) { best_score = score; best = c; }
+        const long rounds = (blocks + 255) / 256;
+        const float overlap = (rounds < 2 && t.resident > 1) ? 0.9f : 1.0f;
+        const float cost = (float)rounds * (float)(t.bm * t.bn) / (t.eff * overlap);
+        if (cost < best_cost) { best_cost = cost; best = c; }
     }
     return best;
 }
