@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     }
     // UNR rows per trip, all loads issued before any use: one 16-byte load per wave in flight cannot cover
     // the HBM latency with <= 512 blocks on 256 CUs (measured 2.9 TB/s before)
-    constexpr int UNR = BWD ? 2 : 4;
+    constexpr int UNR = 4;
     for (int pb = p0 + ty; pb < p1; pb += UNR * TY) {
         Vec16<T> xv[UNR], g[UNR], m[UNR];
         bool ok[UNR];
