@@ -96,6 +96,20 @@ int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S
                      const void* x, const void* dy, float* dw, int split_k, float* workspace,
                      long workspace_floats, void* stream);
 
+/* ---- eval-mode / frozen backbone: BatchNorm folded into the convolution ----------------
+ * Reference: VISUAL.FROZEN puts the CNN in eval mode (visual_backbones.py:49-53); validation and the
+ * downstream feature extractors run model.eval() (scripts/pretrain_virtex.py validation loop,
+ * scripts/clf_voc07.py:165-200).  Replaces aten::convolution + batch_norm(training=False) + add_ + relu_.
+ * vtx_bn_fold:      w[ko][t][c] = w32[ko][t][c] * gamma[ko]*rsqrt(running_var[ko]+eps)   (dtype, C padded to Cp)
+ *                   bias[ko]    = beta[ko] - running_mean[ko] * gamma[ko]*rsqrt(running_var[ko]+eps)
+ * vtx_conv2d_infer: y = act(conv(x, w) + bias (+ residual)); relu != 0 applies ReLU after the residual add. */
+int vtx_bn_fold(int dtype, const float* w32 /*[KO][T][C]*/, const float* gamma, const float* beta,
+                const float* running_mean, const float* running_var, float eps, void* w /*[KO][T][Cp]*/,
+                float* bias /*[KO]*/, int KO, int T, int C, int Cp, void* stream);
+int vtx_conv2d_infer(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
+                     const void* x, const void* w, const float* bias /*nullable*/,
+                     const void* residual /*nullable*/, int relu, void* y, void* stream);
+
 /* ---- BatchNorm2d (training) + ReLU + residual on NHWC, x viewed as [P=N*H*W][C] ---------
  * Replaces aten::batch_norm/relu_/add_ (+backward) of torchvision's Bottleneck
  * (visual_backbones.py:68-74): y = act(gamma*(x-mean)*rstd + beta (+ residual)), running

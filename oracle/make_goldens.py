@@ -10,7 +10,9 @@ the seeded synthetic batch and record
 * loss and both loss components,
 * a strided sample of the forward/backward logits,
 * for every named parameter: gradient L2 norm, sum, and 4 sampled entries,
-* for every BatchNorm buffer after the step: L2 norm (running stats) / value (counter).
+* for every BatchNorm buffer after the step: L2 norm (running stats) / value (counter),
+* (``<case>_eval.json``) the eval-mode forward of the same seeded state: loss, components, argmax
+  predictions and a sample of the backbone features.
 
 The fixtures are what pins the oracle on machines where /root/reference is absent
 (the GPU box): tests/test_oracle.py replays the same seeds through the port.
@@ -86,6 +88,32 @@ def run_case(name, model_kw, batch_kw, use_reference=True):
     return rec
 
 
+def run_eval_case(model_kw, batch_kw, use_reference=True):
+    """Eval-mode forward (running-statistics BatchNorm, no dropout) of the seeded state: what validation
+    (scripts/pretrain_virtex.py validation loop) and the downstream feature extractors see."""
+    oracle_model = synth.seeded_model(port.build_model, seed=0, dropout=0.0, **model_kw)
+    batch = synth.synthetic_batch(**batch_kw)
+    if use_reference:
+        model = reference_import.build_reference_model(dropout=0.0, **model_kw)
+        model.load_state_dict(oracle_model.state_dict())
+    else:
+        model = oracle_model
+    model.eval()
+    captured = {}
+    hook = model.visual.register_forward_hook(lambda m, i, o: captured.__setitem__("features", o))
+    with torch.no_grad():
+        out = model(batch)
+    hook.remove()
+    feats = captured["features"].detach().double()
+    return {
+        "loss": out["loss"].item(),
+        "loss_components": {k: v.item() for k, v in out["loss_components"].items()},
+        "predictions": out["predictions"].tolist(),
+        "features_norm": feats.norm().item(), "features_sum": feats.sum().item(),
+        "features_sample": feats.flatten()[::max(1, feats.numel() // 64)][:64].tolist(),
+    }
+
+
 def main():
     if not reference_import.available():
         sys.exit("needs /root/reference")
@@ -98,6 +126,12 @@ def main():
         with open(path, "w") as f:
             json.dump(rec, f, indent=0)
         print(name, "loss", rec["loss"], "->", path, os.path.getsize(path), "bytes")
+        ev = run_eval_case(mkw, bkw, use_reference=True)
+        ev["meta"] = rec["meta"]
+        path = os.path.join(GOLDEN_DIR, name + "_eval.json")
+        with open(path, "w") as f:
+            json.dump(ev, f, indent=0)
+        print(name, "eval loss", ev["loss"], "->", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

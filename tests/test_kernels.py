@@ -409,3 +409,46 @@ def test_batchnorm_statistics_fused_in_conv_epilogue(backend, case):
     assert torch.allclose(rstd1.cpu(), rstd2.cpu(), rtol=1e-2)
     assert rel_err(out1.float().cpu(), out2.float().cpu()) < 2e-2
     assert torch.allclose(rm1.cpu(), rm2.cpu(), atol=1e-3) and torch.allclose(rv1.cpu(), rv2.cpu(), rtol=1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case,relu,res", [((2, 9, 9, 16, 32, 3, 3, 1, 1), True, False),
+                                           ((3, 8, 8, 64, 256, 1, 1, 1, 0), True, True),
+                                           ((2, 10, 10, 16, 64, 3, 3, 2, 1), True, False),
+                                           ((2, 8, 8, 32, 64, 1, 1, 2, 0), False, False),
+                                           ((1, 20, 20, 8, 64, 7, 7, 2, 3), True, False)])
+def test_conv2d_infer_folded_batchnorm(backend, dtype, case, relu, res):
+    """Eval-mode unit: conv -> BatchNorm(running statistics) -> (+identity) -> ReLU, with the BN folded into the
+    weights/bias (vtx_bn_fold) and the tail fused into the convolution epilogue (vtx_conv2d_infer).
+    Reference semantics: torchvision Bottleneck in eval mode (visual_backbones.py:68-74)."""
+    dev = select(backend)
+    N, H, W, C, KO, R, S, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 7)
+    cin = 3 if R == 7 else C                      # the stem: 3 input channels zero-padded to C=8
+    x = torch.randn(N, H, W, C, generator=g)
+    if cin != C:
+        x[..., cin:] = 0
+    x = x.to(dtype)
+    w32 = torch.randn(KO, R * S, cin, generator=g) / (R * S * cin) ** 0.5
+    gamma = 0.5 + torch.rand(KO, generator=g); beta = 0.2 * torch.randn(KO, generator=g)
+    rm = 0.3 * torch.randn(KO, generator=g); rv = 0.5 + torch.rand(KO, generator=g)
+    eps = 1e-5
+    conv = F.conv2d(x.float()[..., :cin].permute(0, 3, 1, 2), w32.view(KO, R, S, cin).permute(0, 3, 1, 2), stride=stride, padding=pad)
+    ref = F.batch_norm(conv, rm.clone(), rv.clone(), gamma, beta, training=False, eps=eps)
+    r = None
+    if res:
+        r = torch.randn(ref.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dtype)
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    if relu:
+        ref = ref.relu()
+    w, bias = ops.bn_fold(w32.to(dev), gamma.to(dev), beta.to(dev), rm.to(dev), rv.to(dev), eps, dtype, cpad=C)
+    assert w.shape == (KO, R * S, C) and bias.shape == (KO,)
+    sc = gamma / torch.sqrt(rv + eps)
+    assert rel_err(bias.cpu(), beta - rm * sc) < 1e-5
+    y = ops.conv2d_infer(x.to(dev), w.view(KO, R, S, C), bias, stride, pad, relu=relu,
+                         residual=r.to(dev) if res else None)
+    e = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(y.float().cpu(), ref.permute(0, 2, 3, 1)) < e
+    if relu:
+        assert (y.float() >= 0).all()

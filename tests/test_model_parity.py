@@ -95,6 +95,104 @@ def _check(case, dev, dtype, text_tol, loss_tol, cnn_factor, cnn_floor):
     assert model.textual.embedding.words.weight.grad[0].abs().sum().item() > 0
 
 
+def _check_eval(case, dev, dtype, feat_tol, loss_tol):
+    """Eval mode (SURVEY.md 8f row f3): BatchNorm on running statistics, folded into the convolutions;
+    the model returns loss, components and argmax predictions like the reference's validation pass
+    (captioning.py:99-143).  Compared with the oracle and with the reference's own eval goldens."""
+    oracle_model, model, batch = _build_pair(case, dev, dtype)
+    oracle_model.eval(), model.eval()
+    feats = {}
+    h1 = oracle_model.visual.register_forward_hook(lambda m, i, o: feats.__setitem__("oracle", o))
+    h2 = model.visual.register_forward_hook(lambda m, i, o: feats.__setitem__("ours", o))
+    with torch.no_grad():
+        oo = oracle_model(batch)
+        out = model({k: v.to(dev) for k, v in batch.items()})
+    h1.remove(), h2.remove()
+    assert feats["ours"].shape == feats["oracle"].shape
+    assert rel_err(feats["ours"].float().cpu(), feats["oracle"]) < feat_tol
+    with open(os.path.join(GOLDEN, case + "_eval.json")) as f:
+        gold = json.load(f)
+    assert abs(out["loss"].item() - oo["loss"].item()) < loss_tol * abs(oo["loss"].item())
+    assert abs(out["loss"].item() - gold["loss"]) < loss_tol * abs(gold["loss"])
+    for k in ("captioning_forward", "captioning_backward"):
+        assert abs(out["loss_components"][k].item() - gold["loss_components"][k]) < loss_tol * 12
+    assert abs(feats["ours"].double().norm().item() - gold["features_norm"]) < feat_tol * gold["features_norm"]
+    pred, gpred = out["predictions"].cpu(), torch.tensor(gold["predictions"])
+    assert pred.shape == gpred.shape
+    agree = (pred == gpred).float().mean().item()
+    assert agree >= (0.999 if dtype == torch.float32 else 0.5), agree   # fp32: argmax ties only; bf16 on a random-init model (near-uniform logits) flips close calls
+    # running statistics untouched by an eval pass
+    for (n, b), (_, c) in zip(model.named_buffers(), oracle_model.named_buffers()):
+        assert torch.equal(b.cpu(), c), n
+    # a second call reuses the cached folded weights and gives the same answer
+    with torch.no_grad():
+        again = model({k: v.to(dev) for k, v in batch.items()})
+    assert again["loss"].item() == out["loss"].item()
+    # ... until a weight changes in place
+    with torch.no_grad():
+        model.visual.cnn.bn1.running_mean.add_(0.5)
+        changed = model({k: v.to(dev) for k, v in batch.items()})
+    assert changed["loss"].item() != out["loss"].item()
+
+
+@pytest.mark.emu
+def test_small_model_eval_fp32_emulator():
+    _check_eval("r50_l2_h128_b3_small", select("emu"), torch.float32, feat_tol=1e-4, loss_tol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["r50_l2_h128_b3_small", "r50_l1_h1024_b2_full", "r50_l1_h1024_b2_ragged"])
+def test_model_eval_fp32_gpu(case):
+    _check_eval(case, select("gpu"), torch.float32, feat_tol=1e-4, loss_tol=1e-5)
+
+
+@pytest.mark.gpu
+def test_model_eval_bf16_gpu():
+    _check_eval("r50_l1_h1024_b2_full", select("gpu"), torch.bfloat16, feat_tol=3e-2, loss_tol=5e-3)
+
+
+def _check_frozen(case, dev, dtype, text_tol, loss_tol):
+    """VISUAL.FROZEN semantics (visual_backbones.py:49-53): backbone parameters do not require grad and the
+    CNN sits in eval mode while the text heads train on top of it."""
+    oracle_model, model, batch = _build_pair(case, dev, dtype)
+    for m in (oracle_model, model):
+        m.train()
+        for p in m.visual.cnn.parameters():
+            p.requires_grad = False
+        m.visual.cnn.eval()
+    oo = oracle_model(batch)
+    oo["loss"].backward()
+    out = model({k: v.to(dev) for k, v in batch.items()})
+    out["loss"].backward()
+    assert abs(out["loss"].item() - oo["loss"].item()) < loss_tol * abs(oo["loss"].item())
+    for (n, p), (_, q) in zip(model.named_parameters(), oracle_model.named_parameters()):
+        if "cnn" in n:
+            assert p.grad is None and q.grad is None, n
+        else:
+            assert rel_err(p.grad.cpu(), q.grad) < text_tol, n
+    for (n, b), (_, c) in zip(model.named_buffers(), oracle_model.named_buffers()):
+        assert torch.equal(b.cpu(), c), n      # eval-mode BN: running statistics untouched
+
+
+@pytest.mark.emu
+def test_small_model_frozen_backbone_fp32_emulator():
+    _check_frozen("r50_l2_h128_b3_small", select("emu"), torch.float32, text_tol=1e-3, loss_tol=1e-5)
+
+
+@pytest.mark.gpu
+def test_model_frozen_backbone_fp32_gpu():
+    _check_frozen("r50_l1_h1024_b2_ragged", select("gpu"), torch.float32, text_tol=1e-3, loss_tol=1e-5)
+
+
+@pytest.mark.emu
+def test_small_model_eval_requires_no_grad_or_frozen():
+    dev = select("emu")
+    _, model, batch = _build_pair("r50_l2_h128_b3_small", dev, torch.float32)
+    model.eval()
+    with pytest.raises(RuntimeError, match="eval-mode backbone"):
+        model({k: v.to(dev) for k, v in batch.items()})
+
+
 @pytest.mark.emu
 def test_small_model_fp32_emulator():
     dev = select("emu")

@@ -40,6 +40,20 @@ def test_port_reproduces_reference_goldens(case):
         assert rec["buffers"][name] == pytest.approx(b, rel=1e-5), name
 
 
+@pytest.mark.parametrize("case", sorted(make_goldens.CASES))
+def test_port_reproduces_reference_eval_goldens(case):
+    """Eval mode (running-statistics BatchNorm, argmax predictions) of the port vs the verbatim reference."""
+    gold = _load(case + "_eval")
+    mkw, bkw = make_goldens.CASES[case]
+    rec = make_goldens.run_eval_case(mkw, bkw, use_reference=False)
+    assert rec["loss"] == pytest.approx(gold["loss"], rel=1e-6)
+    for k, v in gold["loss_components"].items():
+        assert rec["loss_components"][k] == pytest.approx(v, rel=1e-6)
+    assert rec["predictions"] == gold["predictions"]
+    assert rec["features_norm"] == pytest.approx(gold["features_norm"], rel=1e-6)
+    assert torch.allclose(torch.tensor(rec["features_sample"]), torch.tensor(gold["features_sample"]), rtol=1e-5, atol=1e-6)
+
+
 def test_state_dict_layout_matches_survey():
     m = port.build_model(dropout=0.0)
     assert len(m.state_dict()) == 370

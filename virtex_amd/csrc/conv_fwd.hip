@@ -8,18 +8,18 @@
 using namespace vtxg;
 
 template <class T>
-static int conv_fwd_t(const ConvGeo& g, const void* x, const void* w, void* y, const void* residual,
+static int conv_fwd_t(const ConvGeo& g, const void* x, const void* w, void* y, const float* bias, const void* residual,
                       int act, float* stat_parts, const float* stat_shift, int* stat_strips, hipStream_t st) {
     const int M = g.N * g.OH * g.OW, Kd = g.R * g.S * g.C;
     int strips = 0;
     auto mk_a = [&](auto& a) { a.x = (const T*)x; a.g = g; a.rows = M; a.K = Kd; };
     auto mk_b = [&](auto& b) { b.p = (const T*)w; b.ld = Kd; b.rows = g.KO; b.K = Kd; };
     if (stat_parts && sizeof(T) == 2) {
-        EpiStore<T, true> ep{(T*)y, g.KO, nullptr, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
+        EpiStore<T, true> ep{(T*)y, g.KO, bias, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
         ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
         strips = launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
     } else {
-        EpiStore<T> ep{(T*)y, g.KO, nullptr, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
+        EpiStore<T> ep{(T*)y, g.KO, bias, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
         launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
     }
     if (stat_strips) *stat_strips = strips;
@@ -35,6 +35,37 @@ extern "C" int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int
     int rc = make_geo("conv2d_fwd", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
     if (rc) return rc;
     if (bn_strips) *bn_strips = 0;
-    if (dtype == VTX_BF16) return conv_fwd_t<bf16_t>(g, x, w, y, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
-    return conv_fwd_t<float>(g, x, w, y, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
+    if (dtype == VTX_BF16) return conv_fwd_t<bf16_t>(g, x, w, y, nullptr, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
+    return conv_fwd_t<float>(g, x, w, y, nullptr, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
+}
+
+template <class T>
+static int pointwise_t(int M, int KO, int C, const void* x, const void* w, void* y, const float* bias,
+                       const void* residual, int act, hipStream_t st) {
+    EpiStore<T> ep{(T*)y, KO, bias, (const T*)residual, KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, KO};
+    launch_auto<T, PlainKC, PlainKC>([&](auto& a) { a.p = (const T*)x; a.ld = C; a.rows = M; a.K = C; },
+                                     [&](auto& b) { b.p = (const T*)w; b.ld = C; b.rows = KO; b.K = C; }, ep, M, KO, C, 1, st);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+// Inference convolution with the (folded) BatchNorm, the residual add and the ReLU in the epilogue:
+//   y = act(conv(x, w) + bias[ko] (+ residual)),  relu: 0 none, 1 ReLU.
+// w/bias come from vtx_bn_fold.  This is the eval-mode / frozen backbone (reference: `frozen=True` puts
+// the CNN in eval mode, visual_backbones.py:49-53; downstream feature extraction scripts/clf_voc07.py:165-200).
+extern "C" int vtx_conv2d_infer(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride,
+                                int pad, const void* x, const void* w, const float* bias, const void* residual,
+                                int relu, void* y, void* stream) {
+    VTX_CHECK(x && w && y, VTX_ERR_ARG, "conv2d_infer: null pointer");
+    ConvGeo g;
+    int rc = make_geo("conv2d_infer", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
+    if (rc) return rc;
+    const int act = relu ? (residual ? ACT_RES_RELU : ACT_RELU) : ACT_NONE;
+    if (R == 1 && S == 1 && stride == 1 && pad == 0) {   // pointwise: a plain [N*H*W][C] x [KO][C]^T GEMM
+        const int M = N * H * W;
+        if (dtype == VTX_BF16) return pointwise_t<bf16_t>(M, KO, C, x, w, y, bias, residual, act, (hipStream_t)stream);
+        return pointwise_t<float>(M, KO, C, x, w, y, bias, residual, act, (hipStream_t)stream);
+    }
+    if (dtype == VTX_BF16) return conv_fwd_t<bf16_t>(g, x, w, y, bias, residual, act, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return conv_fwd_t<float>(g, x, w, y, bias, residual, act, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }

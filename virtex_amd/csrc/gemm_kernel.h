@@ -214,7 +214,7 @@ template <class T, int SL> struct ConvWgradB {
 };
 
 // ------------------------------------------------------------------ epilogues
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RES_RELU = 3 };   // 3: ReLU AFTER the residual add (inference Bottleneck tail)
 
 template <class T> __device__ __forceinline__ void st4(T* p, const float* v);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float* v) {
@@ -258,7 +258,20 @@ template <> __device__ __forceinline__ uint4 add16<float>(uint4 a, uint4 b) {
                       __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w)));
 }
 
+__device__ __forceinline__ uint32_t bf2_relu(uint32_t a) {   // two packed bf16: negative (sign bit) -> +0
+    return ((a & 0x8000u) ? 0u : (a & 0xffffu)) | ((a & 0x80000000u) ? 0u : (a & 0xffff0000u));
+}
+template <class T> __device__ __forceinline__ uint4 relu16(uint4 a);
+template <> __device__ __forceinline__ uint4 relu16<bf16_t>(uint4 a) {
+    return make_uint4(bf2_relu(a.x), bf2_relu(a.y), bf2_relu(a.z), bf2_relu(a.w));
+}
+template <> __device__ __forceinline__ uint4 relu16<float>(uint4 a) {
+    return make_uint4((a.x & 0x80000000u) ? 0u : a.x, (a.y & 0x80000000u) ? 0u : a.y,
+                      (a.z & 0x80000000u) ? 0u : a.z, (a.w & 0x80000000u) ? 0u : a.w);
+}
+
 // out = dropout(act(acc*alpha + bias)) + residual ; optional copy of the pre-activation
+// (act = ACT_RES_RELU: out = relu(acc*alpha + bias + residual))
 template <class T, bool WITH_STATS = false> struct EpiStore {
     static constexpr bool STAGED = true;   // generation-2 kernel: 16-byte stores via a wave-private LDS strip
     static constexpr bool STATS = WITH_STATS;   // compile-time: the statistics code costs ~48 VGPRs
@@ -319,6 +332,7 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
                 w = add16<T>(w, make_uint4(r.x, r.y, 0u, 0u));
             }
         }
+        if (act == ACT_RES_RELU) w = relu16<T>(w);
         if (full) *reinterpret_cast<uint4*>(out + o) = w;
         else *reinterpret_cast<uint2*>(out + o) = make_uint2(w.x, w.y);   // bf16: 4 elements
     }
@@ -347,6 +361,10 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
             float r[4]; ld4<T>(residual + mr * ldr + n, r);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        if (act == ACT_RES_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         st4<T>(out + o, v);
     }

@@ -53,6 +53,26 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
         Elem<T>::st(dst + i, src[i]);
 }
 
+// Inference folding of BatchNorm into the preceding bias-free convolution:
+//   scale[ko] = gamma[ko] * rsqrt(running_var[ko] + eps)
+//   w'[ko][t][c] = w[ko][t][c] * scale[ko]   (cast to dtype, C zero-padded to Cp)
+//   bias[ko]     = beta[ko] - running_mean[ko] * scale[ko]
+template <class T>
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ w32, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                      const float* __restrict__ rvar, float eps, T* __restrict__ w,
+                                                      float* __restrict__ bias, int KO, int Tn, int C, int Cp) {
+    const int ko = blockIdx.x;
+    const float sc = gamma[ko] * rsqrtf(rvar[ko] + eps);
+    if (threadIdx.x == 0) bias[ko] = beta[ko] - rmean[ko] * sc;
+    const int per = Tn * Cp;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        const int t = i / Cp, c = i - t * Cp;
+        const float v = c < C ? w32[((long)ko * Tn + t) * C + c] * sc : 0.f;
+        Elem<T>::st(w + (long)ko * per + i, v);
+    }
+}
+
 static int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -100,6 +120,22 @@ extern "C" int vtx_cast_from_f32(int dtype, const float* src, void* dst, long n,
     else if (dtype == VTX_F32)
         hipLaunchKernelGGL((cast_kernel<float>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, n);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "cast: bad dtype");
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+extern "C" int vtx_bn_fold(int dtype, const float* w32, const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, void* w, float* bias, int KO, int T, int C, int Cp,
+                           void* stream) {
+    VTX_CHECK(w32 && gamma && beta && running_mean && running_var && w && bias, VTX_ERR_ARG, "bn_fold: null pointer");
+    VTX_CHECK(KO > 0 && T > 0 && C > 0 && Cp >= C, VTX_ERR_SHAPE, "bn_fold: bad shape");
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((bn_fold_kernel<bf16_t>), dim3(KO), dim3(256), 0, (hipStream_t)stream, w32, gamma, beta,
+                           running_mean, running_var, eps, (bf16_t*)w, bias, KO, T, C, Cp);
+    else if (dtype == VTX_F32)
+        hipLaunchKernelGGL((bn_fold_kernel<float>), dim3(KO), dim3(256), 0, (hipStream_t)stream, w32, gamma, beta,
+                           running_mean, running_var, eps, (float*)w, bias, KO, T, C, Cp);
+    else VTX_CHECK(false, VTX_ERR_DTYPE, "bn_fold: bad dtype");
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -131,6 +131,23 @@ class TorchvisionVisualBackbone(VisualBackbone):
                 p.requires_grad = False
             self.cnn.eval()
 
+    # -- eval mode: running-statistics BatchNorm folded into the convolutions ----
+    def _forward_eval(self, image, stem, blocks):
+        dt = self.compute_dtype
+
+        def run(u, a, relu, residual=None):
+            w, bias = _folded(u, dt)
+            return ops.conv2d_infer(a, w, bias, u.stride, u.pad, relu=relu, residual=residual)
+
+        with torch.no_grad():
+            a0 = ops.image_to_nhwc(image.float().contiguous(), dt, STEM_CPAD)
+            cur, _ = ops.maxpool_fwd(run(stem, a0, True))
+            for (u1, u2, u3, ud) in blocks:
+                t = run(u2, run(u1, cur, True), True)
+                skip = run(ud, cur, False) if ud is not None else cur
+                cur = run(u3, t, True, residual=skip)
+        return cur.permute(0, 3, 1, 2)  # logical NCHW, physical NHWC
+
     # -- schedule ---------------------------------------------------------------------
     def _units(self):
         c = self.cnn
@@ -148,10 +165,35 @@ class TorchvisionVisualBackbone(VisualBackbone):
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         stem, blocks = self._units()
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
+        # BatchNorm mode follows the BN modules' own flag, exactly like the reference's torchvision tree
+        # (`frozen=True` calls cnn.eval() once in the constructor, visual_backbones.py:49-53; a later
+        # model.train() flips it back -- that quirk is the reference's and is kept).
+        if not self.cnn.training:
+            if torch.is_grad_enabled() and any(p.requires_grad for u in units for p in (u.conv.weight, u.bn.weight, u.bn.bias)):
+                raise RuntimeError("eval-mode backbone with trainable parameters under autograd is not supported: "
+                                   "wrap the call in torch.no_grad() or build the backbone with frozen=True")
+            return self._forward_eval(image, stem, blocks)
         params = []
         for u in units:
             params += [u.conv.weight, u.bn.weight, u.bn.bias]
         return _ResNetFn.apply(image, self, *params)
+
+
+def _folded(u: _Unit, dtype):
+    """Eval mode: (w (KO,R,S,Cp), bias (KO,)) with the running-statistics BatchNorm folded into the
+    convolution; cached on the unit's tensors until any of them is modified in place."""
+    bn = u.bn
+    src = (u.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = (dtype,) + tuple((t.data_ptr(), t._version) for t in src)
+    cache = getattr(u.conv, "_vtx_folded", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    w32 = u.conv.weight.detach().permute(0, 2, 3, 1).contiguous().view(u.cout, u.k * u.k, u.cin)
+    w, bias = ops.bn_fold(w32, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, dtype,
+                          cpad=u.cin_pad)
+    w = w.view(u.cout, u.k, u.k, u.cin_pad)
+    u.conv._vtx_folded = (key, w, bias)
+    return w, bias
 
 
 def _prep_weight(u: _Unit, dtype, need_wt: bool):
@@ -261,7 +303,6 @@ class _ResNetFn(torch.autograd.Function):
         dt = module.compute_dtype
         dev = image.device
         stem, blocks = module._units()
-        train = module.training and not module.frozen
         need_grad = any(p.requires_grad for p in params)
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
         saved: List[_Saved] = []
@@ -271,9 +312,6 @@ class _ResNetFn(torch.autograd.Function):
             bn = u.bn
             # the conv epilogue also produces the batch statistics (taken against the running mean)
             x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean if FUSE_BN_STATS else None)
-            if not train:
-                raise RuntimeError("eval-mode (running-statistics) BatchNorm is not part of the "
-                                   "pretraining hot path yet (SURVEY.md 8f row f3)")
             y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                        bn.num_batches_tracked, eps=bn.eps,
                                        momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,

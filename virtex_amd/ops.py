@@ -285,6 +285,38 @@ def weight_prep(w32, dtype, cpad=None, want_w=True, want_wt=True):
     return w, wt
 
 
+def bn_fold(w32, gamma, beta, running_mean, running_var, eps, dtype, cpad=None):
+    """Eval-mode BatchNorm folded into its convolution: fp32 [KO,T,C] -> (w [KO,T,Cp] in `dtype`, bias [KO] fp32)."""
+    if w32.dim() == 2:
+        w32 = w32.unsqueeze(1)
+    KO, T, C = w32.shape
+    for t, n in ((w32, "w32"), (gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, n, torch.float32)
+    Cp = cpad or C
+    w = torch.empty(KO, T, Cp, dtype=dtype, device=w32.device)
+    bias = torch.empty(KO, dtype=torch.float32, device=w32.device)
+    call("vtx_bn_fold", c_int(dtype_code(dtype)), ptr(w32), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+         c_float(eps), ptr(w), ptr(bias), c_int(KO), c_int(T), c_int(C), c_int(Cp), stream_ptr(w32))
+    return w, bias
+
+
+def conv2d_infer(x, w, bias, stride, pad, relu=False, residual=None):
+    """y = act(conv(x, w) + bias (+ residual)) on NHWC; ReLU (if any) comes after the residual add."""
+    N, H, W, C = x.shape
+    KO, R, S, C2 = w.shape
+    assert C2 == C and w.dtype == x.dtype
+    _chk(x, "x"); _chk(w, "w"); _chk(bias, "bias", torch.float32)
+    OH, OW = _conv_out(H, W, R, S, stride, pad)
+    y = torch.empty(N, OH, OW, KO, dtype=x.dtype, device=x.device)
+    if residual is not None:
+        _chk(residual, "residual", x.dtype)
+        assert residual.shape == y.shape
+    call("vtx_conv2d_infer", c_int(dtype_code(x.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
+         c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(x), ptr(w), ptr(bias), ptr(residual),
+         c_int(1 if relu else 0), ptr(y), stream_ptr(x))
+    return y
+
+
 def cast_from_f32(src, dtype):
     _chk(src, "src", torch.float32)
     out = torch.empty(src.shape, dtype=dtype, device=src.device)
