@@ -78,3 +78,26 @@ def test_from_config_builds_the_reference_default_model():
     model = vf.PretrainingModelFactory.from_config(cfg)
     assert sum(p.numel() for p in model.parameters()) == 69482320
     assert model.textual.mask_future_positions and model.backward_textual.embedding is model.textual.embedding
+
+
+def test_detectron2_backbone_state_dict_names():
+    """Reference: visual_backbones.py:76-120 (substring renames applied in dict order).  The expectation below
+    re-derives the names with the reference's rule so the two implementations are checked against each other."""
+    from virtex_amd.modules import TorchvisionVisualBackbone
+    vb = TorchvisionVisualBackbone("resnet50")
+    d2 = vb.detectron2_backbone_state_dict()
+    assert set(d2) == {"model", "__author__", "matching_heuristics"} and d2["matching_heuristics"] is True
+    rule = [("layer1", "res2"), ("layer2", "res3"), ("layer3", "res4"), ("layer4", "res5"), ("bn1", "conv1.norm"),
+            ("bn2", "conv2.norm"), ("bn3", "conv3.norm"), ("downsample.0", "shortcut"), ("downsample.1", "shortcut.norm")]
+    expect = {}
+    for k, v in vb.cnn.state_dict().items():
+        n = k
+        for a, b in rule:
+            n = n.replace(a, b)
+        expect[n if n.startswith("res") else "stem." + n] = v
+    assert list(d2["model"]) == list(expect)
+    for k in expect:
+        assert d2["model"][k].data_ptr() == expect[k].data_ptr()
+    assert "stem.conv1.weight" in d2["model"] and "stem.conv1.norm.running_var" in d2["model"]
+    assert "res2.0.shortcut.norm.weight" in d2["model"] and "res5.2.conv3.norm.bias" in d2["model"]
+    assert d2["model"]["res3.0.conv2.weight"].shape == (128, 128, 3, 3)

@@ -71,3 +71,64 @@ def test_optimizer_matches_reference_chain(backend, fused):
         opt.step(grad_scale=0.5)
     for (n, p), q in zip(model.named_parameters(), ref_params):
         assert torch.allclose(p.detach().cpu(), q.detach(), rtol=2e-5, atol=1e-6), n
+
+
+def _steps(model, opt, buckets, dev, its):
+    for it in its:
+        buckets.zero()
+        for p, g in zip(model.parameters(), _grads(model, it)):
+            p.grad.add_(g.to(dev))
+        opt.step()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_checkpoint_resume_and_reference_interchange(backend, tmp_path):
+    """state_dict() has torch.optim.SGD's layout -- what the reference's Lookahead.state_dict() returns
+    (lookahead.py:74-86) and CheckpointManager writes (checkpointing.py:112-123).  A run resumed from a
+    checkpoint taken at a Lookahead boundary continues bit-for-bit; the same file loads into a stock
+    torch.optim.SGD built with the reference's grouping, and into the unfused optimizer."""
+    dev = select(backend)
+    torch.manual_seed(1)
+    model_a = _Toy().to(dev)
+    buckets_a = vd.GradientBuckets(model_a, bucket_mb=0.01)
+    opt_a = FusedPretrainOptimizer(model_a, buckets_a, total_steps=40, warmup_steps=4)
+    _steps(model_a, opt_a, buckets_a, dev, range(5))                  # k = 5: slow == fast right now
+    ckpt = tmp_path / "checkpoint_5.pth"
+    torch.save({"model": model_a.state_dict(), "optimizer": opt_a.state_dict(), "iteration": 5}, ckpt)
+
+    loaded = torch.load(ckpt, map_location="cpu")
+    torch.manual_seed(2)
+    model_b = _Toy().to(dev)
+    model_b.load_state_dict(loaded["model"])
+    buckets_b = vd.GradientBuckets(model_b, bucket_mb=0.01)
+    opt_b = FusedPretrainOptimizer(model_b, buckets_b, total_steps=40, warmup_steps=4)
+    opt_b.load_state_dict(loaded["optimizer"])
+    assert opt_b.step_idx == 5 and opt_b.kc == 0
+    _steps(model_a, opt_a, buckets_a, dev, range(5, 12))
+    _steps(model_b, opt_b, buckets_b, dev, range(5, 12))
+    for (n, p), (_, q) in zip(model_a.named_parameters(), model_b.named_parameters()):
+        assert torch.equal(p, q), n
+
+    # the reference side: a stock SGD over the reference's one-group-per-tensor layout accepts the file
+    model_c = _Toy()
+    model_c.load_state_dict(loaded["model"])
+    sgd = torch.optim.SGD(port.param_groups(model_c.named_parameters()), momentum=0.9)
+    sgd.load_state_dict({k: v for k, v in loaded["optimizer"].items() if k in ("state", "param_groups")})
+    for i, p in enumerate(model_c.parameters()):
+        assert torch.equal(sgd.state[p]["momentum_buffer"], loaded["optimizer"]["state"][i]["momentum_buffer"])
+    assert [g["weight_decay"] for g in sgd.param_groups] == [g["weight_decay"] for g in loaded["optimizer"]["param_groups"]]
+    # ... and so does the unfused optimizer; its own state dict round-trips through the fused one
+    opt_c = PretrainOptimizer(model_c, total_steps=40, warmup_steps=4)
+    opt_c.load_state_dict(loaded["optimizer"])
+    assert opt_c.step_idx == 5
+    sd_c = opt_c.state_dict()
+    assert set(sd_c["state"]) == set(loaded["optimizer"]["state"])
+    opt_b.load_state_dict(sd_c)
+
+    # slow-weight evaluation helpers (lookahead.py:104-133)
+    before = [p.detach().clone() for p in model_a.parameters()]
+    opt_a.load_slow_weights()
+    assert any(not torch.equal(p, b) for p, b in zip(model_a.parameters(), before))     # 2 steps past the last sync
+    opt_a.restore_fast_weights()
+    for p, b in zip(model_a.parameters(), before):
+        assert torch.equal(p, b)

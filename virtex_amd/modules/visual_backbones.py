@@ -131,6 +131,36 @@ class TorchvisionVisualBackbone(VisualBackbone):
                 p.requires_grad = False
             self.cnn.eval()
 
+    # -- export ---------------------------------------------------------------------------
+    _D2_STAGE = {"layer1": "res2", "layer2": "res3", "layer3": "res4", "layer4": "res5"}
+
+    def detectron2_backbone_state_dict(self):
+        """`.cnn` state dict under Detectron2's ResNet naming (reference: visual_backbones.py:76-120):
+        layerN -> res(N+1), bnK -> convK.norm, downsample.0/.1 -> shortcut / shortcut.norm, and the stem's
+        conv1/bn1 (plus any other top-level entry) prefixed with ``stem.``.  Tensors are the live ones."""
+        out = {}
+        for key, tensor in self.cnn.state_dict().items():
+            parts = key.split(".")
+            if parts[0] in self._D2_STAGE:
+                parts[0] = self._D2_STAGE[parts[0]]
+            renamed = []
+            i = 0
+            while i < len(parts):
+                tok = parts[i]
+                if tok == "downsample" and i + 1 < len(parts) and parts[i + 1] in ("0", "1"):
+                    renamed.append("shortcut" if parts[i + 1] == "0" else "shortcut.norm")
+                    i += 2
+                    continue
+                if tok in ("bn1", "bn2", "bn3"):
+                    tok = f"conv{tok[2]}.norm"
+                renamed.append(tok)
+                i += 1
+            name = ".".join(renamed)
+            if not name.startswith("res"):
+                name = "stem." + name
+            out[name] = tensor
+        return {"model": out, "__author__": "Karan Desai", "matching_heuristics": True}
+
     # -- eval mode: running-statistics BatchNorm folded into the convolutions (SURVEY.md 8f row f3) ----
     def _forward_eval(self, image, stem, blocks):
         dt = self.compute_dtype

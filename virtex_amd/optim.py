@@ -80,6 +80,48 @@ class PretrainOptimizer:
         self.step_idx += 1
         self._set_lr()
 
+    # -- checkpointing: the layout of torch.optim.SGD.state_dict(), which is what the reference's
+    #    Lookahead.state_dict() returns (virtex/optim/lookahead.py:74-86) and CheckpointManager serialises
+    #    (virtex/utils/checkpointing.py:112-123).  Like the reference, slow weights are NOT saved: loading
+    #    re-seeds them from the current parameters.
+    def state_dict(self):
+        groups = []
+        for i, (g, base) in enumerate(zip(self.sgd.param_groups, self.base_lrs)):
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["initial_lr"] = base
+            d["params"] = [i]
+            groups.append(d)
+        state = {i: {"momentum_buffer": self.sgd.state[p]["momentum_buffer"]}
+                 for i, p in enumerate(self.params) if "momentum_buffer" in self.sgd.state.get(p, {})}
+        return {"state": state, "param_groups": groups,
+                "virtex_amd": {"step": self.step_idx, "k_counter": self.kc}}
+
+    def load_state_dict(self, sd):
+        for i, p in enumerate(self.params):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None and st.get("momentum_buffer") is not None:
+                self.sgd.state[p]["momentum_buffer"] = st["momentum_buffer"].to(p.device, p.dtype).clone()
+        extra = sd.get("virtex_amd", {})
+        self.step_idx = int(extra.get("step", self.step_idx))
+        self.kc = int(extra.get("k_counter", 0))
+        with torch.no_grad():
+            for s_, p in zip(self.slow, self.params):
+                s_.copy_(p.data)
+        self._set_lr()
+
+    def load_slow_weights(self):
+        """Evaluate on the slow weights (lookahead.py:104-118); undo with restore_fast_weights()."""
+        self._backup = [p.detach().clone() for p in self.params]
+        with torch.no_grad():
+            for p, s_ in zip(self.params, self.slow):
+                p.data.copy_(s_)
+
+    def restore_fast_weights(self):
+        with torch.no_grad():
+            for p, b in zip(self.params, self._backup):
+                p.data.copy_(b)
+        del self._backup
+
 
 class FusedPretrainOptimizer:
     """Same arithmetic as `PretrainOptimizer`, executed by two HIP kernels over flat buffers
@@ -153,3 +195,52 @@ class FusedPretrainOptimizer:
                                     self.chunk_seg, self.seg_lr, self.seg_wd, mult, self.momentum, grad_scale,
                                     self.sumsq, self.clip_norm, look, self.alpha)
         self.step_idx += 1
+
+    # -- checkpointing: same torch.optim.SGD layout as PretrainOptimizer.state_dict() (momentum buffers are
+    #    views of the flat buffer in each parameter's logical shape), so checkpoints move freely between
+    #    the reference's Lookahead(SGD), PretrainOptimizer and this class.
+    def _views(self, flat):
+        out, off = [], 0
+        for p in self.buckets.params:
+            n = p.numel()
+            slot = flat[off: off + n]
+            if p.dim() == 4 and p.stride(1) == 1 and p.shape[1] > 1:
+                O, I, R, S = p.shape
+                out.append(slot.view(O, R, S, I).permute(0, 3, 1, 2))
+            else:
+                out.append(slot.view(p.shape))
+            off += n
+        return out
+
+    def state_dict(self):
+        mult = lr_multiplier(self.step_idx, self.total_steps, self.warmup_steps)
+        lrs, wds = self.seg_lr.tolist(), self.seg_wd.tolist()
+        groups = [{"lr": lr * mult, "momentum": self.momentum, "dampening": 0, "weight_decay": wd, "nesterov": False,
+                   "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                   "initial_lr": lr, "params": [i]} for i, (lr, wd) in enumerate(zip(lrs, wds))]
+        state = {i: {"momentum_buffer": m} for i, m in enumerate(self._views(self.flat_m))}
+        return {"state": state, "param_groups": groups,
+                "virtex_amd": {"step": self.step_idx, "k_counter": self.kc}}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        for i, view in enumerate(self._views(self.flat_m)):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None and st.get("momentum_buffer") is not None:
+                view.copy_(st["momentum_buffer"])
+            else:
+                view.zero_()
+        extra = sd.get("virtex_amd", {})
+        self.step_idx = int(extra.get("step", self.step_idx))
+        self.kc = int(extra.get("k_counter", 0))
+        self.flat_slow.copy_(self.flat_p)        # reference semantics: slow weights restart from the loaded ones
+
+    @torch.no_grad()
+    def load_slow_weights(self):
+        self._backup = self.flat_p.clone()
+        self.flat_p.copy_(self.flat_slow)
+
+    @torch.no_grad()
+    def restore_fast_weights(self):
+        self.flat_p.copy_(self._backup)
+        del self._backup
