@@ -11,8 +11,9 @@ Workload at N=1 = BASELINE.json configs[1]: bf16 compute, 256 images per GPU.  F
 driver launches this file under torch.distributed.run, one rank per GPU (weak scaling).
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  "roofline"     : the dominant kernel (the MFMA contraction kernel on its heaviest conv shape),
-                   algorithmic FLOPs / HIP-event time measured here, against the dense bf16 peak
+  "roofline"     : the step's dominant kernel (the contraction-kernel instantiation with the largest summed
+                   time), algorithmic FLOPs and bytes / HIP-event time per launch measured live on the launch
+                   streams (vtx_profile_start/stop), against the dense bf16 MFMA peak and the HBM peak
   "step_mfma"    : whole-step algorithmic FLOP/s (35.17 GFLOP/img) against the same peak
   "cpu_baseline" : the oracle port of the reference step timed on this box's host cores.
 """
@@ -44,8 +45,10 @@ def parse():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--roofline-only", action="store_true",
-                    help="run only the dominant-kernel measurement (the command profiles/ traces with rocprofv3)")
+    ap.add_argument("--roofline-steps", type=int, default=3,
+                    help="steps run with per-launch HIP events (after the timed region) for the roofline object")
+    ap.add_argument("--roofline-live", action="store_true",
+                    help="take the per-launch events inside the timed region itself (adds the event overhead to `value`)")
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -57,38 +60,58 @@ def device_batch(B, dev, seed):
     return synthetic_batch(B, dev, image_size=224, max_len=30, vocab_size=10000, seed=seed)
 
 
-def kernel_roofline(dtype):
-    """Time the dominant kernel alone with HIP events on the launch stream (= torch's current
-    stream, which every C-ABI call is enqueued on)."""
-    from virtex_amd import ops
+PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
+# HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: see profiles/ (r01_pmc_*).
+TRAFFIC_PER_LAUNCH = {}
 
-    dt = torch.bfloat16 if dtype == "bf16" else torch.float32
-    # heaviest conv shape of ResNet-50 at B=256: 3x3 stride-1 64->64 @56x56 (3 instances fwd, each
-    # 115.6 MMAC/img; SURVEY.md B.2) -> implicit GEMM M=802816, N=64, K=576
-    N, H, W, C, KO = 256, 56, 56, 64, 64
-    x = torch.randn(N, H, W, C, device="cuda").to(dt)
-    w = (torch.randn(KO, 3, 3, C, device="cuda") / 24).to(dt)
-    for _ in range(3):
-        ops.conv2d_fwd(x, w, 1, 1)
-    torch.cuda.synchronize()
-    iters = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.conv2d_fwd(x, w, 1, 1)
-    e1.record()
-    torch.cuda.synchronize()
-    dur = e0.elapsed_time(e1) / iters * 1e-3
-    flops = 2.0 * N * H * W * KO * 9 * C
-    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
-    return {"bound": "mfma", "kernel": "contraction_kernel<ConvFwdA,PlainKC> conv3x3 s1 64->64 @56x56 B=256",
-            "achieved": round(flops / dur / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(flops / dur / 1e12 / peak, 4),
-            # HBM bytes per launch from separate rocprofv3 PMC passes of `bench.py --roofline-only`
-            # (FETCH_SIZE doubled per the gfx950 guide + WRITE_SIZE): profiles/r01_roofline_kernel_conv3x3_56.txt
-            "traffic": 2.97e8 if dtype == "bf16" else None, "traffic_unit": "bytes/launch",
-            "algorithmic_bytes": 2.056e8 if dtype == "bf16" else 4.11e8,
-            "avg_launch_us": round(dur * 1e6, 1), "flops_per_launch": flops}
+
+def _kernel_name(bracket):
+    """'[BM = 256, ..., AL = vtxg::PlainKC<unsigned short, 2>, ...]' -> the name rocprofv3 prints."""
+    body = bracket.strip()[1:-1] if bracket.startswith("[") else bracket
+    parts, depth, cur = [], 0, ""
+    for ch in body:
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur); cur = ""
+        else:
+            cur += ch
+    parts.append(cur)
+    vals = [p.split("=", 1)[1].strip() if "=" in p else p.strip() for p in parts]
+    name = ", ".join(vals).replace("vtxg::", "").replace("unsigned short", "bf16")
+    return f"contraction_v2_kernel<{name}>"
+
+
+def step_roofline(recs, dtype, default_workload):
+    """Roofline of the step's dominant kernel, measured LIVE: HIP events on the launch stream around every
+    contraction-kernel launch of the step function the timed region runs (`recs` = ops.profile_stop()).  The dominant
+    class is the kernel instantiation with the largest summed time; achieved = its algorithmic FLOPs (or bytes)
+    / its summed launch time; the binding roof is whichever fraction is larger."""
+    if not recs:
+        return None
+    total = sum(r["seconds"] for r in recs)
+    dom = max(recs, key=lambda r: r["seconds"])
+    peak_tf = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    tf = dom["flops"] / dom["seconds"] / 1e12
+    tbs = dom["bytes"] / dom["seconds"] / 1e12
+    f_mfma, f_hbm = tf / peak_tf, tbs / PEAK_HBM_TBS
+    name = _kernel_name(dom["name"])
+    bound = "mfma" if f_mfma >= f_hbm else "hbm"
+    out = {"bound": bound, "kernel": name,
+           "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": peak_tf if bound == "mfma" else PEAK_HBM_TBS * 1e3,
+           "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(max(f_mfma, f_hbm), 4),
+           "traffic": TRAFFIC_PER_LAUNCH.get(name) if default_workload else None, "traffic_unit": "bytes/launch",
+           "launches": dom["launches"], "avg_launch_us": round(dom["seconds"] / dom["launches"] * 1e6, 1),
+           "flops_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes": dom["bytes"] / dom["launches"],
+           "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
+           "share_of_contraction_time": round(dom["seconds"] / total, 3),
+           "all_contractions": {"tflops": round(sum(r["flops"] for r in recs) / total / 1e12, 1),
+                                "hbm_gbs": round(sum(r["bytes"] for r in recs) / total / 1e9, 1),
+                                "kernel_classes": len(recs), "launches": sum(r["launches"] for r in recs)}}
+    return out
 
 
 def cpu_baseline(batch, steps, budget_s=40.0):
@@ -131,10 +154,6 @@ def cpu_baseline(batch, steps, budget_s=40.0):
 
 def main():
     a = parse()
-    if a.roofline_only:
-        torch.cuda.set_device(0)
-        print(json.dumps({"roofline": kernel_roofline(a.dtype)}), flush=True)
-        return
     from virtex_amd import distributed as vd
     import virtex_amd.factories as vf
     from virtex_amd.optim import FusedPretrainOptimizer
@@ -174,6 +193,10 @@ def main():
     torch.cuda.synchronize()
     vd.synchronize()
     torch.cuda.synchronize()
+    from virtex_amd import ops
+    live = a.roofline_live and not a.no_roofline and rank == 0
+    if live:
+        ops.profile_start()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(i)
@@ -181,6 +204,9 @@ def main():
     vd.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    live_recs = None
+    if live:
+        live_recs = ops.profile_stop()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -209,7 +235,16 @@ def main():
             rec["step_mfma"] = {"gflop_per_image": gflop, "achieved_tflops": round(tf, 1),
                                 "peak_tflops": peak * world, "frac": round(tf / (peak * world), 4)}
         if not a.no_roofline:
-            rec["roofline"] = kernel_roofline(a.dtype)
+            default_workload = (a.batch, a.dtype, a.textual, a.visual, world) == (256, "bf16", "transdec_postnorm::L1_H1024_A16_F4096", "torchvision::resnet50", 1)
+            if live_recs is not None:
+                rec["roofline"] = step_roofline(live_recs, a.dtype, default_workload)
+                rec["roofline"]["measured"] = "inside the timed region"
+            else:
+                ops.profile_start()
+                for i in range(a.roofline_steps):
+                    step(i)
+                rec["roofline"] = step_roofline(ops.profile_stop(), a.dtype, default_workload)
+                rec["roofline"]["measured"] = f"{a.roofline_steps} further steps right after the timed region"
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps)
         print(json.dumps(rec), flush=True)

@@ -80,6 +80,18 @@ int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, con
                     float* C, long ldc, float alpha, int split_k, float* workspace, long workspace_floats,
                     void* stream);
 
+/* ---- per-launch timing of the contraction kernels (bench.py roofline leg) ----------------
+ * Between vtx_profile_start() and vtx_profile_stop() every contraction-kernel launch is bracketed by two
+ * HIP events on its own stream.  stop() synchronises the device and returns the number of kernel classes
+ * (one per template instantiation launched so far); vtx_profile_get() reads a class: its name (the
+ * instantiation's template arguments, as rocprofv3 prints them), launches, summed seconds, algorithmic
+ * FLOPs (2*M*N*K) and algorithmic bytes (operand tensors + output, each once).  No reference counterpart:
+ * measurement infrastructure. */
+int vtx_profile_start(void);
+int vtx_profile_stop(void);
+int vtx_profile_get(int cls, char* name, int name_len, long* launches, double* seconds, double* flops,
+                    double* bytes);
+
 /* ---- NHWC convolutions (im2col-free implicit GEMM on MFMA; csrc/conv_*.hip) -------------
  * Replace aten::convolution / convolution_backward of the torchvision ResNet reached from
  * virtex/modules/visual_backbones.py:68-74.  x:[N][H][W][C], y/dy:[N][OH][OW][KO] (dtype),

@@ -211,6 +211,17 @@ inline hipemu_f32x16 hipemu_mfma_32x32x2_f32(float a, float b, hipemu_f32x16 c) 
 #define __builtin_amdgcn_wave_barrier() do { int z_ = 0; (void)hipemu::wave_exchange(&z_, sizeof(z_)); } while (0)
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+// events: the emulator runs launches synchronously, so an event is just a host timestamp
+#include <chrono>
+struct hipemuEvent { double t; };
+typedef hipemuEvent* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{0.0}; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    e->t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    return hipSuccess;
+}
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_nontemporal_load(p) (*(p))

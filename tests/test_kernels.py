@@ -452,3 +452,33 @@ def test_conv2d_infer_folded_batchnorm(backend, dtype, case, relu, res):
     assert rel_err(y.float().cpu(), ref.permute(0, 2, 3, 1)) < e
     if relu:
         assert (y.float() >= 0).all()
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_contraction_profiler_counts_launches_flops_bytes(backend):
+    """vtx_profile_start/stop: one class per kernel instantiation; algorithmic FLOPs 2*M*N*K and bytes
+    (operands + output once) summed over the launches made while profiling is on."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(300, 64, generator=g).to(torch.bfloat16).to(dev)
+    b = torch.randn(128, 64, generator=g).to(torch.bfloat16).to(dev)
+    ops.gemm_nt(a, b)                         # not profiled
+    ops.profile_start()
+    ops.gemm_nt(a, b)
+    ops.gemm_nt(a, b)
+    x = torch.randn(2, 9, 9, 16, generator=g).to(torch.bfloat16).to(dev)
+    w = torch.randn(32, 3, 3, 16, generator=g).to(torch.bfloat16).to(dev)
+    ops.conv2d_fwd(x, w, 1, 1)
+    rec = ops.profile_stop()
+    ops.gemm_nt(a, b)                         # not profiled either
+    assert len(rec) == 2 and sum(r["launches"] for r in rec) == 3
+    gm = [r for r in rec if "ConvFwdA" not in r["name"]][0]
+    cv = [r for r in rec if "ConvFwdA" in r["name"]][0]
+    assert "PlainKC" in gm["name"] and gm["launches"] == 2
+    assert gm["flops"] == 2 * (2.0 * 300 * 128 * 64)
+    assert gm["bytes"] == 2 * 2.0 * (300 * 64 + 128 * 64 + 300 * 128)
+    assert cv["flops"] == 2.0 * (2 * 9 * 9) * 32 * (9 * 16)
+    assert cv["bytes"] == 2.0 * (2 * 9 * 9 * 16 + 32 * 144 + 2 * 9 * 9 * 32)
+    assert gm["seconds"] > 0 and cv["seconds"] > 0
+    ops.profile_start()
+    assert ops.profile_stop() == []           # start resets the counters

@@ -1,6 +1,11 @@
 // Version / backend / error reporting of the C ABI.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
 
 #include "vtx_common.h"
 
@@ -33,3 +38,84 @@ extern "C" int vtx_set_contraction_generation(int gen) {
 extern "C" int vtx_set_ablation(int bits) { vtxg::g_vtx_ablate = bits; return VTX_OK; }
 // tests: force tile candidate 0..5 = 256x256, 256x128, 128x128, 128x64, 64x128, 64x64 (-1: automatic)
 extern "C" int vtx_set_tile_override(int c) { vtxg::g_vtx_tile_override = c; return VTX_OK; }
+
+// ---------------------------------------------------------------------------------------
+// Per-launch timing of the contraction kernels (bench.py's roofline leg): while profiling is on, every
+// launch is bracketed by two HIP events ON ITS OWN STREAM; vtx_profile_stop synchronises the device and
+// sums launches / seconds / algorithmic FLOPs / algorithmic bytes per kernel instantiation.
+// ---------------------------------------------------------------------------------------
+namespace vtxg {
+int g_vtx_prof_on = 0;
+namespace {
+struct ProfClass { std::string name; long launches = 0; double seconds = 0, flops = 0, bytes = 0; };
+struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
+std::mutex g_prof_mu;
+std::vector<ProfClass> g_prof_classes;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+thread_local int t_prof_open = -1;     // index of the record opened by this thread's last begin()
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+}  // namespace
+int vtx_prof_register(const char* pretty) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    // "... [BM = 256, BN = 128, ..., AL = vtxg::PlainKC<unsigned short, 2>, ...]" -> keep the bracket part
+    const char* br = strchr(pretty, '[');
+    ProfClass c; c.name = br ? br : pretty;
+    g_prof_classes.push_back(c);
+    return (int)g_prof_classes.size() - 1;
+}
+void vtx_prof_begin(int cls, double flops, double bytes, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{prof_event(), prof_event(), cls, flops, bytes};
+    hipEventRecord(r.a, st);
+    g_prof_recs.push_back(r);
+    t_prof_open = (int)g_prof_recs.size() - 1;
+}
+void vtx_prof_end(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (t_prof_open >= 0 && t_prof_open < (int)g_prof_recs.size()) hipEventRecord(g_prof_recs[t_prof_open].b, st);
+    t_prof_open = -1;
+}
+}  // namespace vtxg
+
+extern "C" int vtx_profile_start(void) {
+    using namespace vtxg;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& c : g_prof_classes) { c.launches = 0; c.seconds = c.flops = c.bytes = 0; }
+    for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b); }
+    g_prof_recs.clear();
+    g_vtx_prof_on = 1;
+    return VTX_OK;
+}
+extern "C" int vtx_profile_stop(void) {
+    using namespace vtxg;
+    g_vtx_prof_on = 0;
+    VTX_CHECK(hipDeviceSynchronize() == hipSuccess, VTX_ERR_LAUNCH, "profile_stop: device synchronize failed");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ProfClass& c = g_prof_classes[r.cls];
+            c.launches += 1; c.seconds += ms * 1e-3; c.flops += r.flops; c.bytes += r.bytes;
+        }
+        g_prof_pool.push_back(r.a); g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    return (int)g_prof_classes.size();
+}
+extern "C" int vtx_profile_get(int cls, char* name, int name_len, long* launches, double* seconds, double* flops,
+                               double* bytes) {
+    using namespace vtxg;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    VTX_CHECK(cls >= 0 && cls < (int)g_prof_classes.size(), VTX_ERR_ARG, "profile_get: no class %d", cls);
+    const ProfClass& c = g_prof_classes[cls];
+    if (name && name_len > 0) { strncpy(name, c.name.c_str(), name_len - 1); name[name_len - 1] = 0; }
+    if (launches) *launches = c.launches;
+    if (seconds) *seconds = c.seconds;
+    if (flops) *flops = c.flops;
+    if (bytes) *bytes = c.bytes;
+    return VTX_OK;
+}

@@ -437,3 +437,29 @@ def sgd_lookahead_step(p, g, m, slow, chunk_off, chunk_len, chunk_seg, seg_lr, s
          ptr(chunk_seg), c_int(chunk_off.numel()), ptr(seg_lr), ptr(seg_wd), c_float(lr_mult), c_float(momentum),
          c_float(grad_scale), ptr(sumsq_buf), c_float(max_norm if max_norm else 0.0),
          c_int(1 if do_lookahead else 0), c_float(alpha), stream_ptr(p))
+
+
+# ---------------------------------------------------------------------------------------
+# per-launch timing of the contraction kernels (bench.py's roofline leg)
+def profile_start():
+    call("vtx_profile_start")
+
+
+def profile_stop():
+    """-> list of {"name", "launches", "seconds", "flops", "bytes"} for every kernel class that was launched."""
+    ctypes = _lib.ctypes
+    lib = _lib.lib()
+    n = lib.vtx_profile_stop()
+    if n < 0:
+        raise _lib.VtxError(lib.vtx_last_error().decode())
+    out = []
+    for i in range(n):
+        name = ctypes.create_string_buffer(512)
+        launches = ctypes.c_long(0)
+        sec, fl, by = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        call("vtx_profile_get", c_int(i), name, c_int(512), ctypes.byref(launches), ctypes.byref(sec),
+             ctypes.byref(fl), ctypes.byref(by))
+        if launches.value:
+            out.append({"name": name.value.decode(), "launches": launches.value, "seconds": sec.value,
+                        "flops": fl.value, "bytes": by.value})
+    return out
