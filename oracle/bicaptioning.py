@@ -218,6 +218,13 @@ class BicaptioningModel(nn.Module):
         feats = self.visual(batch["image"])
         V = self.textual.vocab_size
         out = {}
+        if "caption_tokens" not in batch:
+            # inference branch (captioning.py:144-162): decode with the forward head
+            if self.decoder is None:
+                raise ValueError("Decoder for predicting captions is missing!")
+            start = feats.new_full((feats.size(0),), self.sos_index).long()
+            tokens, _ = self.decoder.search(start, lambda partial: self.decoding_step(feats, partial))
+            return {"predictions": tokens}
         losses = {}
         for key, head, toks in (("captioning_forward", self.textual, batch["caption_tokens"]),
                                 ("captioning_backward", self.backward_textual, batch["noitpac_tokens"])):
@@ -233,6 +240,21 @@ class BicaptioningModel(nn.Module):
         if not self.training:
             out["predictions"] = torch.argmax(out["logits"], dim=-1)
         return out
+
+
+    def decoding_step(self, feats, partial):
+        """Next-token logits for (beam-expanded) prefixes: the whole prefix is re-run, lengths = current
+        prefix length regardless of EOS/padding inside it (captioning.py:165-213)."""
+        n, c, h, w = feats.size()
+        beams = partial.size(0) // n
+        if beams > 1:
+            feats = feats.unsqueeze(1).expand(n, beams, c, h, w).reshape(n * beams, c, h, w)
+        if partial.dim() == 1:
+            lengths = torch.ones_like(partial)
+            partial = partial.unsqueeze(1)
+        else:
+            lengths = torch.full((partial.size(0),), partial.size(1), dtype=partial.dtype, device=partial.device)
+        return self.textual(feats, partial, lengths)[:, -1, :]
 
 
 # ---------------------------------------------------------------------------------

@@ -61,12 +61,14 @@ def test_factories_mirror_reference_semantics_and_register():
     fake = types.SimpleNamespace(
         VisualBackboneFactory=type("VisualBackboneFactory", (), {"PRODUCTS": {"torchvision": object}}),
         TextualHeadFactory=type("TextualHeadFactory", (), {"PRODUCTS": {"transdec_prenorm": object, "none": object}}),
-        PretrainingModelFactory=type("PretrainingModelFactory", (), {"PRODUCTS": {"masked_lm": object}}))
+        PretrainingModelFactory=type("PretrainingModelFactory", (), {"PRODUCTS": {"masked_lm": object}}),
+        CaptionDecoderFactory=type("CaptionDecoderFactory", (), {"PRODUCTS": {"beam_search": object, "nucleus_sampling": object}}))
     replaced = vf.register(fake)
     assert fake.VisualBackboneFactory.PRODUCTS["torchvision"] is vf.VisualBackboneFactory.PRODUCTS["torchvision"]
     assert "transdec_postnorm" in fake.TextualHeadFactory.PRODUCTS and "none" in fake.TextualHeadFactory.PRODUCTS
     assert set(fake.PretrainingModelFactory.PRODUCTS) == {"masked_lm", "virtex", "bicaptioning", "captioning"}
-    assert len(replaced) == 5
+    assert fake.CaptionDecoderFactory.PRODUCTS["beam_search"] is vf.decoding.AutoRegressiveBeamSearch
+    assert len(replaced) == 7
 
 
 def test_from_config_builds_the_reference_default_model():
@@ -75,7 +77,11 @@ def test_from_config_builds_the_reference_default_model():
                                                FROZEN=False),
                       TEXTUAL=ns(NAME="transdec_postnorm::L1_H1024_A16_F4096", DROPOUT=0.1)),
              DATA=ns(VOCAB_SIZE=10000, MAX_CAPTION_LENGTH=30, UNK_INDEX=0, SOS_INDEX=1, EOS_INDEX=2))
+    cfg.MODEL.DECODER = ns(NAME="beam_search", BEAM_SIZE=5, NUCLEUS_SIZE=0.9, MAX_DECODING_STEPS=50)   # config.py defaults
     model = vf.PretrainingModelFactory.from_config(cfg)
+    assert isinstance(model.decoder, vf.decoding.AutoRegressiveBeamSearch) and model.decoder.beam_size == 5
+    cfg.MODEL.DECODER.NAME = "nucleus_sampling"
+    assert vf.CaptionDecoderFactory.from_config(cfg).nucleus_size == 0.9
     assert sum(p.numel() for p in model.parameters()) == 69482320
     assert model.textual.mask_future_positions and model.backward_textual.embedding is model.textual.embedding
 

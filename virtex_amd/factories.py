@@ -14,7 +14,7 @@ from typing import Any, Callable, Dict, List
 
 import torch
 
-from . import models
+from . import decoding, models
 from .modules import textual_heads, visual_backbones
 
 
@@ -81,8 +81,27 @@ class PretrainingModelFactory(Factory):
         _C = config
         visual = VisualBackboneFactory.from_config(_C)
         textual = TextualHeadFactory.from_config(_C)
-        kwargs = {"sos_index": _C.DATA.SOS_INDEX, "eos_index": _C.DATA.EOS_INDEX, "decoder": None}
+        kwargs = {"sos_index": _C.DATA.SOS_INDEX, "eos_index": _C.DATA.EOS_INDEX,
+                  "decoder": CaptionDecoderFactory.from_config(_C)}
         return cls.create(_C.MODEL.NAME, visual, textual, **kwargs)
+
+
+class CaptionDecoderFactory(Factory):
+    """``{"beam_search", "nucleus_sampling"}`` (reference: factories.py:469-500)."""
+    PRODUCTS: Dict[str, Callable] = {
+        "beam_search": decoding.AutoRegressiveBeamSearch,
+        "nucleus_sampling": decoding.AutoRegressiveNucleusSampling,
+    }
+
+    @classmethod
+    def from_config(cls, config):
+        _C = config
+        kwargs = {"eos_index": _C.DATA.EOS_INDEX, "max_steps": _C.MODEL.DECODER.MAX_DECODING_STEPS}
+        if _C.MODEL.DECODER.NAME == "beam_search":
+            kwargs["beam_size"] = _C.MODEL.DECODER.BEAM_SIZE
+        elif _C.MODEL.DECODER.NAME == "nucleus_sampling":
+            kwargs["nucleus_size"] = _C.MODEL.DECODER.NUCLEUS_SIZE
+        return cls.create(_C.MODEL.DECODER.NAME, **kwargs)
 
 
 def parse_textual_architecture(architecture: str) -> Dict[str, int]:
@@ -118,7 +137,8 @@ def register(reference_factories=None) -> List[str]:
     replaced = []
     for ours, theirs in ((VisualBackboneFactory, reference_factories.VisualBackboneFactory),
                          (TextualHeadFactory, reference_factories.TextualHeadFactory),
-                         (PretrainingModelFactory, reference_factories.PretrainingModelFactory)):
+                         (PretrainingModelFactory, reference_factories.PretrainingModelFactory),
+                         (CaptionDecoderFactory, reference_factories.CaptionDecoderFactory)):
         for key, product in ours.PRODUCTS.items():
             theirs.PRODUCTS[key] = product
             replaced.append(f"{theirs.__name__}.{key}")
