@@ -62,8 +62,10 @@ def device_batch(B, dev, seed):
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: see profiles/ (r01_pmc_*).
-TRAFFIC_PER_LAUNCH = {}
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v6.txt.
+TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v6.txt: (2 x 63.82e3 + 86.87e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16>>": 2.197e8,
+}
 
 
 def _kernel_name(bracket):
