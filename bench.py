@@ -64,7 +64,7 @@ PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
 # (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v6.txt.
 TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v6.txt: (2 x 63.82e3 + 86.87e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16>>": 2.197e8,
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false> >": 2.197e8,
 }
 
 
@@ -84,7 +84,9 @@ def _kernel_name(bracket):
     parts.append(cur)
     vals = [p.split("=", 1)[1].strip() if "=" in p else p.strip() for p in parts]
     name = ", ".join(vals).replace("vtxg::", "").replace("unsigned short", "bf16")
-    return f"contraction_v2_kernel<{name}>"
+    # __PRETTY_FUNCTION__ drops defaulted template arguments; rocprofv3 prints them
+    name = name.replace("EpiStore<bf16>", "EpiStore<bf16, false>").replace("EpiStore<float>", "EpiStore<float, false>")
+    return f"contraction_v2_kernel<{name} >"
 
 
 def step_roofline(recs, dtype, default_workload):
