@@ -340,10 +340,11 @@ def test_small_helpers(backend, dtype):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5, 11, 12])
 def test_contraction_tile_variants_bf16(backend, cand):
-    """Every block-tile configuration of the generation-2 bf16 kernel (256x256 ... 64x64), on all
-    loader kinds: row-major, k-major (transpose-read) and the three conv gathers."""
+    """Every block-tile configuration of the generation-2 bf16 kernel (256x256 ... 64x64; 11, 12: the 64-deep
+    K-step variants for row-major operands), on all loader kinds: row-major, k-major (transpose-read) and the
+    three conv gathers."""
     import ctypes
     from virtex_amd import _lib
     dev = select(backend)
@@ -351,7 +352,7 @@ def test_contraction_tile_variants_bf16(backend, cand):
     g = torch.Generator().manual_seed(cand)
     try:
         _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
-        M, N, K = 300, 520, 96
+        M, N, K = 300, 520, (96 if cand < 10 else 200)      # 200: a 64-deep K step with a ragged tail
         a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
         bias = torch.randn(N, generator=g); res = torch.randn(M, N, generator=g).to(dt)
         out = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), res.to(dev), act=ops.ACT_GELU)

@@ -8,10 +8,14 @@ from bench_layers import CONVS, timeit  # noqa
 
 B, dt = 256, torch.bfloat16
 lib = _lib.lib()
-names = {-1: "auto", 0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x128", 5: "64x64"}
+names = {-1: "auto", 0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x128", 5: "64x64", 11: "256x128k64s2", 12: "128x128k64s2"}
+CANDS = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1, 0, 1, 2, 3, 4, 5]
+ONLY_KC = len(sys.argv) > 2
 def sweep(label, fn, M, N):
+    if ONLY_KC and "wgrad" in label:
+        return
     res = {}
-    for c in (-1, 0, 1, 2, 3, 4, 5):
+    for c in CANDS:
         if c in (0, 1) and M < 256: continue
         if c in (0,) and N <= 128: continue
         if c in (0, 1, 2, 4) and N <= 64 and c != -1: continue

@@ -573,9 +573,16 @@ template <int ROWS> __device__ __forceinline__ int swz_mc(int chunk, int k) {
     else return chunk ^ ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2));
 }
 
-template <int ROWS, int NW, class L> struct DmaStager {
+// 128-byte rows (BK = 64): the eight 16-byte k-slots of a row are XOR-permuted by (row >> 1) & 7 -- every 16-lane
+// group of a ds_read_b128 fragment load (rows r..r+15 at one slot, or two adjacent slots) then covers all 64 banks.
+__device__ __forceinline__ int swz_slot64(int slot, int row) { return slot ^ ((row >> 1) & 7); }
+
+template <int ROWS, int NW, class L, int BK = 32> struct DmaStager {
     static constexpr bool MC = L::MC;
-    static constexpr int NI = ROWS / (16 * NW); // wave-instructions (1 KiB each) per wave per tile
+    static_assert(!MC || BK == 32, "k-major operands are staged 32 k at a time");
+    static constexpr int SLOTS = BK / 8;        // 16-byte k-slots per row (KC image)
+    static constexpr int RPI = 64 / SLOTS;      // rows per wave-instruction (KC image): 16 x 64 B or 8 x 128 B
+    static constexpr int NI = MC ? ROWS / (16 * NW) : ROWS / (RPI * NW);   // wave-instructions (1 KiB each) per wave per tile
     static constexpr int CH = ROWS / 8;         // 16-byte row chunks per k (MC image)
     static constexpr int KPI = 64 / CH > 0 ? 64 / CH : 1;   // k rows per wave-instruction (MC image)
     static_assert(NI >= 1, "tile too small for this many waves");
@@ -587,8 +594,9 @@ template <int ROWS, int NW, class L> struct DmaStager {
         for (int i = 0; i < NI; ++i) {
             const int q = wave + NW * i;        // which 1 KiB piece of the tile image
             if constexpr (!MC) {
-                const int row = 16 * q + (lane >> 2);
-                l.init_slot(st, i, row0 + row, 8 * swz_slot(lane & 3, row));
+                const int row = RPI * q + lane / SLOTS;
+                const int phys = lane % SLOTS;
+                l.init_slot(st, i, row0 + row, 8 * (BK == 32 ? swz_slot(phys, row) : swz_slot64(phys, row)));
             } else if constexpr (CH <= 64) {
                 kl[i] = q * KPI + lane / CH;
                 l.init_slot(st, i, row0 + 8 * swz_mc<ROWS>(lane % CH, kl[i]));
@@ -607,10 +615,14 @@ template <int ROWS, int NW, class L> struct DmaStager {
                                              16, 0, 0);
         }
     }
-    __device__ static __forceinline__ bf16x8_t frag(const bf16_t* tile, int r0, int lane) {
+    // fragment of rows r0..r0+15 for the 32-deep MFMA step `h` of the staged tile (h = 0 when BK = 32)
+    __device__ static __forceinline__ bf16x8_t frag(const bf16_t* tile, int r0, int lane, int h = 0) {
         if constexpr (!MC) {
             const int row = r0 + (lane & 15);
-            return *reinterpret_cast<const bf16x8_t*>(tile + row * 32 + swz_slot(lane >> 4, row) * 8);
+            if constexpr (BK == 32)
+                return *reinterpret_cast<const bf16x8_t*>(tile + row * 32 + swz_slot(lane >> 4, row) * 8);
+            else
+                return *reinterpret_cast<const bf16x8_t*>(tile + row * 64 + swz_slot64(4 * h + (lane >> 4), row) * 8);
         } else {
             const int w = lane & 15, ka = 8 * (lane >> 4) + (w >> 2), rr = r0 + 4 * (w & 3);
             const bf16_t* pa = tile + ka * ROWS + swz_mc<ROWS>(rr >> 3, ka) * 8 + (rr & 7);
@@ -625,14 +637,13 @@ template <int ROWS, int NW, class L> struct DmaStager {
 // Block = WM x WN waves; block tile BM x BN; wave tile (BM/WM) x (BN/WN).  Large tiles matter for the
 // L2 -> LDS bandwidth, not only for LDS: a 128x128 tile needs 2*(128+128)*64 B per 2*128*128*32 flop
 // = 64 flop/B, i.e. 39 TB/s of cache bandwidth at the MFMA peak (L2 delivers ~34); 256x256 needs half.
-template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EP, int BK = 32, int STAGES = 3>
 __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
                                                                       int kt_per_split, int abl) {
-    constexpr int NW = WM * WN, BK = 32, WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
+    constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int TILE = (BM + BN) * BK;       // elements per stage
-    constexpr int STAGES = 3;
-    typedef DmaStager<BM, NW, AL> SA;
-    typedef DmaStager<BN, NW, BL> SB;
+    typedef DmaStager<BM, NW, AL, BK> SA;
+    typedef DmaStager<BN, NW, BL, BK> SB;
     constexpr int NDMA = SA::NI + SB::NI;      // DMA instructions per wave per tile
     HIP_DYNAMIC_SHARED(bf16_t, lds)
 
@@ -664,52 +675,59 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8]); only vmcnt waits
-    constexpr int WAIT_ONE_TILE_LEFT = (NDMA & 0xF) | ((NDMA >> 4) << 14) | (0x7 << 4) | (0xF << 8);
+    constexpr int INFLIGHT = NDMA * (STAGES - 2);       // DMA instructions that may still be pending at a K step
+    static_assert(INFLIGHT < 64, "vmcnt is 6 bits");
+    constexpr int WAIT_TILES_LEFT = (INFLIGHT & 0xF) | ((INFLIGHT >> 4) << 14) | (0x7 << 4) | (0xF << 8);
     constexpr int WAIT_ALL = 0 | (0x7 << 4) | (0xF << 8);
 
-    // Pipeline: three LDS stages, one s_barrier per K step, the DMA of tile kt+2 is issued right after
-    // the barrier of step kt (into the stage tile kt-1 occupied) and has two MFMA phases to land.
+    // Pipeline: STAGES LDS stages, one s_barrier per K step (BK deep = BK/32 MFMA steps), the DMA of tile
+    // kt+STAGES-1 is issued right after the barrier of step kt (into the stage tile kt-1 occupied) and has
+    // STAGES-1 MFMA phases to land.
     if (kt0 < kt1) {
-        sa.issue(al, kt0 * BK, lds, wave);
-        sb.issue(bl, kt0 * BK, lds + BM * BK, wave);
-        if (kt0 + 1 < kt1) {
-            sa.issue(al, (kt0 + 1) * BK, lds + TILE, wave);
-            sb.issue(bl, (kt0 + 1) * BK, lds + TILE + BM * BK, wave);
+#pragma unroll
+        for (int p = 0; p < STAGES - 1; ++p) {
+            if (kt0 + p < kt1) {
+                sa.issue(al, (kt0 + p) * BK, lds + p * TILE, wave);
+                sb.issue(bl, (kt0 + p) * BK, lds + p * TILE + BM * BK, wave);
+            }
         }
         int stage = 0;                          // stage holding tile kt
         for (int kt = kt0; kt < kt1; ++kt) {
             if (!(abl & 8)) {
-                // this wave's pieces of tile kt have landed (tile kt+1 may still be in flight) ...
-                if (kt + 1 < kt1) __builtin_amdgcn_s_waitcnt(WAIT_ONE_TILE_LEFT);
+                // this wave's pieces of tile kt have landed (later tiles may still be in flight) ...
+                if (STAGES > 2 && kt + (STAGES - 2) < kt1) __builtin_amdgcn_s_waitcnt(WAIT_TILES_LEFT);
                 else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
                 // ... and after the barrier so have everybody's; all waves are also done reading the
-                // stage that held tile kt-1, which is the one tile kt+2 is DMA'd into next.
+                // stage that held tile kt-1, which is the one the next DMA goes into.
                 __builtin_amdgcn_s_barrier();
             }
             const bf16_t* cur = lds + stage * TILE;
-            if (kt + 2 < kt1 && !(abl & 4)) {
-                const int s2 = stage + 2 >= STAGES ? stage + 2 - STAGES : stage + 2;
-                sa.issue(al, (kt + 2) * BK, lds + s2 * TILE, wave);
-                sb.issue(bl, (kt + 2) * BK, lds + s2 * TILE + BM * BK, wave);
+            if (kt + (STAGES - 1) < kt1 && !(abl & 4)) {
+                const int s2 = stage + (STAGES - 1) >= STAGES ? stage - 1 : stage + (STAGES - 1);
+                sa.issue(al, (kt + (STAGES - 1)) * BK, lds + s2 * TILE, wave);
+                sb.issue(bl, (kt + (STAGES - 1)) * BK, lds + s2 * TILE + BM * BK, wave);
             }
-            bf16x8_t fa[MT], fb[NT];
-            if (!(abl & 2) || kt == kt0) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i) fa[i] = SA::frag(cur, wm * WTM + i * 16, lane);
+            for (int h = 0; h < BK / 32; ++h) {
+                bf16x8_t fa[MT], fb[NT];
+                if (!(abl & 2) || kt == kt0) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) fb[j] = SB::frag(cur + BM * BK, wn * WTN + j * 16, lane);
-            }
-            if (!(abl & 1)) {
+                    for (int i = 0; i < MT; ++i) fa[i] = SA::frag(cur, wm * WTM + i * 16, lane, h);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int j = 0; j < NT; ++j) fb[j] = SB::frag(cur + BM * BK, wn * WTN + j * 16, lane, h);
+                }
+                if (!(abl & 1)) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            } else {
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                } else {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(fb[j]));
+                    for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(fa[i]));
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) asm volatile("" ::"v"(fb[j]));
+                }
             }
             stage = stage + 1 >= STAGES ? 0 : stage + 1;
         }
@@ -820,17 +838,16 @@ template <class T, bool S> inline double epi_bytes(const EpiStore<T, S>& e, doub
     return mn * sizeof(T) * (split_k > 1 ? split_k : 1) + (e.residual ? mn * sizeof(T) : 0.0) + (e.preact ? mn * sizeof(T) : 0.0);
 }
 
-template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+template <int BM, int BN, int WM, int WN, int BK = 32, int STAGES = 3, class AL, class BL, class EP>
 inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
-    constexpr int BK = 32;
     const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
     const int nkt = vtx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
     if (split_k > nkt) split_k = nkt > 0 ? nkt : 1;
     const int per = vtx_cdiv(nkt, split_k);       // K == 0: no K steps, the epilogue alone runs
     split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
-    constexpr size_t lds_bytes = 3 * (size_t)(BM + BN) * BK * 2;
-    auto kern = contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP>;
+    constexpr size_t lds_bytes = STAGES * (size_t)(BM + BN) * BK * 2;
+    auto kern = contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP, BK, STAGES>;
     static bool attr_set = false;
     if (lds_bytes > 65536 && !attr_set) {
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -890,6 +907,22 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
 #define VTX_V2(BM_, BN_, WM_, WN_, SA_, SB_)                                                \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); strips = launch_v2<BM_, BN_, WM_, WN_>(a, b, ep, M, N, K, split_k, st); }
     int strips = 0;
+#define VTX_V2X(BM_, BN_, WM_, WN_, BK_, ST_, SA_, SB_)                                    \
+    { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); strips = launch_v2<BM_, BN_, WM_, WN_, BK_, ST_>(a, b, ep, M, N, K, split_k, st); }
+    if constexpr (BF && !ALT<T, 1>::MC && !BLT<T, 1>::MC && !EP::STATS) {
+        // Row-major operands, small grids: when 256x128 tiles would not even give every CU one block, LDS
+        // capacity is free, so stage 64-deep K steps -- every LDS-DMA row is a whole 128-byte line (measured
+        // 30 vs 22.6 TB/s L2->LDS, tools/probes/dma_probe.hip) and there are half as many barriers.
+        // tools/sweep_tiles.py: +9...19 % on exactly these shapes (ffn2 fwd, ffn1/in_proj/vocab dgrad, the
+        // 7x7 stage), -10...40 % on larger grids where two co-resident 256x128 blocks overlap instead.
+        const long t256 = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, 128) * (split_k < 1 ? 1 : split_k);
+        const bool small_grid = g_vtx_tile_override < 0 && t256 <= 256 && K >= 256 && N > 64 && M > 128;
+        if (v2 && (small_grid || g_vtx_tile_override >= 10)) {
+            if (g_vtx_tile_override == 11) VTX_V2X(256, 128, 4, 2, 64, 2, 4, 2)     //  96 KiB LDS: one block per CU
+            else VTX_V2X(128, 128, 2, 2, 64, 2, 4, 4)                               //  64 KiB: two blocks per CU
+            return 0;
+        }
+    }
     if constexpr (BF) {
         if (v2) {
             switch (c) {
@@ -911,6 +944,7 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
     }
 #undef VTX_V1
 #undef VTX_V2
+#undef VTX_V2X
     return 0;
 }
 
