@@ -483,3 +483,45 @@ def test_contraction_profiler_counts_launches_flops_bytes(backend):
     assert gm["seconds"] > 0 and cv["seconds"] > 0
     ops.profile_start()
     assert ops.profile_stop() == []           # start resets the counters
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,A,T,S,causal", [(2, 3, 30, 49, False), (3, 2, 30, 30, True)])
+def test_attention_dropout_mask_is_shared_by_forward_and_backward(backend, dtype, B, A, T, S, causal):
+    """Attention dropout is a counter-based hash re-evaluated in backward (no mask tensor).  Recover the mask the
+    forward pass used by running it with V = identity (then O[i][j] = dropout(P)[i][j]), rebuild the op in torch
+    with that mask and check the output and all three gradients -- fp32 scalar kernel and bf16 MFMA kernel."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(17 * T + S)
+    p_drop, seed, Hd = 0.25, 1234, A * 64
+    q = torch.randn(B * T, Hd, generator=g).to(dtype)
+    k = torch.randn(B * S, Hd, generator=g).to(dtype)
+    v = torch.randn(B * S, Hd, generator=g).to(dtype)
+    dout = torch.randn(B * T, Hd, generator=g).to(dtype)
+    eye = torch.eye(S, 64).repeat(B, A).to(dtype)                       # [B*S, A*64]: V_h = I for every head
+    pd = ops.attention_fwd(q.to(dev), k.to(dev), eye.to(dev), B, A, T, S, causal, None, p_drop, seed)
+    pd = pd.float().cpu().reshape(B, T, A, 64)[..., :S].permute(0, 2, 1, 3)          # (B, A, T, S) dropped probabilities
+
+    def heads(t, L):
+        return t.float().reshape(B, L, A, 64).transpose(1, 2)
+    qr, kr, vr = (heads(q, T).requires_grad_(), heads(k, S).requires_grad_(), heads(v, S).requires_grad_())
+    mask = torch.triu(torch.full((T, S), float("-inf")), 1) if causal else torch.zeros(T, S)
+    p = torch.softmax(qr @ kr.transpose(-1, -2) / 8.0 + mask, dim=-1)
+    keep = (pd != 0) | (p.detach() < 1e-6)                 # a kept probability that underflowed to 0 is harmless
+    frac = keep[p.detach() > 1e-6].float().mean().item()
+    assert 0.65 < frac < 0.85                              # ~ 1 - p_drop
+    e = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(pd, (p * keep / (1 - p_drop)).detach()) < e
+    oref = ((p * keep / (1 - p_drop)) @ vr).transpose(1, 2).reshape(B * T, Hd)
+    oref.backward(dout.float())
+    o = ops.attention_fwd(q.to(dev), k.to(dev), v.to(dev), B, A, T, S, causal, None, p_drop, seed)
+    assert rel_err(o.float().cpu(), oref.detach()) < e
+    dq, dk, dv = torch.empty_like(q, device=dev), torch.empty_like(k, device=dev), torch.empty_like(v, device=dev)
+    ops.attention_bwd(q.to(dev), k.to(dev), v.to(dev), dout.to(dev), dq, dk, dv, B, A, T, S, causal, None, p_drop, seed)
+
+    def unheads(t, L):
+        return t.transpose(1, 2).reshape(B * L, Hd)
+    assert rel_err(dq.float().cpu(), unheads(qr.grad, T)) < 2 * e
+    assert rel_err(dk.float().cpu(), unheads(kr.grad, S)) < 2 * e
+    assert rel_err(dv.float().cpu(), unheads(vr.grad, S)) < 2 * e

@@ -169,6 +169,315 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, const T* __re
                     [&](int j, int i) { return sG[i * SMAX + j]; });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16: the same attention on the matrix cores, ONE WAVE per (batch, head), 4 waves per workgroup.
+//
+// Notation: mfma(X, Y) = v_mfma_f32_16x16x32_bf16 with X as the first and Y as the second operand gives every
+// lane out[y = lane&15][x = 4*(lane>>4) + r], r = 0..3, = sum_k X[x][k] * Y[y][k]; lane (., g = lane>>4) supplies
+// eight k of row lane&15 of each operand -- WHICH eight is free as long as both operands agree.
+//
+//   scores[i][j] = mfma(K rows j, Q rows i), k = d: both fragments are 16-byte global loads (no LDS);
+//                  lane (i, g) ends up with scores[i][16*jt + 4g + r] for the four key tiles jt: the four lanes
+//                  sharing a query row hold all 64 keys -> masks, softmax and dropout stay in registers
+//                  (row max / sum = 16 local values + two xor-shuffles).
+//   O[i][d]      = mfma(V^T rows d, P rows i), k = j with the k-set of lane (., g) in step ks chosen as
+//                  {32ks + 4g + r} U {32ks + 16 + 4g + r}: exactly the probabilities the lane already owns (tiles
+//                  2ks and 2ks+1), so P never moves.  V^T fragments with that k-set are two ds_read_b64_tr_b16
+//                  from the row-major V tile in LDS (the only LDS tile).
+// The backward kernel adds dP = mfma(V rows j, dO rows i) in the scores layout, the softmax backward in
+// registers, dQ = mfma(K^T rows d, dS rows i) like O, and dV / dK (contraction over the queries) from the
+// probabilities / dS written once to LDS in bf16 and read back transposed with the same tr instruction.
+constexpr int SP = 64;                     // keys padded to four 16-wide tiles
+constexpr int VROW = D + 8;                // LDS row pitch (elements): 144 B, keeps the tr reads off one bank set
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_bf16(bf16_t* p, f32x4_t v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
+                                              (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+}
+__device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* base, long ld, int row, int nrows, int col) {
+    // 8 consecutive bf16 of row `row` (zeros past the end of the tile)
+    if (row >= nrows) return bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    return *reinterpret_cast<const bf16x8_t*>(base + (long)row * ld + col);
+}
+__device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
+    bf16x8_t r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { r[t] = (short)f2bf(lo[t]); r[4 + t] = (short)f2bf(hi[t]); }
+    return r;
+}
+// rows x 64 bf16 tile -> LDS (pitch VROW), rows >= nrows zero-filled up to `pad_rows`; one wave
+__device__ __forceinline__ void stage_tile(bf16_t* dst, const bf16_t* src, long ld, int nrows, int pad_rows, int lane) {
+    for (int c = lane; c < pad_rows * 8; c += 64) {
+        const int r = c >> 3, col = (c & 7) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r < nrows) v = *reinterpret_cast<const uint4*>(src + (long)r * ld + col);
+        *reinterpret_cast<uint4*>(dst + r * VROW + col) = v;
+    }
+}
+// fragment of the TRANSPOSED tile: rows = columns c0..c0+15 of the LDS tile, k-set {kb + jj} U {kb + 16 + jj}
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int c0, int kb, int lane) {
+    const int w = lane & 15;
+    const bf16_t* pa = tile + (kb + (w >> 2)) * VROW + c0 + 4 * (w & 3);
+    const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)pa);
+    const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(pa + 16 * VROW));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// same, standard k-set {kb + 0..7}: two reads 4 rows apart
+__device__ __forceinline__ bf16x8_t tr_frag_std(const bf16_t* tile, int c0, int kb, int lane) {
+    const int w = lane & 15;
+    const bf16_t* pa = tile + (kb + (w >> 2)) * VROW + c0 + 4 * (w & 3);
+    const v4s_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)pa);
+    const v4s_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(pa + 4 * VROW));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ float quad_max(float v) {   // over the four lanes sharing lane & 15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// scores -> probabilities (pre-dropout) for the two query tiles; p[it][jt][r] belongs to (i, j) =
+// (16 it + lane&15, 16 jt + 4 (lane>>4) + r)
+__device__ __forceinline__ void mfma_probabilities(const AttnArgs& a, const bf16_t* q, const bf16_t* k, int len, int lane,
+                                                   float (&p)[2][4][4]) {
+    const int w = lane & 15, g = lane >> 4;
+    f32x4_t sc[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) sc[it][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t fq[2], fk[4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) fq[it] = ld_frag(q, a.ldq, 16 * it + w, a.T, 32 * ks + 8 * g);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) fk[jt] = ld_frag(k, a.ldk, 16 * jt + w, a.S, 32 * ks + 8 * g);
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                sc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt], fq[it], sc[it][jt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 16 * it + w;
+        float m = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * g + r;
+                const bool masked = j >= a.S || j >= len || (a.causal && j > i);
+                p[it][jt][r] = masked ? -INFINITY : sc[it][jt][r] * a.scale;
+                m = fmaxf(m, p[it][jt][r]);
+            }
+        m = quad_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = (m > -INFINITY && p[it][jt][r] > -INFINITY) ? __expf(p[it][jt][r] - m) : 0.f;
+                p[it][jt][r] = e;
+                sum += e;
+            }
+        sum = quad_sum(sum);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[it][jt][r] *= inv;
+    }
+}
+
+// out[i][16 dt + 4g + r] (+)= sum_j coef[i][j] * tile[j][d]: the "O = P V" product; coef in the scores layout
+__device__ __forceinline__ void mfma_rows_times_tile(const float (&c)[2][4][4], const bf16_t* tile, int lane,
+                                                     f32x4_t (&out)[2][4]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t fc[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) fc[it] = pack8(c[it][2 * ks], c[it][2 * ks + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x8_t ft = tr_frag(tile, 16 * dt, 32 * ks + 4 * g, lane);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+                out[it][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ft, fc[it], out[it][dt], 0, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ void store_rows(bf16_t* dst, long ld, int nrows, int lane, const f32x4_t (&v)[2][4]) {
+    const int w = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 16 * it + w;
+        if (i >= nrows) continue;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) st4_bf16(dst + (long)i * ld + 16 * dt + 4 * g, v[it][dt]);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, bf16_t* __restrict__ o, int nbh) {
+    __shared__ __attribute__((aligned(16))) bf16_t sV[4][SP * VROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 4 + wave;
+    if (bh >= nbh) return;
+    const int b = bh / a.heads, h = bh % a.heads;
+    const bf16_t* q = (const bf16_t*)a.q + (long)b * a.T * a.ldq + h * D;
+    const bf16_t* k = (const bf16_t*)a.k + (long)b * a.S * a.ldk + h * D;
+    const bf16_t* v = (const bf16_t*)a.v + (long)b * a.S * a.ldv + h * D;
+    stage_tile(sV[wave], v, a.ldv, a.S, SP, lane);
+    const int len = a.lengths ? (int)a.lengths[b] : a.S;
+    float p[2][4][4];
+    mfma_probabilities(a, q, k, len, lane, p);
+    if (a.drop.thresh) {
+        const uint64_t pbase = (uint64_t)bh * (TMAX * SMAX);
+        const int w = lane & 15, g = lane >> 4;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    p[it][jt][r] = a.drop.apply(p[it][jt][r], pbase + (16 * it + w) * SMAX + 16 * jt + 4 * g + r);
+    }
+    __builtin_amdgcn_wave_barrier();          // sV written by this wave's own lanes
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[it][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    mfma_rows_times_tile(p, sV[wave], lane, acc);
+    store_rows(o + (long)b * a.T * a.ldo + h * D, a.ldo, a.T, lane, acc);
+}
+
+// scores-layout coefficients c[it][jt][r] -> LDS tile [i][j] (bf16), so that products contracting over the
+// queries can read them transposed
+__device__ __forceinline__ void spill_coef(bf16_t* tile, const float (&c)[2][4][4], int lane) {
+    const int w = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+            { const f32x4_t t4 = {c[it][jt][0], c[it][jt][1], c[it][jt][2], c[it][jt][3]}; st4_bf16(tile + (16 * it + w) * VROW + 16 * jt + 4 * g, t4); }
+}
+// out[j][16 dt + 4g + r] = sum_i coef[i][j] * tile[i][d]   (coef and tile both in LDS, 32 rows = one MFMA K step)
+__device__ __forceinline__ void mfma_coefT_times_tile(const bf16_t* coef, const bf16_t* tile, bf16_t* dst, long ld,
+                                                      int nrows, int lane) {
+    const int w = lane & 15, g = lane >> 4;
+    bf16x8_t ft[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ft[dt] = tr_frag_std(tile, 16 * dt, 8 * g, lane);
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const bf16x8_t fc = tr_frag_std(coef, 16 * jt, 8 * g, lane);
+        const int j = 16 * jt + w;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+            const f32x4_t r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ft[dt], fc, zero, 0, 0, 0);
+            if (j < nrows) st4_bf16(dst + (long)j * ld + 16 * dt + 4 * g, r);
+        }
+    }
+}
+
+__global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a, const bf16_t* __restrict__ dout,
+                                                            bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
+                                                            bf16_t* __restrict__ dv, long lddq, long lddk, long lddv,
+                                                            int nbh) {
+    __shared__ __attribute__((aligned(16))) bf16_t sK[2][SP * VROW], sQ[2][TMAX * VROW], sO[2][TMAX * VROW], sC[2][TMAX * VROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bh = blockIdx.x * 2 + wave;
+    if (bh >= nbh) return;
+    const int b = bh / a.heads, h = bh % a.heads;
+    const int w = lane & 15, g = lane >> 4;
+    const bf16_t* q = (const bf16_t*)a.q + (long)b * a.T * a.ldq + h * D;
+    const bf16_t* k = (const bf16_t*)a.k + (long)b * a.S * a.ldk + h * D;
+    const bf16_t* v = (const bf16_t*)a.v + (long)b * a.S * a.ldv + h * D;
+    const bf16_t* go = dout + (long)b * a.T * a.ldo + h * D;
+    stage_tile(sK[wave], k, a.ldk, a.S, SP, lane);
+    stage_tile(sQ[wave], q, a.ldq, a.T, TMAX, lane);
+    stage_tile(sO[wave], go, a.ldo, a.T, TMAX, lane);
+    const int len = a.lengths ? (int)a.lengths[b] : a.S;
+    const uint64_t pbase = (uint64_t)bh * (TMAX * SMAX);
+    float p[2][4][4];
+    mfma_probabilities(a, q, k, len, lane, p);
+    // dV[j][d] = sum_i dropout(P)[i][j] dO[i][d]
+    {
+        float pd[2][4][4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pd[it][jt][r] = a.drop.apply(p[it][jt][r], pbase + (16 * it + w) * SMAX + 16 * jt + 4 * g + r);
+        spill_coef(sC[wave], pd, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+    mfma_coefT_times_tile(sC[wave], sO[wave], dv + (long)b * a.S * lddv + h * D, lddv, a.S, lane);
+    // dP[i][j] = dropout'( sum_d dO[i][d] V[j][d] ), in the scores layout
+    f32x4_t dp[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) dp[it][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t fo[2], fv[4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) fo[it] = ld_frag(go, a.ldo, 16 * it + w, a.T, 32 * ks + 8 * g);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) fv[jt] = ld_frag(v, a.ldv, 16 * jt + w, a.S, 32 * ks + 8 * g);
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+                dp[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt], fo[it], dp[it][jt], 0, 0, 0);
+    }
+    // dS = P * (dP - rowsum(dP * P)) * scale
+    float ds[2][4][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        float dot = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float gji = a.drop.apply(dp[it][jt][r], pbase + (16 * it + w) * SMAX + 16 * jt + 4 * g + r);
+                ds[it][jt][r] = gji;
+                dot += gji * p[it][jt][r];
+            }
+        dot = quad_sum(dot);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[it][jt][r] = p[it][jt][r] * (ds[it][jt][r] - dot) * a.scale;
+    }
+    // dQ[i][d] = sum_j dS[i][j] K[j][d]
+    {
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[it][dt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        mfma_rows_times_tile(ds, sK[wave], lane, acc);
+        store_rows(dq + (long)b * a.T * lddq + h * D, lddq, a.T, lane, acc);
+    }
+    // dK[j][d] = sum_i dS[i][j] Q[i][d]
+    __builtin_amdgcn_wave_barrier();          // every lane is done reading the dropout(P) tile
+    spill_coef(sC[wave], ds, lane);
+    __builtin_amdgcn_wave_barrier();
+    mfma_coefT_times_tile(sC[wave], sQ[wave], dk + (long)b * a.S * lddk + h * D, lddk, a.S, lane);
+}
+
 static int check(const char* who, int dtype, int B, int heads, int T, int S, int head_dim) {
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "%s: bad dtype", who);
     VTX_CHECK(B >= 0 && heads > 0 && T > 0 && S > 0, VTX_ERR_ARG, "%s: bad shape", who);
@@ -189,7 +498,10 @@ extern "C" int vtx_attention_fwd(int dtype, const void* q, long ldq, const void*
     AttnArgs a{q, k, v, ldq, ldk, ldv, ldo, T, S, heads, 1.0f / sqrtf((float)head_dim), causal, key_lengths,
                make_dropout(p_drop, seed)};
     dim3 grid(B * heads), block(256);
-    if (dtype == VTX_BF16) hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a, (bf16_t*)o);
+    if (dtype == VTX_BF16) {
+        VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, VTX_ERR_SHAPE, "attention_fwd: row strides must be multiples of 8");
+        hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 4)), block, 0, (hipStream_t)stream, a, (bf16_t*)o, B * heads);
+    }
     else hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a, (float*)o);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
@@ -206,9 +518,12 @@ extern "C" int vtx_attention_bwd(int dtype, const void* q, long ldq, const void*
     AttnArgs a{q, k, v, ldq, ldk, ldv, ldo, T, S, heads, 1.0f / sqrtf((float)head_dim), causal, key_lengths,
                make_dropout(p_drop, seed)};
     dim3 grid(B * heads), block(256);
-    if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), grid, block, 0, (hipStream_t)stream, a, (const bf16_t*)dout,
-                           (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv);
+    if (dtype == VTX_BF16) {
+        VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
+                  VTX_ERR_SHAPE, "attention_bwd: row strides must be multiples of 8 (inputs) / 4 (gradients)");
+        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 2)), dim3(128), 0, (hipStream_t)stream, a,
+                           (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, B * heads);
+    }
     else
         hipLaunchKernelGGL((attn_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a, (const float*)dout,
                            (float*)dq, (float*)dk, (float*)dv, lddq, lddk, lddv);
