@@ -291,3 +291,41 @@ def test_other_baseline_configs_fp32_gpu(visual, textual):
                 zip(model.named_parameters(), oracle_model.named_parameters()) if "cnn" not in n)
     assert worst[0] < 1e-3, worst
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def _train_then_eval(dev, steps=2):
+    """Two optimizer steps (fused HIP optimizer, direct-to-buffer gradients, BatchNorm statistics updated inside
+    the kernels), then an eval-mode forward: the folded inference weights must reflect BOTH the updated parameters
+    and the updated running statistics (neither change goes through a torch operator)."""
+    from virtex_amd import distributed as vd
+    from virtex_amd.optim import FusedPretrainOptimizer
+    oracle_model, model, batch = _build_pair("r50_l2_h128_b3_small", dev, torch.float32)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    with torch.no_grad():                       # populate the fold cache with the initial state
+        model.eval()
+        first = model(dbatch)["loss"].item()
+    step = port.TrainStep(oracle_model, total_steps=50, warmup_steps=5, start_step=3)
+    buckets = vd.GradientBuckets(model, bucket_mb=1.0)
+    opt = FusedPretrainOptimizer(model, buckets, total_steps=50, warmup_steps=5, start_step=3)
+    for _ in range(steps):
+        oracle_model.train(), model.train()
+        step(batch)
+        buckets.zero(); buckets.begin()
+        model(dbatch)["loss"].backward()
+        opt.step(grad_scale=buckets.finish())
+    oracle_model.eval(), model.eval()
+    with torch.no_grad():
+        ref = oracle_model(batch)["loss"].item()
+        out = model(dbatch)["loss"].item()
+    assert abs(ref - first) > 1e-3 * abs(first)            # the state really moved
+    assert abs(out - ref) < 2e-3 * abs(ref), (out, ref, first)
+
+
+@pytest.mark.emu
+def test_eval_after_fused_training_steps_sees_updated_weights_and_statistics_emulator():
+    _train_then_eval(select("emu"))
+
+
+@pytest.mark.gpu
+def test_eval_after_fused_training_steps_sees_updated_weights_and_statistics_gpu():
+    _train_then_eval(select("gpu"))

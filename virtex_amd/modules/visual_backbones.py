@@ -126,6 +126,7 @@ class TorchvisionVisualBackbone(VisualBackbone):
                 m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
         self.compute_dtype = compute_dtype
         self.frozen = frozen
+        self._stats_epoch = 0          # training-mode forwards so far (they rewrite the BatchNorm running statistics)
         if frozen:
             for p in self.cnn.parameters():
                 p.requires_grad = False
@@ -166,7 +167,7 @@ class TorchvisionVisualBackbone(VisualBackbone):
         dt = self.compute_dtype
 
         def run(u, a, relu, residual=None):
-            w, bias = _folded(u, dt)
+            w, bias = _folded(u, dt, self._stats_epoch)
             return ops.conv2d_infer(a, w, bias, u.stride, u.pad, relu=relu, residual=residual)
 
         with torch.no_grad():
@@ -209,12 +210,14 @@ class TorchvisionVisualBackbone(VisualBackbone):
         return _ResNetFn.apply(image, self, *params)
 
 
-def _folded(u: _Unit, dtype):
+def _folded(u: _Unit, dtype, epoch: int = 0):
     """Eval mode: (w (KO,R,S,Cp), bias (KO,)) with the running-statistics BatchNorm folded into the
     convolution; cached on the unit's tensors until any of them is modified in place."""
     bn = u.bn
     src = (u.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = (dtype,) + tuple((t.data_ptr(), t._version) for t in src)
+    # running statistics are updated by the BatchNorm kernel itself (no torch version bump): the module counts its
+    # training-mode forwards and the key carries that count
+    key = (dtype, epoch) + tuple((t.data_ptr(), t._version) for t in src)
     cache = getattr(u.conv, "_vtx_folded", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
@@ -333,6 +336,7 @@ class _ResNetFn(torch.autograd.Function):
         dt = module.compute_dtype
         dev = image.device
         stem, blocks = module._units()
+        module._stats_epoch += 1
         need_grad = any(p.requires_grad for p in params)
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
         saved: List[_Saved] = []

@@ -194,6 +194,10 @@ class FusedPretrainOptimizer:
         self.ops.sgd_lookahead_step(self.flat_p, g, self.flat_m, self.flat_slow, self.chunk_off, self.chunk_len,
                                     self.chunk_seg, self.seg_lr, self.seg_wd, mult, self.momentum, grad_scale,
                                     self.sumsq, self.clip_norm, look, self.alpha)
+        # the kernel wrote the parameters behind torch's back: bump their version counters so that everything
+        # keyed on them (the eval-mode folded weights, autograd's saved-tensor checks) sees the update
+        for p in self.buckets.params:
+            torch.autograd.graph.increment_version(p)
         self.step_idx += 1
 
     # -- checkpointing: same torch.optim.SGD layout as PretrainOptimizer.state_dict() (momentum buffers are
@@ -235,12 +239,18 @@ class FusedPretrainOptimizer:
         self.kc = int(extra.get("k_counter", 0))
         self.flat_slow.copy_(self.flat_p)        # reference semantics: slow weights restart from the loaded ones
 
+    def _touch(self):
+        for p in self.buckets.params:
+            torch.autograd.graph.increment_version(p)
+
     @torch.no_grad()
     def load_slow_weights(self):
         self._backup = self.flat_p.clone()
         self.flat_p.copy_(self.flat_slow)
+        self._touch()
 
     @torch.no_grad()
     def restore_fast_weights(self):
         self.flat_p.copy_(self._backup)
         del self._backup
+        self._touch()
