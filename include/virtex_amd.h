@@ -155,6 +155,17 @@ int vtx_image_to_nhwc(int dtype, const float* src_nchw, void* dst_nhwc, int N, i
                       int Cpad, void* stream);
 int vtx_weight_prep(int dtype, const float* w32 /*[KO][T][C]*/, void* w /*[KO][T][Cp] or NULL*/,
                     void* wt /*[Cp][T][KO] or NULL*/, int KO, int T, int C, int Cp, void* stream);
+/* every weight of the step in one launch: descs[i] (device memory) describes one vtx_weight_prep; tile_start[i]
+ * (device, int[ndesc]) = number of 32x32 tiles of the descriptors before i; a descriptor has
+ * ceil(Cp/32)*ceil(KO/32)*T tiles; total_tiles = their sum. */
+typedef struct VtxPrepDesc {
+    const void* w32; /* fp32 [KO][T][C] */
+    void* w;         /* dtype [KO][T][Cp] or NULL */
+    void* wt;        /* dtype [Cp][T][KO] or NULL */
+    int KO, T, C, Cp;
+} VtxPrepDesc;
+int vtx_weight_prep_batched(int dtype, const VtxPrepDesc* descs, const int* tile_start, int ndesc,
+                            int total_tiles, void* stream);
 int vtx_cast_from_f32(int dtype, const float* src, void* dst, long n, void* stream);
 
 /* ---- WordAndPositionalEmbedding (virtex/modules/embedding.py:46-74) -------------------

@@ -525,3 +525,35 @@ def test_attention_dropout_mask_is_shared_by_forward_and_backward(backend, dtype
     assert rel_err(dq.float().cpu(), unheads(qr.grad, T)) < 2 * e
     assert rel_err(dk.float().cpu(), unheads(kr.grad, S)) < 2 * e
     assert rel_err(dv.float().cpu(), unheads(vr.grad, S)) < 2 * e
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batched_weight_preparation_and_cache(backend, dtype):
+    """ops.prep_many: one launch for many weights == the per-weight kernel; copies are cached on the parameter and
+    refreshed when its version counter or storage moves."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(5)
+    conv = torch.nn.Parameter(torch.randn(40, 24, 3, 3, generator=g).contiguous(memory_format=torch.channels_last).to(dev))
+    stem = torch.nn.Parameter(torch.randn(16, 3, 7, 7, generator=g).contiguous(memory_format=torch.channels_last).to(dev))
+    lin = torch.nn.Parameter(torch.randn(70, 50, generator=g).to(dev))
+    items = [(conv, None, True), (stem, 8, False), (lin, None, True)]
+    assert ops.prep_many(items, dtype) == 3
+    assert ops.prep_many(items, dtype) == 0                       # everything current: no launch
+    for (p, cpad, want_wt) in items:
+        w, wt = ops.prepped(p, dtype, cpad=cpad, want_wt=want_wt)
+        w32 = ops._w32_view(p)
+        rw, rwt = ops.weight_prep(w32, dtype, cpad=cpad, want_wt=want_wt)
+        assert torch.equal(w.float().cpu(), rw.float().cpu())
+        if want_wt:
+            assert torch.equal(wt.float().cpu(), rwt.float().cpu())
+        else:
+            assert wt is None
+    before = ops.prepped(lin, dtype)[0].float().cpu().clone()
+    with torch.no_grad():
+        lin.mul_(2.0)                                              # in-place edit bumps the version
+    assert ops.prep_many(items, dtype) == 1
+    assert torch.allclose(ops.prepped(lin, dtype)[0].float().cpu(), 2 * before, rtol=1e-2)
+    # the transposed copy of the stem was not asked for at first: asking later computes just that
+    w, wt = ops.prepped(stem, dtype, cpad=8, want_wt=True)
+    assert wt is not None and wt.shape == (8, 49, 16)

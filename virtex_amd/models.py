@@ -35,9 +35,10 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
         targets = torch.full((B, T), padding_idx, dtype=torch.int64, device=tokens.device)
         targets[:, :-1] = tokens[:, 1:]
         targets = targets.view(-1)
-        w = weight.detach() if dt == torch.float32 else ops.cast_from_f32(weight.detach(), dt)
+        w, _ = ops.prepped(weight, dt, want_wt=False)
         h2 = hidden.reshape(B * T, H)
-        logits = ops.gemm_nt(h2, w, bias=bias.detach(), out_f32=True)
+        logits = ops.gemm_nt(h2, w.view(weight.shape), bias=bias.detach(), out_f32=True)
+        ctx.weight_param = weight
         lc, lse = ops.cross_entropy_fwd(logits, targets, padding_idx)
         ctx.save_for_backward(h2, weight, targets, logits, lse, lc)
         ctx.cfg = (B, T, H, V, padding_idx, dt)
@@ -49,7 +50,7 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
         B, T, H, V, padding_idx, dt = ctx.cfg
         g = gout.reshape(1).to(torch.float32).contiguous()
         d = ops.cross_entropy_bwd(logits, targets, lse, lc, g, dt, padding_idx)      # (B*T, V) compute dtype
-        _, wt = ops.weight_prep(weight.detach(), dt, want_w=False)
+        _, wt = ops.prepped(ctx.weight_param, dt, want_w=False)
         dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
         dW = torch.zeros_like(weight)
         ops.gemm_tn_acc(d, h2, dW)
@@ -81,7 +82,25 @@ class CaptioningModel(nn.Module):
         return _TiedCrossEntropyFn.apply(hidden, head.output.weight, head.output.bias, tokens,
                                          self.padding_idx)
 
+    def _refresh_compute_weights(self):
+        """One launch for all the bf16/fp32 compute copies (and their transposes) the step will use; weights whose
+        copies are current (no optimizer step / in-place edit since) cost nothing."""
+        seen, items = set(), []
+        heads = [self.textual] + ([self.backward_textual] if self.caption_backward else [])
+        plan = (self.visual.weight_plan() if hasattr(self.visual, "weight_plan") else [])
+        for h in heads:
+            if hasattr(h, "weight_plan"):
+                plan = plan + h.weight_plan()
+        for it in plan:
+            if id(it[0]) not in seen:
+                seen.add(id(it[0]))
+                items.append(it)
+        dt = getattr(self.textual, "compute_dtype", None)
+        if items and dt is not None:
+            ops.prep_many(items, dt)
+
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
+        self._refresh_compute_weights()
         visual_features = self.visual(batch["image"])
         batch_size = visual_features.size(0)
         if "caption_tokens" in batch:

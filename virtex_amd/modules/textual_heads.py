@@ -156,6 +156,16 @@ class TransformerDecoderTextualHead(TextualHead):
         h = self.features(visual_features, caption_tokens, caption_lengths)
         return _OutputProjectionFn.apply(h, self.output.weight, self.output.bias)
 
+    def weight_plan(self):
+        """(parameter, channel padding, transposed copy wanted) for every GEMM weight of this head."""
+        items = [(self.visual_projection.weight, None, True)]
+        for layer in self.transformer.layers:
+            for w in (layer.self_attn.in_proj_weight, layer.self_attn.out_proj.weight, layer.multihead_attn.in_proj_weight,
+                      layer.multihead_attn.out_proj.weight, layer.linear1.weight, layer.linear2.weight):
+                items.append((w, None, True))
+        items.append((self.output.weight, None, True))
+        return items
+
     @staticmethod
     def make_future_mask(size, dtype, device):
         """Kept for API parity (reference :280-292); the fused attention kernel applies the
@@ -185,18 +195,20 @@ class _DecoderFn(torch.autograd.Function):
         T = x0.shape[1]
         x = x0.reshape(B * T, H)
         lengths = lengths.contiguous()
-        Wv32, bv = params[0].detach(), params[1].detach()
-        Wv, Wv_t = ops.weight_prep(Wv32, dt)
+        bv = params[1].detach()
+        Wv, Wv_t = ops.prepped(params[0], dt)
         Wv, Wv_t = Wv.view(H, -1), Wv_t.view(-1, H)
         mem = ops.gemm_nt(mem_in, Wv, bias=bv)                       # (B*S, H)
         saved_layers = []
         for li in range(head.num_layers):
-            P = [t.detach() for t in params[2 + 18 * li: 2 + 18 * (li + 1)]]
+            raw = params[2 + 18 * li: 2 + 18 * (li + 1)]
+            P = [t.detach() for t in raw]
             (Win, bin_, Wo, bo, g1, b1, Win2, bin2, Wo2, bo2, g2, b2, W1, bf1, W2, bf2, g3, b3) = P
             seeds = [next_dropout_seed() for _ in range(7)]
             cw = {}
-            for name, w32 in (("Win", Win), ("Wo", Wo), ("Win2", Win2), ("Wo2", Wo2), ("W1", W1), ("W2", W2)):
-                w, wt = ops.weight_prep(w32, dt)
+            for name, idx in (("Win", 0), ("Wo", 2), ("Win2", 6), ("Wo2", 8), ("W1", 12), ("W2", 14)):
+                w32 = P[idx]
+                w, wt = ops.prepped(raw[idx], dt)
                 cw[name] = (w.view(w32.shape), wt.view(w32.shape[1], w32.shape[0]))
             # ---- masked self-attention
             qkv = ops.gemm_nt(x, cw["Win"][0], bias=bin_)                           # (B*T, 3H)
@@ -327,9 +339,10 @@ class _OutputProjectionFn(torch.autograd.Function):
     def forward(ctx, hidden, weight, bias):
         B, T, H = hidden.shape
         dt = hidden.dtype
-        w = weight.detach() if dt == torch.float32 else ops.cast_from_f32(weight.detach(), dt)
-        logits = ops.gemm_nt(hidden.reshape(B * T, H), w, bias=bias.detach(), out_f32=True)
+        w, _ = ops.prepped(weight, dt, want_wt=False)
+        logits = ops.gemm_nt(hidden.reshape(B * T, H), w.view(weight.shape), bias=bias.detach(), out_f32=True)
         ctx.save_for_backward(hidden, weight)
+        ctx.weight_param = weight
         return logits.view(B, T, -1)
 
     @staticmethod
@@ -340,7 +353,7 @@ class _OutputProjectionFn(torch.autograd.Function):
         V = weight.shape[0]
         d = dlogits.reshape(B * T, V)
         d = d.contiguous() if d.dtype == dt else d.to(dt).contiguous()
-        _, wt = ops.weight_prep(weight.detach(), dt, want_w=False)
+        _, wt = ops.prepped(ctx.weight_param, dt, want_w=False)
         dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
         dW = torch.zeros_like(weight)
         ops.gemm_tn_acc(d, hidden.reshape(B * T, H), dW)

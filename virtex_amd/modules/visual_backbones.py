@@ -132,6 +132,15 @@ class TorchvisionVisualBackbone(VisualBackbone):
                 p.requires_grad = False
             self.cnn.eval()
 
+    def weight_plan(self):
+        """(parameter, channel padding, transposed copy wanted) for every convolution: what ops.prep_many refreshes."""
+        if not self.cnn.training:
+            return []
+        stem, blocks = self._units()
+        units = [stem] + [u for blk in blocks for u in blk if u is not None]
+        need_grad = any(u.conv.weight.requires_grad or u.bn.weight.requires_grad or u.bn.bias.requires_grad for u in units)
+        return [(u.conv.weight, u.cin_pad, need_grad and u is not stem) for u in units]
+
     # -- export ---------------------------------------------------------------------------
     _D2_STAGE = {"layer1": "res2", "layer2": "res3", "layer3": "res4", "layer4": "res5"}
 
@@ -230,13 +239,9 @@ def _folded(u: _Unit, dtype, epoch: int = 0):
 
 
 def _prep_weight(u: _Unit, dtype, need_wt: bool):
-    """fp32 master (KO,C,R,S logical) -> compute copies w (KO,R,S,Cp) and wt (Cp,R,S,KO)."""
-    w32 = u.conv.weight.detach().permute(0, 2, 3, 1).contiguous().view(u.cout, u.k * u.k, u.cin)
-    if dtype == torch.float32 and u.cin_pad == u.cin:
-        w = w32
-        wt = ops.weight_prep(w32, dtype, want_w=False)[1] if need_wt else None
-    else:
-        w, wt = ops.weight_prep(w32, dtype, cpad=u.cin_pad, want_wt=need_wt)
+    """fp32 master (KO,C,R,S logical) -> compute copies w (KO,R,S,Cp) and wt (Cp,R,S,KO); cached on the
+    parameter until it changes (ops.prepped), normally already refreshed for the whole model by ops.prep_many."""
+    w, wt = ops.prepped(u.conv.weight, dtype, cpad=u.cin_pad, want_w=True, want_wt=need_wt)
     w = w.view(u.cout, u.k, u.k, u.cin_pad)
     if wt is not None:
         wt = wt.view(u.cin_pad, u.k, u.k, u.cout)

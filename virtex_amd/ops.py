@@ -285,6 +285,105 @@ def weight_prep(w32, dtype, cpad=None, want_w=True, want_wt=True):
     return w, wt
 
 
+# ---- compute copies of the master weights, cached on the parameter until its version changes -----------
+def _w32_view(param):
+    """fp32 master weight as [KO, T, C]: conv weights are stored (KO,R,S,C) physically (channels_last)."""
+    t = param.detach()
+    if t.dim() == 4:
+        KO, C, R, S = t.shape
+        return t.permute(0, 2, 3, 1).contiguous().view(KO, R * S, C)
+    return t.contiguous().view(t.shape[0], 1, t.shape[1])
+
+
+def _prep_entry(param, dtype, cpad):
+    store = param.__dict__.setdefault("_vtx_prep", {})
+    return store, (dtype, cpad)
+
+
+def prepped(param, dtype, cpad=None, want_w=True, want_wt=True):
+    """(w [KO,T,Cp], wt [Cp,T,KO]) compute copies of `param` in `dtype`; cached on the parameter object and
+    recomputed when its version counter moves (optimizer step, load_state_dict, in-place edits)."""
+    w32 = None
+    store, key = _prep_entry(param, dtype, cpad)
+    e = store.get(key)
+    stamp = (param._version, param.data_ptr())
+    if e is not None and e[0] == stamp and (e[1] is not None or not want_w) and (e[2] is not None or not want_wt):
+        return e[1], e[2]
+    w32 = _w32_view(param)
+    _chk(w32, "weight", torch.float32)
+    C = w32.shape[2]
+    if dtype == torch.float32 and (cpad or C) == C:
+        w = w32                                        # the master weight is its own compute copy
+        wt = weight_prep(w32, dtype, want_w=False)[1] if want_wt else None
+    else:
+        w, wt = weight_prep(w32, dtype, cpad=cpad, want_w=want_w, want_wt=want_wt)
+    if e is not None and e[0] == stamp:                # keep what was already there (e.g. w) when only wt was missing
+        w = w if w is not None else e[1]
+        wt = wt if wt is not None else e[2]
+    store[key] = (stamp, w, wt)
+    return w, wt
+
+
+_prep_tables = {}
+
+
+def prep_many(items, dtype):
+    """Refresh the compute copies of many weights with ONE kernel launch.  items: (param, cpad, want_wt).
+    Weights whose cached copies are current are skipped; output buffers are reused from step to step, so the
+    device-side descriptor table is built once per (set of weights)."""
+    import numpy as np
+    stale = []
+    for (param, cpad, want_wt) in items:
+        store, key = _prep_entry(param, dtype, cpad)
+        e = store.get(key)
+        if e is not None and e[0] == (param._version, param.data_ptr()) and (e[2] is not None or not want_wt):
+            continue
+        if e is not None and e[1] is not None and e[1].device != param.device:
+            e = None                                   # the module moved: old copies are on another device
+        stale.append((param, cpad, want_wt, store, key, e))
+    if not stale:
+        return 0
+    if len(stale) == 1:
+        prepped(stale[0][0], dtype, stale[0][1], True, stale[0][2])
+        return 1
+    dev = stale[0][0].device
+    descs, starts, keep, total = [], [], [], 0
+    for (param, cpad, want_wt, store, key, e) in stale:
+        w32 = _w32_view(param)
+        KO, T, C = w32.shape
+        Cp = cpad or C
+        alias = dtype == torch.float32 and Cp == C
+        w = w32 if alias else (e[1] if (e is not None and e[1] is not None and e[1].data_ptr() != w32.data_ptr()) else
+                               torch.empty(KO, T, Cp, dtype=dtype, device=dev))
+        wt = None
+        if want_wt:
+            wt = e[2] if (e is not None and e[2] is not None) else torch.empty(Cp, T, KO, dtype=dtype, device=dev)
+        if alias and not want_wt:
+            store[key] = ((param._version, param.data_ptr()), w, None)
+            continue
+        descs.append((w32.data_ptr(), 0 if alias else w.data_ptr(), wt.data_ptr() if wt is not None else 0, KO, T, C, Cp))
+        starts.append(total)
+        total += ((Cp + 31) // 32) * ((KO + 31) // 32) * T
+        keep.append((store, key, param, w32, w, wt))
+    if descs:
+        sig = (dtype, tuple(descs))
+        tab = _prep_tables.get(sig)
+        if tab is None:
+            if len(_prep_tables) > 16:
+                _prep_tables.clear()
+            arr = np.zeros(len(descs), dtype=np.dtype([("w32", "<u8"), ("w", "<u8"), ("wt", "<u8"), ("KO", "<i4"), ("T", "<i4"),
+                                                       ("C", "<i4"), ("Cp", "<i4")]))
+            for i, d in enumerate(descs):
+                arr[i] = d
+            tab = (torch.from_numpy(arr.view(np.uint8).copy()).to(dev), torch.tensor(starts, dtype=torch.int32, device=dev))
+            _prep_tables[sig] = tab
+        call("vtx_weight_prep_batched", c_int(dtype_code(dtype)), ptr(tab[0]), ptr(tab[1]), c_int(len(descs)), c_int(total),
+             stream_ptr(keep[0][3]))
+    for (store, key, param, w32, w, wt) in keep:
+        store[key] = ((param._version, param.data_ptr()), w, wt)
+    return len(stale)
+
+
 def bn_fold(w32, gamma, beta, running_mean, running_var, eps, dtype, cpad=None):
     """Eval-mode BatchNorm folded into its convolution: fp32 [KO,T,C] -> (w [KO,T,Cp] in `dtype`, bias [KO] fp32)."""
     if w32.dim() == 2:
