@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .modules.textual_heads import TextualHead
+from .modules.textual_heads import TextualHead, _sink_or_zeros
 from .modules.visual_backbones import VisualBackbone
 
 
@@ -38,7 +38,7 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
         w, _ = ops.prepped(weight, dt, want_wt=False)
         h2 = hidden.reshape(B * T, H)
         logits = ops.gemm_nt(h2, w.view(weight.shape), bias=bias.detach(), out_f32=True)
-        ctx.weight_param = weight
+        ctx.weight_param, ctx.bias_param = weight, bias
         lc, lse = ops.cross_entropy_fwd(logits, targets, padding_idx)
         ctx.save_for_backward(h2, weight, targets, logits, lse, lc)
         ctx.cfg = (B, T, H, V, padding_idx, dt)
@@ -52,11 +52,11 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
         d = ops.cross_entropy_bwd(logits, targets, lse, lc, g, dt, padding_idx)      # (B*T, V) compute dtype
         _, wt = ops.prepped(ctx.weight_param, dt, want_w=False)
         dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
-        dW = torch.zeros_like(weight)
+        dW, rW = _sink_or_zeros(ctx.weight_param)
         ops.gemm_tn_acc(d, h2, dW)
-        db = torch.zeros(V, dtype=torch.float32, device=d.device)
+        db, rb = _sink_or_zeros(ctx.bias_param)
         ops.colsum_acc(d, db)
-        return dh, dW, db, None, None
+        return dh, rW, rb, None, None
 
 
 class CaptioningModel(nn.Module):

@@ -57,17 +57,27 @@ class _EmbeddingFn(torch.autograd.Function):
                                             beta.detach(), dtype, padding_idx, eps, p, seed)
         ctx.save_for_backward(tokens, words, positions, gamma, mean, rstd)
         ctx.cfg = (padding_idx, p, seed)
+        ctx.owners = (words, positions, gamma, beta)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         tokens, words, positions, gamma, mean, rstd = ctx.saved_tensors
         padding_idx, p, seed = ctx.cfg
-        dw, dp = torch.zeros_like(words), torch.zeros_like(positions)
-        dg, db = torch.zeros_like(gamma), torch.zeros_like(gamma)
+        # every kernel accumulates (+=): write straight into the parameters' gradient buffers when they have
+        # one (also for the tied word matrix, which the output projection accumulates into as well)
+        bufs, rets = [], []
+        for owner in ctx.owners:
+            t = gradsink.target(owner)
+            if t is None:
+                t = torch.zeros_like(owner, dtype=torch.float32)
+                rets.append(t)
+            else:
+                rets.append(None)
+            bufs.append(t)
         ops.embedding_bwd(tokens, words.detach(), positions.detach(), gamma.detach(), mean, rstd,
-                          dout.contiguous(), dw, dp, dg, db, padding_idx, p, seed)
-        return None, dw, dp, dg, db, None, None, None, None
+                          dout.contiguous(), bufs[0], bufs[1], bufs[2], bufs[3], padding_idx, p, seed)
+        return None, rets[0], rets[1], rets[2], rets[3], None, None, None, None
 
 
 class TextualHead(nn.Module):
@@ -234,6 +244,7 @@ class _DecoderFn(torch.autograd.Function):
         ctx.head, ctx.p, ctx.dims = head, p, (B, T, S, H, A)
         ctx.layer_params = [list(params[2 + 18 * li: 2 + 18 * (li + 1)]) for li in range(head.num_layers)]
         ctx.saved_layers, ctx.mem, ctx.mem_in, ctx.Wv_t, ctx.lengths = saved_layers, mem, mem_in, Wv_t, lengths
+        ctx.vis_owner = (params[0], params[1])
         ctx.vshape = visual_features.shape
         ctx.needs_vis_grad = visual_features.requires_grad
         return x.view(B, T, H)
@@ -313,16 +324,25 @@ class _DecoderFn(torch.autograd.Function):
             pgrads = [dWin, dbin, dWo, dbo, rdg1, rdb1, rWin2, rbin2, dWo2, dbo2, rdg2, rdb2, dW1, dbf1, dW2, dbf2,
                       rdg3, rdb3] + pgrads
         # ---- visual projection
-        Cv = ctx.mem_in.shape[1]
-        dWv = zeros(H, Cv)
+        dWv, rWv = sink(ctx.vis_owner[0])
         ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
-        dbv = zeros(H)
+        dbv, rbv = sink(ctx.vis_owner[1])
         ops.colsum_acc(dmem, dbv)
         dvis = None
         if ctx.needs_vis_grad:
             Bv, C, h, w = ctx.vshape
             dvis = ops.gemm_nt(dmem, ctx.Wv_t).view(Bv, h, w, C).permute(0, 3, 1, 2)
-        return (dvis, dx.view(B, T, H), None, None, None, dWv, dbv, *pgrads)
+        return (dvis, dx.view(B, T, H), None, None, None, rWv, rbv, *pgrads)
+
+
+def _sink_or_zeros(p):
+    """(fp32 buffer the gradient kernels accumulate into, value to hand back to autograd): the parameter's own
+    gradient buffer and None when it has a suitable one (virtex_amd/gradsink.py), else a fresh zero tensor twice."""
+    t = gradsink.target(p)
+    if t is not None:
+        return t, None
+    z = torch.zeros_like(p, dtype=torch.float32)
+    return z, z
 
 
 def _wt_cols(wt, c0, c1):
@@ -342,7 +362,7 @@ class _OutputProjectionFn(torch.autograd.Function):
         w, _ = ops.prepped(weight, dt, want_wt=False)
         logits = ops.gemm_nt(hidden.reshape(B * T, H), w.view(weight.shape), bias=bias.detach(), out_f32=True)
         ctx.save_for_backward(hidden, weight)
-        ctx.weight_param = weight
+        ctx.weight_param, ctx.bias_param = weight, bias
         return logits.view(B, T, -1)
 
     @staticmethod
@@ -355,8 +375,8 @@ class _OutputProjectionFn(torch.autograd.Function):
         d = d.contiguous() if d.dtype == dt else d.to(dt).contiguous()
         _, wt = ops.prepped(ctx.weight_param, dt, want_w=False)
         dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
-        dW = torch.zeros_like(weight)
+        dW, rW = _sink_or_zeros(ctx.weight_param)
         ops.gemm_tn_acc(d, hidden.reshape(B * T, H), dW)
-        db = torch.zeros(V, dtype=torch.float32, device=d.device)
+        db, rb = _sink_or_zeros(ctx.bias_param)
         ops.colsum_acc(d, db)
-        return dh, dW, db
+        return dh, rW, rb
