@@ -62,9 +62,9 @@ def device_batch(B, dev, seed):
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v6.txt.
-TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v6.txt: (2 x 63.82e3 + 86.87e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false> >": 2.197e8,
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v7.txt.
+TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v7.txt: (2 x 70.03e3 + 113.7e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false>, 32, 3>": 2.598e8,
 }
 
 
@@ -82,11 +82,17 @@ def _kernel_name(bracket):
         else:
             cur += ch
     parts.append(cur)
-    vals = [p.split("=", 1)[1].strip() if "=" in p else p.strip() for p in parts]
-    name = ", ".join(vals).replace("vtxg::", "").replace("unsigned short", "bf16")
-    # __PRETTY_FUNCTION__ drops defaulted template arguments; rocprofv3 prints them
+    kv = {}
+    for p in parts:
+        if "=" in p:
+            k, v = p.split("=", 1)
+            kv[k.strip()] = v.strip()
+    # the kernel's own template parameter order (launch_v2 lists BK/STAGES earlier); __PRETTY_FUNCTION__ drops
+    # defaulted template arguments, rocprofv3 prints them
+    order = ["BM", "BN", "WM", "WN", "AL", "BL", "EP", "BK", "STAGES"]
+    name = ", ".join(kv[k] for k in order if k in kv).replace("vtxg::", "").replace("unsigned short", "bf16")
     name = name.replace("EpiStore<bf16>", "EpiStore<bf16, false>").replace("EpiStore<float>", "EpiStore<float, false>")
-    return f"contraction_v2_kernel<{name} >"
+    return f"contraction_v2_kernel<{name}>"
 
 
 def step_roofline(recs, dtype, default_workload):
