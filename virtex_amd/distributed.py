@@ -29,6 +29,8 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
+from .streams import wgrad_stream
+
 
 def init_process_group(backend: Optional[str] = None) -> int:
     """Rendezvous from torchrun-style environment variables; returns the local rank."""
@@ -58,7 +60,10 @@ def rank() -> int:
 
 def synchronize():
     if world_size() > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])   # pin the barrier's collective to this rank's GPU
+        else:
+            dist.barrier()
 
 
 def average_across_processes(tensors: dict) -> dict:
@@ -149,8 +154,11 @@ class GradientBuckets:
         if self.side is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            wg = wgrad_stream.peek(chunk.device)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
+                if wg is not None:              # weight gradients are produced on their own side stream
+                    self.side.wait_stream(wg)
                 self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
         else:
             self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
@@ -158,6 +166,7 @@ class GradientBuckets:
     def finish(self) -> float:
         """Wait for the outstanding collectives; returns the scale (1/world) the optimizer must
         apply to the summed gradients."""
+        wgrad_stream.join(self.flat.device)
         if not self.enabled:
             return 1.0
         for b, left in enumerate(self.pending):

@@ -21,6 +21,7 @@ import torch
 from torch import nn
 
 from .. import gradsink, ops
+from ..streams import wgrad_stream
 
 _seed_counter = itertools.count(1)
 
@@ -77,6 +78,9 @@ class _EmbeddingFn(torch.autograd.Function):
             bufs.append(t)
         ops.embedding_bwd(tokens, words.detach(), positions.detach(), gamma.detach(), mean, rstd,
                           dout.contiguous(), bufs[0], bufs[1], bufs[2], bufs[3], padding_idx, p, seed)
+        # the embedding is the first node of a head's forward, hence the last of its backward: from here on the
+        # compute stream also sees the weight gradients the decoder layers put on the side stream
+        wgrad_stream.join(dout.device)
         return None, rets[0], rets[1], rets[2], rets[3], None, None, None, None
 
 
@@ -273,11 +277,18 @@ class _DecoderFn(torch.autograd.Function):
             return z, z
 
         def linear_grads(inp, dout, wp, bp):
-            """dW ([out,in]) and dbias of y = inp @ W^T + b, accumulated into sinks."""
+            """dW ([out,in]) and dbias of y = inp @ W^T + b, accumulated into sinks.  With direct sinks (the
+            parameters own gradient buffers) both kernels go to the weight-gradient side stream: nothing on the
+            compute stream depends on them (virtex_amd/streams.py)."""
             dW, rW = sink(wp)
-            ops.gemm_tn_acc(dout, inp, dW)
             db, rb = sink(bp)
-            ops.colsum_acc(dout, db)
+            if rW is None and rb is None:
+                with wgrad_stream(dev, inp, dout):
+                    ops.gemm_tn_acc(dout, inp, dW)
+                    ops.colsum_acc(dout, db)
+            else:
+                ops.gemm_tn_acc(dout, inp, dW)
+                ops.colsum_acc(dout, db)
             return rW, rb
 
         for li in reversed(range(head.num_layers)):
@@ -303,11 +314,18 @@ class _DecoderFn(torch.autograd.Function):
             ops.attention_bwd(L["q2"], L["kv2"][:, :H], L["kv2"][:, H:], do2, dq2, dkv2[:, :H], dkv2[:, H:],
                               B, A, T, S, False, None, p, seeds[2])
             dWin2, rWin2 = sink(PP[6])
-            ops.gemm_tn_acc(dq2, L["x1"], dWin2[:H])
-            ops.gemm_tn_acc(dkv2, ctx.mem, dWin2[H:])
             dbin2, rbin2 = sink(PP[7])
-            ops.colsum_acc(dq2, dbin2[:H])
-            ops.colsum_acc(dkv2, dbin2[H:])
+
+            def cross_in_proj_grads():
+                ops.gemm_tn_acc(dq2, L["x1"], dWin2[:H])
+                ops.gemm_tn_acc(dkv2, ctx.mem, dWin2[H:])
+                ops.colsum_acc(dq2, dbin2[:H])
+                ops.colsum_acc(dkv2, dbin2[H:])
+            if rWin2 is None and rbin2 is None:
+                with wgrad_stream(dev, dq2, dkv2, L["x1"], ctx.mem):
+                    cross_in_proj_grads()
+            else:
+                cross_in_proj_grads()
             dx1 = ops.gemm_nt(dq2, _wt_cols(cw["Win2"][1], 0, H), residual=dz2)
             dmem = ops.gemm_nt(dkv2, _wt_cols(cw["Win2"][1], H, 3 * H), residual=dmem)
             # ---- self-attention block: x1 = LN1(x + drop(y1))
@@ -325,9 +343,14 @@ class _DecoderFn(torch.autograd.Function):
                       rdg3, rdb3] + pgrads
         # ---- visual projection
         dWv, rWv = sink(ctx.vis_owner[0])
-        ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
         dbv, rbv = sink(ctx.vis_owner[1])
-        ops.colsum_acc(dmem, dbv)
+        if rWv is None and rbv is None:          # shared by both heads: both go through the one side stream, in order
+            with wgrad_stream(dev, dmem, ctx.mem_in):
+                ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
+                ops.colsum_acc(dmem, dbv)
+        else:
+            ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
+            ops.colsum_acc(dmem, dbv)
         dvis = None
         if ctx.needs_vis_grad:
             Bv, C, h, w = ctx.vshape

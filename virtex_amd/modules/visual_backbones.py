@@ -286,49 +286,7 @@ def _conv_wgrad(u: _Unit, x, dy):
     return dw.permute(0, 3, 1, 2)
 
 
-_side_streams = {}
-
-
-class wgrad_stream:
-    """Context manager: run weight-gradient GEMMs (off the critical path of backward: nothing downstream
-    reads them until the optimizer) on a side HIP stream, concurrently with the input-gradient chain.
-    Inputs are fenced with an event; their memory is kept alive for the side stream with record_stream;
-    `join()` makes the main stream wait for everything issued so far."""
-    enabled = os.environ.get("VIRTEX_AMD_WGRAD_STREAM", "1") != "0"
-
-    def __init__(self, device, *inputs):
-        self.device, self.inputs = device, inputs
-        self.active = wgrad_stream.enabled and device.type == "cuda"
-
-    @staticmethod
-    def side(device):
-        st = _side_streams.get(device)
-        if st is None:
-            st = torch.cuda.Stream(device=device)
-            _side_streams[device] = st
-        return st
-
-    def __enter__(self):
-        if self.active:
-            side = wgrad_stream.side(self.device)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            side.wait_event(ev)
-            for t in self.inputs:
-                t.record_stream(side)
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if self.active:
-            self.ctx.__exit__(*exc)
-        return False
-
-    @staticmethod
-    def join(device):
-        if wgrad_stream.enabled and device.type == "cuda" and device in _side_streams:
-            torch.cuda.current_stream(device).wait_stream(_side_streams[device])
+from ..streams import wgrad_stream  # noqa: E402  (shared with the text heads and the data-parallel engine)
 
 
 class _Saved:

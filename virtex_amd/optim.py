@@ -16,6 +16,8 @@ from typing import Iterable, List, Tuple
 
 import torch
 
+from .streams import wgrad_stream
+
 NO_DECAY = r".*textual.(embedding|transformer).*(norm.*|bias)"
 
 
@@ -64,6 +66,7 @@ class PretrainOptimizer:
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         """`grad_scale` multiplies every gradient first (1/world_size after a SUM all-reduce)."""
+        wgrad_stream.join(self.params[0].device)
         grads = [p.grad for p in self.params]
         if grad_scale != 1.0:
             torch._foreach_mul_(grads, grad_scale)
@@ -184,6 +187,7 @@ class FusedPretrainOptimizer:
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         g = self.buckets.flat
+        wgrad_stream.join(g.device)
         if self.clip_norm:
             self.ops.sumsq(g, self.partials, self.sumsq)
         self.kc += 1

@@ -1,0 +1,64 @@
+"""The weight-gradient side stream.
+
+Weight gradients are off the critical path of backward: nothing downstream reads them until the gradient
+exchange / the optimizer.  The hand-written backward passes therefore enqueue their weight-gradient GEMMs (and
+the bias-gradient column sums) on ONE side HIP stream per device, where they run concurrently with the
+input-gradient chain on the compute stream.  One stream for all of them keeps every accumulation into a given
+gradient buffer ordered.  Who waits for it:
+  * the last backward node of each sub-graph (`_ResNetFn.backward`, `_EmbeddingFn.backward`) joins it into the
+    compute stream, so ordinary consumers of `.grad` on the compute stream are safe;
+  * the data-parallel engine makes its communication stream wait for it before every bucket all-reduce;
+  * the optimizers join it before touching gradients.
+"""
+import os
+
+import torch
+
+_side_streams = {}
+
+
+class wgrad_stream:
+    """Context manager: run weight-gradient GEMMs (off the critical path of backward: nothing downstream
+    reads them until the optimizer) on a side HIP stream, concurrently with the input-gradient chain.
+    Inputs are fenced with an event; their memory is kept alive for the side stream with record_stream;
+    `join()` makes the main stream wait for everything issued so far."""
+    enabled = os.environ.get("VIRTEX_AMD_WGRAD_STREAM", "1") != "0"
+
+    def __init__(self, device, *inputs):
+        self.device, self.inputs = device, inputs
+        self.active = wgrad_stream.enabled and device.type == "cuda"
+
+    @staticmethod
+    def side(device):
+        st = _side_streams.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            _side_streams[device] = st
+        return st
+
+    def __enter__(self):
+        if self.active:
+            side = wgrad_stream.side(self.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            side.wait_event(ev)
+            for t in self.inputs:
+                t.record_stream(side)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+    @staticmethod
+    def join(device):
+        if wgrad_stream.enabled and device.type == "cuda" and device in _side_streams:
+            torch.cuda.current_stream(device).wait_stream(_side_streams[device])
+
+    @staticmethod
+    def peek(device):
+        """The side stream of `device` if one has been created (None otherwise)."""
+        return _side_streams.get(device) if wgrad_stream.enabled else None
