@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .modules.textual_heads import TextualHead, _sink_or_zeros
+from .modules.textual_heads import TextualHead, tied_projection_grads
 from .modules.visual_backbones import VisualBackbone
 
 
@@ -52,10 +52,7 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
         d = ops.cross_entropy_bwd(logits, targets, lse, lc, g, dt, padding_idx)      # (B*T, V) compute dtype
         _, wt = ops.prepped(ctx.weight_param, dt, want_w=False)
         dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
-        dW, rW = _sink_or_zeros(ctx.weight_param)
-        ops.gemm_tn_acc(d, h2, dW)
-        db, rb = _sink_or_zeros(ctx.bias_param)
-        ops.colsum_acc(d, db)
+        rW, rb = tied_projection_grads(d, h2, ctx.weight_param, ctx.bias_param)
         return dh, rW, rb, None, None
 
 
@@ -101,6 +98,11 @@ class CaptioningModel(nn.Module):
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
         self._refresh_compute_weights()
+        emb = getattr(self.textual, "embedding", None)
+        if emb is not None and hasattr(emb, "defer_join"):
+            # the backbone's backward runs after both heads' and joins the weight-gradient side stream itself
+            emb.defer_join = bool(self.training and torch.is_grad_enabled()
+                                  and any(p.requires_grad for p in self.visual.parameters()))
         visual_features = self.visual(batch["image"])
         batch_size = visual_features.size(0)
         if "caption_tokens" in batch:

@@ -41,17 +41,20 @@ class WordAndPositionalEmbedding(nn.Module):
         self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-8, elementwise_affine=True)
         self.dropout = nn.Dropout(p=dropout)
         self.compute_dtype = torch.bfloat16
+        # set by the model when another backward node (the backbone's) is guaranteed to run after this one and
+        # joins the weight-gradient side stream itself (virtex_amd/streams.py)
+        self.defer_join = False
 
     def forward(self, tokens: torch.Tensor) -> torch.Tensor:
         p = self.dropout.p if self.training else 0.0
         return _EmbeddingFn.apply(tokens, self.words.weight, self.positions.weight, self.layer_norm.weight,
                                   self.layer_norm.bias, self.padding_idx, self.layer_norm.eps, p,
-                                  self.compute_dtype)
+                                  self.compute_dtype, self.defer_join)
 
 
 class _EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tokens, words, positions, gamma, beta, padding_idx, eps, p, dtype):
+    def forward(ctx, tokens, words, positions, gamma, beta, padding_idx, eps, p, dtype, defer_join=False):
         tokens = tokens.contiguous()
         seed = next_dropout_seed()
         out, mean, rstd = ops.embedding_fwd(tokens, words.detach(), positions.detach(), gamma.detach(),
@@ -59,6 +62,7 @@ class _EmbeddingFn(torch.autograd.Function):
         ctx.save_for_backward(tokens, words, positions, gamma, mean, rstd)
         ctx.cfg = (padding_idx, p, seed)
         ctx.owners = (words, positions, gamma, beta)
+        ctx.defer_join = defer_join
         return out
 
     @staticmethod
@@ -76,12 +80,25 @@ class _EmbeddingFn(torch.autograd.Function):
             else:
                 rets.append(None)
             bufs.append(t)
-        ops.embedding_bwd(tokens, words.detach(), positions.detach(), gamma.detach(), mean, rstd,
-                          dout.contiguous(), bufs[0], bufs[1], bufs[2], bufs[3], padding_idx, p, seed)
-        # the embedding is the first node of a head's forward, hence the last of its backward: from here on the
-        # compute stream also sees the weight gradients the decoder layers put on the side stream
-        wgrad_stream.join(dout.device)
-        return None, rets[0], rets[1], rets[2], rets[3], None, None, None, None
+        dev = dout.device
+        dout = dout.contiguous()
+        # Nothing on the compute stream reads these gradients.  When the word matrix accumulates in place, ALL of
+        # its writers (this scatter and the tied output projection's weight gradient) use the one side stream, so
+        # they stay ordered among themselves.
+        on_side = rets[0] is None
+        if on_side:
+            with wgrad_stream(dev, dout, mean, rstd):
+                ops.embedding_bwd(tokens, words.detach(), positions.detach(), gamma.detach(), mean, rstd,
+                                  dout, bufs[0], bufs[1], bufs[2], bufs[3], padding_idx, p, seed)
+        else:
+            ops.embedding_bwd(tokens, words.detach(), positions.detach(), gamma.detach(), mean, rstd,
+                              dout, bufs[0], bufs[1], bufs[2], bufs[3], padding_idx, p, seed)
+        # The embedding is the first node of a head's forward, hence the last of its backward: unless a later
+        # node is known to join the side stream (the backbone's backward), do it here; and always when a freshly
+        # allocated gradient is handed back to autograd, which will read it on the compute stream.
+        if not ctx.defer_join or (on_side and any(r is not None for r in rets)):
+            wgrad_stream.join(dev)
+        return None, rets[0], rets[1], rets[2], rets[3], None, None, None, None, None
 
 
 class TextualHead(nn.Module):
@@ -368,6 +385,24 @@ def _sink_or_zeros(p):
     return z, z
 
 
+def tied_projection_grads(d, h2, weight_param, bias_param):
+    """Weight / bias gradient of logits = h2 @ W^T + b for the TIED matrix.  In-place accumulation into the word
+    matrix' gradient buffer happens on the weight-gradient side stream, like the embedding scatter into the same
+    buffer (one stream => ordered).  Returns what autograd should get (None where accumulated in place)."""
+    dW, rW = _sink_or_zeros(weight_param)
+    db, rb = _sink_or_zeros(bias_param)
+    if rW is None:
+        with wgrad_stream(d.device, d, h2):
+            ops.gemm_tn_acc(d, h2, dW)
+            ops.colsum_acc(d, db)
+        if rb is not None:
+            wgrad_stream.join(d.device)          # a fresh bias-gradient tensor goes back to autograd
+    else:
+        ops.gemm_tn_acc(d, h2, dW)
+        ops.colsum_acc(d, db)
+    return rW, rb
+
+
 def _wt_cols(wt, c0, c1):
     """Columns [c0, c1) of a transposed weight wt = W^T (in_features, out_features) as a strided
     (in_features, c1-c0) view: the B operand of the input-gradient GEMM of the sub-projection
@@ -398,8 +433,5 @@ class _OutputProjectionFn(torch.autograd.Function):
         d = d.contiguous() if d.dtype == dt else d.to(dt).contiguous()
         _, wt = ops.prepped(ctx.weight_param, dt, want_w=False)
         dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
-        dW, rW = _sink_or_zeros(ctx.weight_param)
-        ops.gemm_tn_acc(d, hidden.reshape(B * T, H), dW)
-        db, rb = _sink_or_zeros(ctx.bias_param)
-        ops.colsum_acc(d, db)
+        rW, rb = tied_projection_grads(d, hidden.reshape(B * T, H), ctx.weight_param, ctx.bias_param)
         return dh, rW, rb
