@@ -286,7 +286,7 @@ def _conv_wgrad(u: _Unit, x, dy):
     return dw.permute(0, 3, 1, 2)
 
 
-from ..streams import wgrad_stream  # noqa: E402  (shared with the text heads and the data-parallel engine)
+from ..streams import branch_stream, wgrad_stream  # noqa: E402  (shared with the text heads and the data-parallel engine)
 
 
 class _Saved:
@@ -302,7 +302,7 @@ class _ResNetFn(torch.autograd.Function):
         module._stats_epoch += 1
         need_grad = any(p.requires_grad for p in params)
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
-        saved: List[_Saved] = []
+        rec = {}
 
         def run(u: _Unit, a, relu, residual=None, first=False):
             w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
@@ -315,7 +315,7 @@ class _ResNetFn(torch.autograd.Function):
                                        residual=residual, stats=stats)
             s = _Saved()
             s.a, s.x, s.y, s.mean, s.rstd, s.wt = a, x, y, mean, rstd, wt
-            saved.append(s)
+            rec[u] = s
             return y
 
         a0 = ops.image_to_nhwc(image.float().contiguous(), dt, STEM_CPAD)
@@ -324,20 +324,30 @@ class _ResNetFn(torch.autograd.Function):
         cur = pooled
         for (u1, u2, u3, ud) in blocks:
             inp = cur
-            t = run(u1, inp, True)
-            t = run(u2, t, True)
-            skip = run(ud, inp, False) if ud is not None else inp
+            if ud is not None:
+                # projection shortcut (1x1 conv + BN) on the branch stream, under the main branch's convolutions
+                br = branch_stream(dev, inp)
+                with br:
+                    skip = run(ud, inp, False)
+                t = run(u1, inp, True)
+                t = run(u2, t, True)
+                br.wait(skip)
+            else:
+                t = run(u1, inp, True)
+                t = run(u2, t, True)
+                skip = inp
             cur = run(u3, t, True, residual=skip)
-        ctx.module, ctx.saved, ctx.argmax, ctx.stem_out_shape = module, saved, argmax, y.shape
+        ctx.module, ctx.rec, ctx.argmax, ctx.stem_out_shape = module, rec, argmax, y.shape
+        ctx.units = (stem, blocks)
         ctx.nparams = len(params)
         N, H, W, C = cur.shape
         return cur.permute(0, 3, 1, 2)  # logical NCHW, physical NHWC
 
     @staticmethod
     def backward(ctx, dfeat):
-        module, saved = ctx.module, ctx.saved
+        module, rec = ctx.module, ctx.rec
         dt = module.compute_dtype
-        stem, blocks = module._units()
+        stem, blocks = ctx.units
         dcur = dfeat.permute(0, 2, 3, 1)
         if dcur.dtype != dt or not dcur.is_contiguous():
             dcur = dcur.to(dt).contiguous()
@@ -357,15 +367,20 @@ class _ResNetFn(torch.autograd.Function):
             grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
             return out
 
-        # index of each unit's saved record, in forward execution order
-        order = [stem]
-        for (u1, u2, u3, ud) in blocks:
-            order += [u1, u2] + ([ud] if ud is not None else []) + [u3]
-        rec = {u: s for u, s in zip(order, saved)}
-
         for (u1, u2, u3, ud) in reversed(blocks):
             s1, s2, s3 = rec[u1], rec[u2], rec[u3]
             dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True, residual=True)      # dz: gradient of the identity path
+            br = None
+            if ud is not None:
+                # the shortcut's backward (BN backward, weight gradient, input gradient) on the branch stream,
+                # under the main branch's three convolutions
+                sd = rec[ud]
+                br = branch_stream(dev, dz, sd.x, sd.a, sd.mean, sd.rstd)
+                with br:
+                    dxd = bn_back(ud, sd, dz, False)
+                    with wgrad_stream(dev, sd.a, dxd):
+                        grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
+                    dskip = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape)
             with wgrad_stream(dev, s3.a, dx3):
                 grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
             dy2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape)
@@ -376,13 +391,9 @@ class _ResNetFn(torch.autograd.Function):
             dx1 = bn_back(u1, s1, dy1, True)
             with wgrad_stream(dev, s1.a, dx1):
                 grads[u1][0] = _conv_wgrad(u1, s1.a, dx1)
-            if ud is not None:
-                sd = rec[ud]
-                dxd = bn_back(ud, sd, dz, False)
-                with wgrad_stream(dev, sd.a, dxd):
-                    grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
-                dmain = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape)
-                dcur = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape, residual=dmain)
+            if br is not None:
+                br.wait(dskip)
+                dcur = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=dskip)
             else:
                 dcur = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=dz)
         s0 = rec[stem]
@@ -390,6 +401,7 @@ class _ResNetFn(torch.autograd.Function):
         dx0 = bn_back(stem, s0, dstem, True)
         with wgrad_stream(dev, s0.a, dx0):
             grads[stem][0] = _conv_wgrad(stem, s0.a, dx0)  # no input gradient for the image
+        branch_stream.join(dev)           # fallback BN gradients of the shortcuts may have been allocated there
         wgrad_stream.join(dev)
 
         out = [None, None]

@@ -34,6 +34,12 @@ def layernorm_residual_fwd(x, y, gamma, beta, eps, p_drop=0.0, seed=0):
     return out, mean, rstd
 
 
+def _ws_key(device):
+    """Scratch buffers are per (device, stream): the same kernels run concurrently on the compute stream, the
+    weight-gradient side stream and the shortcut-branch stream (virtex_amd/streams.py)."""
+    return (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+
+
 _ln_ws = {}
 
 
@@ -44,10 +50,10 @@ def layernorm_residual_bwd(x, y, gamma, mean, rstd, dout, dgamma, dbeta, p_drop=
     _chk(x, "x"); _chk(y, "y", x.dtype); _chk(dout, "dout", x.dtype)
     dz = torch.empty_like(x)
     dy = torch.empty_like(x) if (y is not None and p_drop > 0.0) else None
-    ws = _ln_ws.get(x.device)
+    ws = _ln_ws.get(_ws_key(x.device))
     if ws is None or ws.numel() < 1024 * H:
         ws = torch.empty(1024 * max(H, 2048), dtype=torch.float32, device=x.device)
-        _ln_ws[x.device] = ws
+        _ln_ws[_ws_key(x.device)] = ws
     call("vtx_layernorm_residual_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(y), ptr(gamma),
          ptr(mean), ptr(rstd), ptr(dout), ptr(dz), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(rows),
          c_int(H), c_float(p_drop), c_u64(seed), stream_ptr(x))
@@ -64,10 +70,10 @@ STAT_WS_FLOATS = 8 * 1024 * 1024
 
 
 def stat_workspace(device):
-    ws = _stat_ws.get(device)
+    ws = _stat_ws.get(_ws_key(device))
     if ws is None:
         ws = torch.empty(STAT_WS_FLOATS if device.type == "cuda" else 1 << 20, dtype=torch.float32, device=device)
-        _stat_ws[device] = ws
+        _stat_ws[_ws_key(device)] = ws
     return ws
 
 
@@ -123,7 +129,7 @@ SPLITK_WS_FLOATS = 32 * 1024 * 1024      # 128 MB of fp32 partial sums per devic
 def splitk_workspace(device):
     """One scratch buffer per (device, stream): weight-gradient GEMMs may run on a side stream
     concurrently with the main stream's (virtex_amd/modules: `wgrad_stream`)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    key = _ws_key(device)
     ws = _splitk_ws.get(key)
     if ws is None:
         n = SPLITK_WS_FLOATS if device.type == "cuda" else 4 * 1024 * 1024
@@ -198,15 +204,15 @@ _bn_ws = {}
 
 
 def bn_workspace(device, C):
-    """fp32 scratch for the per-strip partial sums; one buffer per device, shared by every BN call
-    (calls are ordered on the stream)."""
+    """fp32 scratch for the per-strip partial sums; one buffer per (device, stream), shared by every BN call
+    issued on that stream (they are ordered there)."""
     lib = _lib.lib()
     lib.vtx_bn_workspace_floats.restype = _lib.ctypes.c_long
     need = lib.vtx_bn_workspace_floats(c_int(C))
-    ws = _bn_ws.get(device)
+    ws = _bn_ws.get(_ws_key(device))
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, lib.vtx_bn_workspace_floats(c_int(2048))), dtype=torch.float32, device=device)
-        _bn_ws[device] = ws
+        _bn_ws[_ws_key(device)] = ws
     return ws
 
 
@@ -499,10 +505,10 @@ _colsum_ws = {}
 def colsum_acc(x, out):
     assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
     C = x.shape[1]
-    ws = _colsum_ws.get(x.device)
+    ws = _colsum_ws.get(_ws_key(x.device))
     if ws is None or ws.numel() < 256 * C:
         ws = torch.empty(256 * max(C, 10000), dtype=torch.float32, device=x.device)
-        _colsum_ws[x.device] = ws
+        _colsum_ws[_ws_key(x.device)] = ws
     call("vtx_colsum_acc", c_int(dtype_code(x.dtype)), ptr(x), c_long(x.stride(0)), ptr(out), ptr(ws),
          c_int(x.shape[0]), c_int(C), stream_ptr(x))
     return out

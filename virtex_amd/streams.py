@@ -62,3 +62,66 @@ class wgrad_stream:
     def peek(device):
         """The side stream of `device` if one has been created (None otherwise)."""
         return _side_streams.get(device) if wgrad_stream.enabled else None
+
+
+_branch_streams = {}
+
+
+class branch_stream:
+    """Fork / join for work that is independent of the compute stream for a while: the projection shortcut of a
+    Bottleneck (1x1 conv + BatchNorm, and their backward) runs here while the three-conv main branch runs on the
+    compute stream -- HBM-bound BatchNorm passes of one branch under the MFMA-bound convolutions of the other.
+
+        br = branch_stream(device, *tensors_it_reads)
+        with br:            # side stream waits for the compute stream's work so far
+            y = ...
+        ...                 # compute stream carries on
+        br.wait(y)          # compute stream waits for the branch; y may now be used (and freed) there
+    """
+    enabled = os.environ.get("VIRTEX_AMD_BRANCH_STREAM", "1") != "0"
+
+    def __init__(self, device, *inputs):
+        self.device, self.inputs = device, inputs
+        self.active = branch_stream.enabled and device.type == "cuda"
+        self.done = None
+
+    @staticmethod
+    def side(device):
+        st = _branch_streams.get(device)
+        if st is None:
+            st = torch.cuda.Stream(device=device)
+            _branch_streams[device] = st
+        return st
+
+    def __enter__(self):
+        if self.active:
+            side = branch_stream.side(self.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            side.wait_event(ev)
+            for t in self.inputs:
+                if t is not None:
+                    t.record_stream(side)
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.done = torch.cuda.Event()
+            self.done.record(torch.cuda.current_stream(self.device))
+            self.ctx.__exit__(*exc)
+        return False
+
+    def wait(self, *outputs):
+        if self.active and self.done is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self.done)
+            for t in outputs:
+                if t is not None:
+                    t.record_stream(cur)
+
+    @staticmethod
+    def join(device):
+        if branch_stream.enabled and device.type == "cuda" and device in _branch_streams:
+            torch.cuda.current_stream(device).wait_stream(_branch_streams[device])
