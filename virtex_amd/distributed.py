@@ -29,7 +29,7 @@ from typing import List, Optional
 import torch
 import torch.distributed as dist
 
-from .streams import wgrad_stream
+from .streams import branch_stream, wgrad_stream
 
 
 def init_process_group(backend: Optional[str] = None) -> int:
@@ -159,6 +159,9 @@ class GradientBuckets:
                 self.side.wait_event(ev)
                 if wg is not None:              # weight gradients are produced on their own side stream
                     self.side.wait_stream(wg)
+                bs = branch_stream.peek(chunk.device)
+                if bs is not None:              # ... and one caption direction's backward runs on the branch stream
+                    self.side.wait_stream(bs)
                 self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
         else:
             self.handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
@@ -166,6 +169,7 @@ class GradientBuckets:
     def finish(self) -> float:
         """Wait for the outstanding collectives; returns the scale (1/world) the optimizer must
         apply to the summed gradients."""
+        branch_stream.join(self.flat.device)
         wgrad_stream.join(self.flat.device)
         if not self.enabled:
             return 1.0

@@ -17,7 +17,10 @@ from typing import Any, Dict
 import torch
 from torch import nn
 
+import os
+
 from . import ops
+from .streams import branch_stream
 from .modules.textual_heads import TextualHead, tied_projection_grads
 from .modules.visual_backbones import VisualBackbone
 
@@ -54,6 +57,10 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
         dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
         rW, rb = tied_projection_grads(d, h2, ctx.weight_param, ctx.bias_param)
         return dh, rW, rb, None, None
+
+
+# the two caption directions on two streams (A/B switch; see DESIGN.md, Streams)
+HEAD_STREAMS = os.environ.get("VIRTEX_AMD_HEAD_STREAMS", "1") != "0"
 
 
 class CaptioningModel(nn.Module):
@@ -108,7 +115,12 @@ class CaptioningModel(nn.Module):
         if "caption_tokens" in batch:
             caption_tokens = batch["caption_tokens"]
             caption_lengths = batch["caption_lengths"]
+            br = None
             if self.training:
+                if self.caption_backward and HEAD_STREAMS:
+                    # the two heads are independent until their losses are added: the backward-captioning head runs
+                    # on the branch stream (autograd replays each node on the stream its forward ran on)
+                    br = branch_stream(visual_features.device, visual_features, batch["noitpac_tokens"], caption_lengths).mark()
                 loss = self._head_loss(self.textual, visual_features, caption_tokens, caption_lengths)
             else:
                 output_logits = self.textual(visual_features, caption_tokens, caption_lengths)
@@ -117,7 +129,12 @@ class CaptioningModel(nn.Module):
                 "loss": loss, "loss_components": {"captioning_forward": loss.clone().detach()}}
             if self.caption_backward:
                 backward_caption_tokens = batch["noitpac_tokens"]
-                if self.training:
+                if self.training and br is not None:
+                    with br:
+                        backward_loss = self._head_loss(self.backward_textual, visual_features,
+                                                        backward_caption_tokens, caption_lengths)
+                    br.wait(backward_loss)
+                elif self.training:
                     backward_loss = self._head_loss(self.backward_textual, visual_features,
                                                     backward_caption_tokens, caption_lengths)
                 else:

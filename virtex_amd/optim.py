@@ -16,7 +16,7 @@ from typing import Iterable, List, Tuple
 
 import torch
 
-from .streams import wgrad_stream
+from .streams import branch_stream, wgrad_stream
 
 NO_DECAY = r".*textual.(embedding|transformer).*(norm.*|bias)"
 
@@ -66,6 +66,7 @@ class PretrainOptimizer:
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         """`grad_scale` multiplies every gradient first (1/world_size after a SUM all-reduce)."""
+        branch_stream.join(self.params[0].device)
         wgrad_stream.join(self.params[0].device)
         grads = [p.grad for p in self.params]
         if grad_scale != 1.0:
@@ -187,6 +188,7 @@ class FusedPretrainOptimizer:
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         g = self.buckets.flat
+        branch_stream.join(g.device)
         wgrad_stream.join(g.device)
         if self.clip_norm:
             self.ops.sumsq(g, self.partials, self.sumsq)

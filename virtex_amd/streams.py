@@ -84,6 +84,15 @@ class branch_stream:
         self.device, self.inputs = device, inputs
         self.active = branch_stream.enabled and device.type == "cuda"
         self.done = None
+        self.start = None
+
+    def mark(self):
+        """Fix the fork point NOW (the branch will wait for the compute stream's work up to here, not up to
+        the later `with`): lets the caller enqueue the compute stream's share first."""
+        if self.active:
+            self.start = torch.cuda.Event()
+            self.start.record(torch.cuda.current_stream(self.device))
+        return self
 
     @staticmethod
     def side(device):
@@ -96,8 +105,10 @@ class branch_stream:
     def __enter__(self):
         if self.active:
             side = branch_stream.side(self.device)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            ev = self.start
+            if ev is None:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
             side.wait_event(ev)
             for t in self.inputs:
                 if t is not None:
@@ -125,3 +136,7 @@ class branch_stream:
     def join(device):
         if branch_stream.enabled and device.type == "cuda" and device in _branch_streams:
             torch.cuda.current_stream(device).wait_stream(_branch_streams[device])
+
+    @staticmethod
+    def peek(device):
+        return _branch_streams.get(device) if branch_stream.enabled else None
