@@ -81,12 +81,14 @@ int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, con
                     void* stream);
 
 /* ---- per-launch timing of the contraction kernels (bench.py roofline leg) ----------------
- * Between vtx_profile_start() and vtx_profile_stop() every contraction-kernel launch is bracketed by two
- * HIP events on its own stream.  stop() synchronises the device and returns the number of kernel classes
+ * Between vtx_profile_start() and vtx_profile_stop() every contraction-kernel launch carries a start and a stop
+ * HIP event (hipExtLaunchKernel: the dispatch's own begin / end timestamps, i.e. what rocprofv3 reports).  stop() synchronises the device and returns the number of kernel classes
  * (one per template instantiation launched so far); vtx_profile_get() reads a class: its name (the
  * instantiation's template arguments, as rocprofv3 prints them), launches, summed seconds, algorithmic
  * FLOPs (2*M*N*K) and algorithmic bytes (operand tensors + output, each once).  No reference counterpart:
- * measurement infrastructure. */
+ * measurement infrastructure.  vtx_profile_select(c) restricts the timing to class c: two events per launch cost
+ * ~4 us of stream time each, so timing only the class of interest perturbs the multi-stream step far less. */
+int vtx_profile_select(int cls);   /* -1: time every class (default); >= 0: only that class */
 int vtx_profile_start(void);
 int vtx_profile_stop(void);
 int vtx_profile_get(int cls, char* name, int name_len, long* launches, double* seconds, double* flops,

@@ -216,12 +216,17 @@ inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess
 struct hipemuEvent { double t; };
 typedef hipemuEvent* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemuEvent{0.0}; return hipSuccess; }
+enum { hipEventReleaseToDevice = 0x40000000 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
     e->t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return hipSuccess;
 }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((b->t - a->t) * 1e3); return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+#define hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0, e1, flags, ...) \
+    do { hipEventRecord((e0), (stream)); hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); }); \
+         hipEventRecord((e1), (stream)); } while (0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_nontemporal_load(p) (*(p))

@@ -41,11 +41,13 @@ extern "C" int vtx_set_tile_override(int c) { vtxg::g_vtx_tile_override = c; ret
 
 // ---------------------------------------------------------------------------------------
 // Per-launch timing of the contraction kernels (bench.py's roofline leg): while profiling is on, every
-// launch is bracketed by two HIP events ON ITS OWN STREAM; vtx_profile_stop synchronises the device and
-// sums launches / seconds / algorithmic FLOPs / algorithmic bytes per kernel instantiation.
+// launch carries a start and a stop HIP event (hipExtLaunchKernel: the dispatch's own begin / end
+// timestamps); vtx_profile_stop synchronises the device and sums launches / seconds / algorithmic FLOPs /
+// algorithmic bytes per kernel instantiation.
 // ---------------------------------------------------------------------------------------
 namespace vtxg {
 int g_vtx_prof_on = 0;
+int g_vtx_prof_only = -1;     // >= 0: only this class is timed (fewer events perturb the step less)
 namespace {
 struct ProfClass { std::string name; long launches = 0; double seconds = 0, flops = 0, bytes = 0; };
 struct ProfRec { hipEvent_t a, b; int cls; double flops, bytes; };
@@ -53,10 +55,11 @@ std::mutex g_prof_mu;
 std::vector<ProfClass> g_prof_classes;
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
-thread_local int t_prof_open = -1;     // index of the record opened by this thread's last begin()
 hipEvent_t prof_event() {
     if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    // device-scope release: a default event ends the kernel with a system-scope L2 write-back, which is exactly the
+    // perturbation a per-launch timer must not add
+    hipEvent_t e; hipEventCreateWithFlags(&e, hipEventReleaseToDevice); return e;
 }
 }  // namespace
 int vtx_prof_register(const char* pretty) {
@@ -67,20 +70,15 @@ int vtx_prof_register(const char* pretty) {
     g_prof_classes.push_back(c);
     return (int)g_prof_classes.size() - 1;
 }
-void vtx_prof_begin(int cls, double flops, double bytes, hipStream_t st) {
+void vtx_prof_events(int cls, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{prof_event(), prof_event(), cls, flops, bytes};
-    hipEventRecord(r.a, st);
     g_prof_recs.push_back(r);
-    t_prof_open = (int)g_prof_recs.size() - 1;
-}
-void vtx_prof_end(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (t_prof_open >= 0 && t_prof_open < (int)g_prof_recs.size()) hipEventRecord(g_prof_recs[t_prof_open].b, st);
-    t_prof_open = -1;
+    *start = r.a; *stop = r.b;
 }
 }  // namespace vtxg
 
+extern "C" int vtx_profile_select(int cls) { vtxg::g_vtx_prof_only = cls; return VTX_OK; }
 extern "C" int vtx_profile_start(void) {
     using namespace vtxg;
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -19,6 +19,7 @@
 //               gradients; transposed into the LDS tile on store)
 #pragma once
 #include "vtx_common.h"
+#include <hip/hip_ext.h>
 
 namespace vtxg {
 
@@ -820,11 +821,10 @@ inline void launch_v1(const AL& al, const BL& bl, const EP& ep, int M, int N, in
 }
 
 // ---- optional per-launch timing (vtx_profile_start / vtx_profile_stop in core.hip): one class per kernel
-// instantiation, HIP events on the launch stream around every launch, algorithmic FLOPs and bytes summed.
-extern int g_vtx_prof_on;
+// instantiation, begin/end HIP events attached to every launch, algorithmic FLOPs and bytes summed.
+extern int g_vtx_prof_on, g_vtx_prof_only;
 int vtx_prof_register(const char* pretty_name);
-void vtx_prof_begin(int cls, double flops, double bytes, hipStream_t st);
-void vtx_prof_end(hipStream_t st);
+void vtx_prof_events(int cls, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop);
 // elements of the operand tensor a loader reads (the tensor itself, not its im2col view)
 template <class T, int SL> inline double algo_elems(const PlainKC<T, SL>& l) { return (double)l.rows * l.K; }
 template <class T, int SL> inline double algo_elems(const PlainMC<T, SL>& l) { return (double)l.rows * l.K; }
@@ -854,13 +854,21 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int
         attr_set = true;
     }
     dim3 grid(tiles_m * tiles_n, split_k), block(64 * WM * WN);
-    const bool prof = g_vtx_prof_on != 0;
+    bool prof = g_vtx_prof_on != 0;
     if (prof) {
         static const int cls = vtx_prof_register(__PRETTY_FUNCTION__);
-        vtx_prof_begin(cls, 2.0 * M * N * K, 2.0 * (algo_elems(al) + algo_elems(bl)) + epi_bytes(ep, (double)M * N, split_k), st);
+        prof = g_vtx_prof_only < 0 || g_vtx_prof_only == cls;     // optionally time one kernel class only
+        if (prof) {
+            // the launch itself carries the two events: they take the dispatch's own begin / end timestamps (what
+            // rocprofv3 reports), not the stream-order times around it -- with three streams sharing the chip a
+            // kernel often waits for CUs after its predecessor on the stream has finished
+            hipEvent_t e0, e1;
+            vtx_prof_events(cls, 2.0 * M * N * K, 2.0 * (algo_elems(al) + algo_elems(bl)) + epi_bytes(ep, (double)M * N, split_k), &e0, &e1);
+            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds_bytes, st, e0, e1, 0, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
+            return tiles_m * WM;
+        }
     }
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
-    if (prof) vtx_prof_end(st);
     return tiles_m * WM;    // number of statistics strips (rows of waves) this launch produced
 }
 

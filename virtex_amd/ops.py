@@ -546,7 +546,9 @@ def sgd_lookahead_step(p, g, m, slow, chunk_off, chunk_len, chunk_seg, seg_lr, s
 
 # ---------------------------------------------------------------------------------------
 # per-launch timing of the contraction kernels (bench.py's roofline leg)
-def profile_start():
+def profile_start(only_class=-1):
+    """only_class: index (the "cls" field of profile_stop()'s records) of the one kernel class to time, -1 = all."""
+    call("vtx_profile_select", c_int(only_class))
     call("vtx_profile_start")
 
 
@@ -565,6 +567,6 @@ def profile_stop():
         call("vtx_profile_get", c_int(i), name, c_int(512), ctypes.byref(launches), ctypes.byref(sec),
              ctypes.byref(fl), ctypes.byref(by))
         if launches.value:
-            out.append({"name": name.value.decode(), "launches": launches.value, "seconds": sec.value,
+            out.append({"cls": i, "name": name.value.decode(), "launches": launches.value, "seconds": sec.value,
                         "flops": fl.value, "bytes": by.value})
     return out
