@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=3,
                     help="steps run with per-launch HIP events (after the timed region) for the roofline object")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run everything on the compute stream (no weight-gradient / branch streams): the kernel-trace of "
+                         "this mode shows every kernel un-contended, which is what the roofline object reports")
     ap.add_argument("--roofline-live", action="store_true",
                     help="take the per-launch events inside the timed region itself (adds the event overhead to `value`)")
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -62,9 +65,9 @@ def device_batch(B, dev, seed):
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v7.txt.
-TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v7.txt: (2 x 70.03e3 + 113.7e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false>, 32, 3>": 2.598e8,
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v8.txt.
+TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v8.txt: (2 x 75.64e3 + 113.8e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false>, 32, 3>": 2.714e8,
 }
 
 
@@ -165,8 +168,18 @@ def cpu_baseline(batch, steps, budget_s=40.0):
                       f"thread count calibrated over 16..{ncpu} logical CPUs"}
 
 
+def set_streams(concurrent: bool):
+    """Turn the side streams of the step on / off at run time (virtex_amd/streams.py, models.HEAD_STREAMS)."""
+    from virtex_amd import models, streams
+    streams.wgrad_stream.enabled = concurrent
+    streams.branch_stream.enabled = concurrent
+    models.HEAD_STREAMS = concurrent
+
+
 def main():
     a = parse()
+    if a.serial_streams:
+        set_streams(False)
     from virtex_amd import distributed as vd
     import virtex_amd.factories as vf
     from virtex_amd.optim import FusedPretrainOptimizer
@@ -253,9 +266,13 @@ def main():
                 rec["roofline"] = step_roofline(live_recs, a.dtype, default_workload)
                 rec["roofline"]["measured"] = "inside the timed region"
             else:
+                # The roofline is about the kernel, so it is timed WITHOUT co-running kernels: the side streams are
+                # switched off for these steps (same kernels, same shapes, same order, one stream).
                 # pass 1 (one step, every contraction launch timed): which kernel class dominates, and the totals;
-                # pass 2 (roofline_steps steps, ONLY that class timed: ~10x fewer events, so the three streams of
-                # the step overlap as in the timed region): its per-launch duration
+                # pass 2 (roofline_steps steps, only that class timed): its per-launch duration;
+                # pass 3 (streams back on, same class): what the same launches take while sharing the chip.
+                set_streams(False)
+                step(0)
                 ops.profile_start()
                 step(0)
                 survey = ops.profile_stop()
@@ -264,10 +281,21 @@ def main():
                 for i in range(a.roofline_steps):
                     step(i)
                 focused = [r for r in ops.profile_stop() if r["cls"] == dom["cls"]]
+                concurrent = None
+                if not a.serial_streams:
+                    set_streams(True)
+                    step(0)
+                    ops.profile_start(only_class=dom["cls"])
+                    for i in range(a.roofline_steps):
+                        step(i)
+                    concurrent = [r for r in ops.profile_stop() if r["cls"] == dom["cls"]]
                 ops.profile_start(only_class=-1); ops.profile_stop()
                 rec["roofline"] = step_roofline(survey, a.dtype, default_workload, focused[0] if focused else None)
-                rec["roofline"]["measured"] = (f"{a.roofline_steps} further steps right after the timed region, HIP events "
-                                               "around this kernel class only (class chosen from one fully timed step)")
+                rec["roofline"]["measured"] = (f"{a.roofline_steps} further steps right after the timed region, side streams off, begin/end "
+                                               "HIP events on this kernel class only (class chosen from one fully timed step)")
+                if concurrent:
+                    c = concurrent[0]
+                    rec["roofline"]["concurrent_avg_launch_us"] = round(c["seconds"] / c["launches"] * 1e6, 1)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps)
         print(json.dumps(rec), flush=True)
