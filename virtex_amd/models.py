@@ -61,6 +61,10 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
 
 # the two caption directions on two streams (A/B switch; see DESIGN.md, Streams)
 HEAD_STREAMS = os.environ.get("VIRTEX_AMD_HEAD_STREAMS", "1") != "0"
+if HEAD_STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    # gradients of the backward-captioning head are produced on the branch stream on purpose; autograd's
+    # AccumulateGrad nodes synchronise with it correctly, the warning is only about that extra synchronisation
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 
 
 class CaptioningModel(nn.Module):
