@@ -155,6 +155,13 @@ int vtx_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* argmax, void*
 /* ---- layout / precision preparation -------------------------------------------------- */
 int vtx_image_to_nhwc(int dtype, const float* src_nchw, void* dst_nhwc, int N, int Cin, int H, int W,
                       int Cpad, void* stream);
+/* uint8 [N][Hs][Ws][3] decoded images -> normalised NHWC (dtype), channels zero-padded to Cpad, with a per-image crop
+ * window (crop_xy[n] = {x0, y0}, nullable = {0,0}) and horizontal flip (flip[n] != 0, nullable): fuses
+ * albumentations.Normalize(mean, std, max_pixel_value=255) + crop + flip + HWC->NHWC of the reference's CPU pipeline
+ * (virtex/data/transforms.py:85-97, virtex/data/datasets/captioning.py:61-64) into the stem's input conversion;
+ * mean/std are host pointers to 3 floats in [0,1] units. */
+int vtx_image_u8_to_nhwc(int dtype, const uint8_t* src, void* dst, int N, int Hs, int Ws, int H, int W, int Cpad,
+                         const int* crop_xy, const uint8_t* flip, const float* mean, const float* std, void* stream);
 int vtx_weight_prep(int dtype, const float* w32 /*[KO][T][C]*/, void* w /*[KO][T][Cp] or NULL*/,
                     void* wt /*[Cp][T][KO] or NULL*/, int KO, int T, int C, int Cp, void* stream);
 /* every weight of the step in one launch: descs[i] (device memory) describes one vtx_weight_prep; tile_start[i]

@@ -557,3 +557,32 @@ def test_batched_weight_preparation_and_cache(backend, dtype):
     # the transposed copy of the stem was not asked for at first: asking later computes just that
     w, wt = ops.prepped(stem, dtype, cpad=8, want_wt=True)
     assert wt is not None and wt.shape == (8, 49, 16)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_image_u8_preprocessing(backend, dtype):
+    """uint8 HWC -> normalised NHWC: albumentations.Normalize's closed form ((x - 255*mean) * (1/(255*std)), fp32) +
+    crop window + horizontal flip + channel padding (reference pipeline: transforms.py:85-97, captioning.py:61-64)."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(11)
+    N, Hs, Ws, size, cpad = 3, 20, 26, 16, 8
+    img = torch.randint(0, 256, (N, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    crop = torch.tensor([[0, 0], [10, 4], [3, 2]], dtype=torch.int32)
+    flip = torch.tensor([0, 1, 1], dtype=torch.uint8)
+    mean = torch.tensor(ops.IMAGENET_COLOR_MEAN); std = torch.tensor(ops.IMAGENET_COLOR_STD)
+    out = ops.image_u8_to_nhwc(img.to(dev), dtype, cpad, size=size, crop_xy=crop.to(dev), flip=flip.to(dev))
+    ref = torch.zeros(N, size, size, cpad)
+    for n in range(N):
+        x0, y0 = crop[n].tolist()
+        win = img[n, y0:y0 + size, x0:x0 + size].float()
+        if flip[n]:
+            win = win.flip(1)
+        ref[n, :, :, :3] = (win - 255.0 * mean) * (1.0 / (255.0 * std))
+    assert out.shape == (N, size, size, cpad) and out.dtype == dtype
+    if dtype == torch.float32:
+        assert torch.equal(out.cpu(), ref)                       # same fp32 expression: exact
+    else:
+        assert torch.equal(out.cpu(), ref.to(torch.bfloat16))    # one rounding to bf16
+    full = ops.image_u8_to_nhwc(img.to(dev), dtype, cpad)        # no crop / flip: whole image
+    assert full.shape == (N, Hs, Ws, cpad) and torch.equal(full[..., 3:].cpu(), torch.zeros(N, Hs, Ws, cpad - 3, dtype=dtype))

@@ -329,3 +329,21 @@ def test_eval_after_fused_training_steps_sees_updated_weights_and_statistics_emu
 @pytest.mark.gpu
 def test_eval_after_fused_training_steps_sees_updated_weights_and_statistics_gpu():
     _train_then_eval(select("gpu"))
+
+
+@pytest.mark.emu
+def test_uint8_image_batches_are_normalised_on_the_device_emulator():
+    """The backbone accepts decoder output directly: uint8 (B,H,W,3) gives the same features as the reference's
+    wire format (float CHW, normalised on the CPU with ImageNet mean/std)."""
+    from virtex_amd import ops
+    dev = select("emu")
+    _, model, _ = _build_pair("r50_l2_h128_b3_small", dev, torch.float32)
+    model.eval()
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (2, 64, 64, 3), generator=g, dtype=torch.uint8)
+    mean = torch.tensor(ops.IMAGENET_COLOR_MEAN); std = torch.tensor(ops.IMAGENET_COLOR_STD)
+    chw = ((u8.float() - 255.0 * mean) * (1.0 / (255.0 * std))).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        a = model.visual(u8.to(dev))
+        b = model.visual(chw.to(dev))
+    assert torch.equal(a.cpu(), b.cpu())

@@ -111,6 +111,30 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
     }
 }
 
+// uint8 HWC pixels (what an image decoder produces) -> normalised NHWC in the compute dtype, channels padded:
+//   dst[n][y][x][c] = (src[n][y0+y][xs][c] - 255*mean[c]) * (1 / (255*std[c])),  xs = flip ? x0+W-1-x : x0+x
+// i.e. albumentations.Normalize(mean, std, max_pixel_value=255) (reference: virtex/data/transforms.py:85-97) fused
+// with the crop window, the horizontal flip and the layout change; the batch crosses PCIe as 1 byte per value.
+template <class T>
+__global__ __launch_bounds__(256) void image_u8_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int N, int Hs,
+                                                       int Ws, int H, int W, int Cp, const int* __restrict__ crop_xy,
+                                                       const uint8_t* __restrict__ flip, float m0, float m1, float m2,
+                                                       float r0, float r1, float r2) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / ((long)H * W));
+        const int rem = (int)(i - (long)n * H * W);
+        const int y = rem / W, x = rem - y * W;
+        const int x0 = crop_xy ? crop_xy[2 * n] : 0, y0 = crop_xy ? crop_xy[2 * n + 1] : 0;
+        const int xs = (flip && flip[n]) ? x0 + W - 1 - x : x0 + x;
+        const uint8_t* p = src + (((long)n * Hs + (y0 + y)) * Ws + xs) * 3;
+        const float v0 = ((float)p[0] - m0) * r0, v1 = ((float)p[1] - m1) * r1, v2 = ((float)p[2] - m2) * r2;
+        T* o = dst + i * Cp;
+        Elem<T>::st(o, v0); Elem<T>::st(o + 1, v1); Elem<T>::st(o + 2, v2);
+        for (int c = 3; c < Cp; ++c) Elem<T>::st(o + c, 0.f);
+    }
+}
+
 static int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -186,6 +210,25 @@ extern "C" int vtx_weight_prep_batched(int dtype, const VtxPrepDesc* descs, cons
     else if (dtype == VTX_F32)
         hipLaunchKernelGGL((weight_prep_batched_kernel<float>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs, tile_start, ndesc);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "weight_prep_batched: bad dtype");
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+extern "C" int vtx_image_u8_to_nhwc(int dtype, const uint8_t* src, void* dst, int N, int Hs, int Ws, int H, int W, int Cpad,
+                                    const int* crop_xy, const uint8_t* flip, const float* mean, const float* std,
+                                    void* stream) {
+    VTX_CHECK(src && dst && mean && std, VTX_ERR_ARG, "image_u8_to_nhwc: null pointer");
+    VTX_CHECK(N > 0 && H > 0 && W > 0 && Hs >= H && Ws >= W && Cpad >= 3, VTX_ERR_SHAPE, "image_u8_to_nhwc: bad shape");
+    const float m0 = 255.f * mean[0], m1 = 255.f * mean[1], m2 = 255.f * mean[2];
+    const float r0 = 1.f / (255.f * std[0]), r1 = 1.f / (255.f * std[1]), r2 = 1.f / (255.f * std[2]);
+    const long total = (long)N * H * W;
+    if (dtype == VTX_BF16)
+        hipLaunchKernelGGL((image_u8_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                           N, Hs, Ws, H, W, Cpad, crop_xy, flip, m0, m1, m2, r0, r1, r2);
+    else if (dtype == VTX_F32)
+        hipLaunchKernelGGL((image_u8_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
+                           N, Hs, Ws, H, W, Cpad, crop_xy, flip, m0, m1, m2, r0, r1, r2);
+    else VTX_CHECK(false, VTX_ERR_DTYPE, "image_u8_to_nhwc: bad dtype");
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -180,7 +180,7 @@ class TorchvisionVisualBackbone(VisualBackbone):
             return ops.conv2d_infer(a, w, bias, u.stride, u.pad, relu=relu, residual=residual)
 
         with torch.no_grad():
-            a0 = ops.image_to_nhwc(image.float().contiguous(), dt, STEM_CPAD)
+            a0 = _stem_input(image, dt)
             cur, _ = ops.maxpool_fwd(run(stem, a0, True))
             for (u1, u2, u3, ud) in blocks:
                 t = run(u2, run(u1, cur, True), True)
@@ -217,6 +217,17 @@ class TorchvisionVisualBackbone(VisualBackbone):
         for u in units:
             params += [u.conv.weight, u.bn.weight, u.bn.bias]
         return _ResNetFn.apply(image, self, *params)
+
+
+def _stem_input(image, dt):
+    """(B,3,H,W) float batches are the reference's wire format (already normalised on the CPU).  uint8 (B,H,W,3)
+    batches -- decoder output -- are normalised here, on the device, in the same kernel that changes the layout
+    (ImageNet mean/std as in virtex/data/transforms.py:85-97): a quarter of the PCIe bytes, no CPU float pass."""
+    if image.dtype == torch.uint8:
+        if image.dim() != 4 or image.shape[-1] != 3:
+            raise ValueError("uint8 image batches must be (B, H, W, 3)")
+        return ops.image_u8_to_nhwc(image.contiguous(), dt, STEM_CPAD)
+    return ops.image_to_nhwc(image.float().contiguous(), dt, STEM_CPAD)
 
 
 def _folded(u: _Unit, dtype, epoch: int = 0):
@@ -318,7 +329,7 @@ class _ResNetFn(torch.autograd.Function):
             rec[u] = s
             return y
 
-        a0 = ops.image_to_nhwc(image.float().contiguous(), dt, STEM_CPAD)
+        a0 = _stem_input(image, dt)
         y = run(stem, a0, True, first=True)
         pooled, argmax = ops.maxpool_fwd(y)
         cur = pooled

@@ -291,6 +291,32 @@ def weight_prep(w32, dtype, cpad=None, want_w=True, want_wt=True):
     return w, wt
 
 
+IMAGENET_COLOR_MEAN = (0.485, 0.456, 0.406)      # reference: virtex/data/transforms.py:85-89
+IMAGENET_COLOR_STD = (0.229, 0.224, 0.225)
+
+
+def image_u8_to_nhwc(images, dtype, cpad, size=None, crop_xy=None, flip=None, mean=IMAGENET_COLOR_MEAN,
+                     std=IMAGENET_COLOR_STD):
+    """uint8 (N, Hs, Ws, 3) -> normalised (N, H, W, cpad) in `dtype`; H = W = size (default: the whole image).
+    crop_xy: int32 (N, 2) window origins {x0, y0}; flip: uint8 (N,) horizontal-flip flags."""
+    assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[-1] == 3 and images.is_contiguous()
+    N, Hs, Ws, _ = images.shape
+    H = W = size if size is not None else None
+    if size is None:
+        H, W = Hs, Ws
+    if crop_xy is not None:
+        assert crop_xy.dtype == torch.int32 and tuple(crop_xy.shape) == (N, 2) and crop_xy.is_contiguous()
+    if flip is not None:
+        assert flip.dtype == torch.uint8 and tuple(flip.shape) == (N,)
+    out = torch.empty(N, H, W, cpad, dtype=dtype, device=images.device)
+    ctypes = _lib.ctypes
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    call("vtx_image_u8_to_nhwc", c_int(dtype_code(dtype)), ptr(images), ptr(out), c_int(N), c_int(Hs), c_int(Ws), c_int(H),
+         c_int(W), c_int(cpad), ptr(crop_xy), ptr(flip), m, sd, stream_ptr(images))
+    return out
+
+
 # ---- compute copies of the master weights, cached on the parameter until its version changes -----------
 def _w32_view(param):
     """fp32 master weight as [KO, T, C]: conv weights are stored (KO,R,S,C) physically (channels_last)."""
