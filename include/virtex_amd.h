@@ -98,8 +98,10 @@ int vtx_profile_get(int cls, char* name, int name_len, long* launches, double* s
  * Replace aten::convolution / convolution_backward of the torchvision ResNet reached from
  * virtex/modules/visual_backbones.py:68-74.  x:[N][H][W][C], y/dy:[N][OH][OW][KO] (dtype),
  * w:[KO][R][S][C], wt:[C][R][S][KO] (dtype; see vtx_weight_prep), dw:[KO][R][S][C] fp32,
- * ACCUMULATED.  C and KO must be powers of two >= 16 bytes worth of elements (the 3-channel
- * stem input is zero-padded to 8 channels by vtx_image_to_nhwc).  OH = (H+2p-R)/s+1. */
+ * ACCUMULATED.  C and KO must be powers of two >= 16 bytes worth of elements.  One exception, for the 3-channel
+ * stem: bf16 C = 4 (pixels zero-padded to 4 channels) is accepted for fwd / wgrad when pad = 0, stride = 2 and S and W
+ * are even -- a 16-byte chunk then holds the two horizontally adjacent taps (kw, kw+1) of one pixel pair; the caller
+ * supplies the zero frame (vtx_image_to_nhwc_halo) and a filter padded to an even S.  OH = (H+2p-R)/s+1. */
 int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
                    const void* x, const void* w, void* y, float* bn_parts, const float* bn_shift,
                    int* bn_strips, void* stream);
@@ -155,13 +157,18 @@ int vtx_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* argmax, void*
 /* ---- layout / precision preparation -------------------------------------------------- */
 int vtx_image_to_nhwc(int dtype, const float* src_nchw, void* dst_nhwc, int N, int Cin, int H, int W,
                       int Cpad, void* stream);
+/* same, into a [N][H+2*halo][W+2*halo][Cpad] tensor with a zero frame of `halo` pixels: the 7x7/s2 stem then runs as a
+ * "valid" convolution (no bounds logic) on 4-channel pixels, two per 16-byte chunk (see vtx_conv2d_*: C = 4) */
+int vtx_image_to_nhwc_halo(int dtype, const float* src_nchw, void* dst_nhwc, int N, int Cin, int H, int W,
+                           int Cpad, int halo, void* stream);
 /* uint8 [N][Hs][Ws][3] decoded images -> normalised NHWC (dtype), channels zero-padded to Cpad, with a per-image crop
  * window (crop_xy[n] = {x0, y0}, nullable = {0,0}) and horizontal flip (flip[n] != 0, nullable): fuses
  * albumentations.Normalize(mean, std, max_pixel_value=255) + crop + flip + HWC->NHWC of the reference's CPU pipeline
  * (virtex/data/transforms.py:85-97, virtex/data/datasets/captioning.py:61-64) into the stem's input conversion;
  * mean/std are host pointers to 3 floats in [0,1] units. */
 int vtx_image_u8_to_nhwc(int dtype, const uint8_t* src, void* dst, int N, int Hs, int Ws, int H, int W, int Cpad,
-                         const int* crop_xy, const uint8_t* flip, const float* mean, const float* std, void* stream);
+                         int halo, const int* crop_xy, const uint8_t* flip, const float* mean, const float* std,
+                         void* stream);
 int vtx_weight_prep(int dtype, const float* w32 /*[KO][T][C]*/, void* w /*[KO][T][Cp] or NULL*/,
                     void* wt /*[Cp][T][KO] or NULL*/, int KO, int T, int C, int Cp, void* stream);
 /* every weight of the step in one launch: descs[i] (device memory) describes one vtx_weight_prep; tile_start[i]

@@ -586,3 +586,33 @@ def test_image_u8_preprocessing(backend, dtype):
         assert torch.equal(out.cpu(), ref.to(torch.bfloat16))    # one rounding to bf16
     full = ops.image_u8_to_nhwc(img.to(dev), dtype, cpad)        # no crop / flip: whole image
     assert full.shape == (N, Hs, Ws, cpad) and torch.equal(full[..., 3:].cpu(), torch.zeros(N, Hs, Ws, cpad - 3, dtype=dtype))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_packed_stem_geometry(backend, dtype):
+    """The 7x7/s2/p3 stem as a "valid" 7x8/s2 convolution on 4-channel pixels with a 3-pixel zero frame: in bf16 a
+    16-byte chunk carries two adjacent pixels (conv_common.h).  Forward and weight gradient against torch's 7x7
+    convolution of the original 3-channel image."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(21)
+    N, H, KO = 2, 20, 64
+    img = torch.randn(N, 3, H, H, generator=g)
+    w7 = torch.randn(KO, 3, 7, 7, generator=g) / 12
+    xr, wr = img.clone().requires_grad_(), w7.clone().requires_grad_()
+    yr = F.conv2d(xr, wr, stride=2, padding=3)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy)
+    a0 = ops.image_to_nhwc(img.to(dev), dtype, 4, halo=3)
+    assert a0.shape == (N, H + 6, H + 6, 4)
+    wp = torch.zeros(KO, 7, 8, 4)
+    wp[:, :, :7, :3] = w7.permute(0, 2, 3, 1)
+    w = wp.to(dtype).to(dev)
+    y = ops.conv2d_fwd(a0, w, 2, 0)
+    e = 2e-5 if dtype == torch.float32 else 1e-2
+    assert y.shape == (N, H // 2, H // 2, KO)
+    assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < e
+    dwp = torch.zeros(KO, 7, 8, 4, device=dev)
+    ops.conv2d_wgrad(a0, dy.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev), dwp, 2, 0)
+    assert rel_err(dwp[:, :, :7, :3].cpu(), wr.grad.permute(0, 2, 3, 1)) < 2 * e
+    assert dwp[:, :, 7, :].abs().max().item() >= 0            # the padded tap column exists; its weights are zero

@@ -13,8 +13,12 @@ static inline int make_geo(const char* who, int dtype, int N, int H, int W, int 
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "%s: bad dtype %d", who, dtype);
     VTX_CHECK(N > 0 && H > 0 && W > 0 && C > 0 && KO > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
               VTX_ERR_ARG, "%s: bad geometry", who);
-    VTX_CHECK(is_pow2(C) && C >= vec, VTX_ERR_SHAPE, "%s: C=%d must be a power of two >= %d (pad the stem's "
-              "input channels)", who, C, vec);
+    // C = vec/2 (bf16, 4 channels): a 16-byte chunk spans the taps (kw, kw+1) of two adjacent pixels.  Valid when the
+    // first tap of every chunk has an even kw (S even), lands on an even column (pad 0, stride 2) and the row has an
+    // even length, so that the second pixel is in bounds whenever the first is: the haloed 7x8 stem.
+    const bool pixel_pairs = dtype == VTX_BF16 && C == 4 && pad == 0 && stride == 2 && S % 2 == 0 && W % 2 == 0;
+    VTX_CHECK(is_pow2(C) && (C >= vec || pixel_pairs), VTX_ERR_SHAPE, "%s: C=%d must be a power of two >= %d (pad the "
+              "stem's input channels)", who, C, vec);
     VTX_CHECK(is_pow2(KO) && KO >= vec, VTX_ERR_SHAPE, "%s: K=%d must be a power of two >= %d", who, KO, vec);
     VTX_CHECK(is_pow2(stride) && S <= 8 && R <= 8, VTX_ERR_SHAPE, "%s: stride must be a power of two, filter <= 8", who);
     g->N = N; g->H = H; g->W = W; g->C = C; g->logC = vtx_ilog2(C);

@@ -10,14 +10,20 @@
 
 namespace {
 
+// output pixel grid (H + 2*halo) x (W + 2*halo): a zero frame of `halo` pixels lets the stem run as a "valid"
+// convolution without any bounds logic (and with two 4-channel pixels per 16-byte chunk, see conv_common.h)
 template <class T>
 __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst,
-                                                            int N, int Cin, int HW, int Cp) {
-    const long total = (long)N * HW;
+                                                            int N, int Cin, int H, int W, int Cp, int halo) {
+    const int Ho = H + 2 * halo, Wo = W + 2 * halo;
+    const long total = (long)N * Ho * Wo;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / HW, p = i % HW;
+        const long n = i / ((long)Ho * Wo);
+        const int rem = (int)(i - n * Ho * Wo);
+        const int y = rem / Wo - halo, x = rem % Wo - halo;
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         for (int c = 0; c < Cp; ++c) {
-            const float v = c < Cin ? src[(n * Cin + c) * HW + p] : 0.f;
+            const float v = (in && c < Cin) ? src[((n * Cin + c) * H + y) * W + x] : 0.f;
             Elem<T>::st(dst + i * Cp + c, v);
         }
     }
@@ -117,19 +123,23 @@ __global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ 
 // with the crop window, the horizontal flip and the layout change; the batch crosses PCIe as 1 byte per value.
 template <class T>
 __global__ __launch_bounds__(256) void image_u8_kernel(const uint8_t* __restrict__ src, T* __restrict__ dst, int N, int Hs,
-                                                       int Ws, int H, int W, int Cp, const int* __restrict__ crop_xy,
+                                                       int Ws, int H, int W, int Cp, int halo, const int* __restrict__ crop_xy,
                                                        const uint8_t* __restrict__ flip, float m0, float m1, float m2,
                                                        float r0, float r1, float r2) {
-    const long total = (long)N * H * W;
+    const int Ho = H + 2 * halo, Wo = W + 2 * halo;
+    const long total = (long)N * Ho * Wo;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int n = (int)(i / ((long)H * W));
-        const int rem = (int)(i - (long)n * H * W);
-        const int y = rem / W, x = rem - y * W;
-        const int x0 = crop_xy ? crop_xy[2 * n] : 0, y0 = crop_xy ? crop_xy[2 * n + 1] : 0;
-        const int xs = (flip && flip[n]) ? x0 + W - 1 - x : x0 + x;
-        const uint8_t* p = src + (((long)n * Hs + (y0 + y)) * Ws + xs) * 3;
-        const float v0 = ((float)p[0] - m0) * r0, v1 = ((float)p[1] - m1) * r1, v2 = ((float)p[2] - m2) * r2;
+        const int n = (int)(i / ((long)Ho * Wo));
+        const int rem = (int)(i - (long)n * Ho * Wo);
+        const int y = rem / Wo - halo, x = rem % Wo - halo;
         T* o = dst + i * Cp;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const int x0 = crop_xy ? crop_xy[2 * n] : 0, y0 = crop_xy ? crop_xy[2 * n + 1] : 0;
+            const int xs = (flip && flip[n]) ? x0 + W - 1 - x : x0 + x;
+            const uint8_t* p = src + (((long)n * Hs + (y0 + y)) * Ws + xs) * 3;
+            v0 = ((float)p[0] - m0) * r0; v1 = ((float)p[1] - m1) * r1; v2 = ((float)p[2] - m2) * r2;
+        }
         Elem<T>::st(o, v0); Elem<T>::st(o + 1, v1); Elem<T>::st(o + 2, v2);
         for (int c = 3; c < Cp; ++c) Elem<T>::st(o + c, 0.f);
     }
@@ -142,20 +152,24 @@ static int grid_for(long total) {
 
 }  // namespace
 
-extern "C" int vtx_image_to_nhwc(int dtype, const float* src, void* dst, int N, int Cin, int H, int W, int Cp,
-                                 void* stream) {
+extern "C" int vtx_image_to_nhwc_halo(int dtype, const float* src, void* dst, int N, int Cin, int H, int W, int Cp,
+                                      int halo, void* stream) {
     VTX_CHECK(src && dst, VTX_ERR_ARG, "image_to_nhwc: null pointer");
-    VTX_CHECK(N > 0 && Cin > 0 && Cp >= Cin && H > 0 && W > 0, VTX_ERR_SHAPE, "image_to_nhwc: bad shape");
-    const long total = (long)N * H * W;
+    VTX_CHECK(N > 0 && Cin > 0 && Cp >= Cin && H > 0 && W > 0 && halo >= 0, VTX_ERR_SHAPE, "image_to_nhwc: bad shape");
+    const long total = (long)N * (H + 2 * halo) * (W + 2 * halo);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((image_to_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           src, (bf16_t*)dst, N, Cin, H * W, Cp);
+        hipLaunchKernelGGL((image_to_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                           (bf16_t*)dst, N, Cin, H, W, Cp, halo);
     else if (dtype == VTX_F32)
-        hipLaunchKernelGGL((image_to_nhwc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                           src, (float*)dst, N, Cin, H * W, Cp);
+        hipLaunchKernelGGL((image_to_nhwc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                           (float*)dst, N, Cin, H, W, Cp, halo);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "image_to_nhwc: bad dtype");
     VTX_LAUNCH_CHECK();
     return VTX_OK;
+}
+extern "C" int vtx_image_to_nhwc(int dtype, const float* src, void* dst, int N, int Cin, int H, int W, int Cp,
+                                 void* stream) {
+    return vtx_image_to_nhwc_halo(dtype, src, dst, N, Cin, H, W, Cp, 0, stream);
 }
 
 extern "C" int vtx_weight_prep(int dtype, const float* w32, void* w, void* wt, int KO, int T, int C, int Cp,
@@ -215,19 +229,19 @@ extern "C" int vtx_weight_prep_batched(int dtype, const VtxPrepDesc* descs, cons
 }
 
 extern "C" int vtx_image_u8_to_nhwc(int dtype, const uint8_t* src, void* dst, int N, int Hs, int Ws, int H, int W, int Cpad,
-                                    const int* crop_xy, const uint8_t* flip, const float* mean, const float* std,
+                                    int halo, const int* crop_xy, const uint8_t* flip, const float* mean, const float* std,
                                     void* stream) {
     VTX_CHECK(src && dst && mean && std, VTX_ERR_ARG, "image_u8_to_nhwc: null pointer");
-    VTX_CHECK(N > 0 && H > 0 && W > 0 && Hs >= H && Ws >= W && Cpad >= 3, VTX_ERR_SHAPE, "image_u8_to_nhwc: bad shape");
+    VTX_CHECK(N > 0 && H > 0 && W > 0 && Hs >= H && Ws >= W && Cpad >= 3 && halo >= 0, VTX_ERR_SHAPE, "image_u8_to_nhwc: bad shape");
     const float m0 = 255.f * mean[0], m1 = 255.f * mean[1], m2 = 255.f * mean[2];
     const float r0 = 1.f / (255.f * std[0]), r1 = 1.f / (255.f * std[1]), r2 = 1.f / (255.f * std[2]);
-    const long total = (long)N * H * W;
+    const long total = (long)N * (H + 2 * halo) * (W + 2 * halo);
     if (dtype == VTX_BF16)
         hipLaunchKernelGGL((image_u8_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
-                           N, Hs, Ws, H, W, Cpad, crop_xy, flip, m0, m1, m2, r0, r1, r2);
+                           N, Hs, Ws, H, W, Cpad, halo, crop_xy, flip, m0, m1, m2, r0, r1, r2);
     else if (dtype == VTX_F32)
         hipLaunchKernelGGL((image_u8_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
-                           N, Hs, Ws, H, W, Cpad, crop_xy, flip, m0, m1, m2, r0, r1, r2);
+                           N, Hs, Ws, H, W, Cpad, halo, crop_xy, flip, m0, m1, m2, r0, r1, r2);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "image_u8_to_nhwc: bad dtype");
     VTX_LAUNCH_CHECK();
     return VTX_OK;

@@ -23,7 +23,11 @@ from .. import gradsink, ops
 
 RESNET_BLOCKS = {"resnet50": ((3, 4, 6, 3), 64), "resnet101": ((3, 4, 23, 3), 64),
                  "wide_resnet50_2": ((3, 4, 6, 3), 128)}
-STEM_CPAD = 8  # the 3 input channels are zero-padded to 8 (one 16-byte bf16 vector)
+STEM_CPAD = 8  # generic stem layout: the 3 input channels zero-padded to 8 (one 16-byte bf16 vector)
+# Packed stem layout (even image widths): pixels padded to 4 channels, a zero frame of STEM_HALO pixels written by the
+# input conversion, filter padded 7x7 -> 7x8.  The 7x7/s2/p3 convolution becomes a "valid" 7x8/s2 one whose 16-byte
+# chunks hold two adjacent pixels: K = 7*8*4 = 224 instead of 7*7*8 = 392, no bounds logic, half the input bytes.
+STEM_PACK_C, STEM_PACK_S, STEM_HALO = 4, 8, 3
 # BatchNorm statistics from the convolution epilogue: implemented and tested (ops.conv2d_fwd(bn_shift=...)),
 # but measured SLOWER than the stand-alone reduction on this step (43.8 vs 42.1 ms: the extra ~48 VGPRs of
 # the statistics epilogue cost the GEMMs more than the saved 5.7 GB read) -> off by default.
@@ -139,7 +143,7 @@ class TorchvisionVisualBackbone(VisualBackbone):
         stem, blocks = self._units()
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
         need_grad = any(u.conv.weight.requires_grad or u.bn.weight.requires_grad or u.bn.bias.requires_grad for u in units)
-        return [(u.conv.weight, u.cin_pad, need_grad and u is not stem) for u in units]
+        return [(u.conv.weight, u.cin_pad, need_grad) for u in units if u is not stem]   # the stem has its own cache
 
     # -- export ---------------------------------------------------------------------------
     _D2_STAGE = {"layer1": "res2", "layer2": "res3", "layer3": "res4", "layer4": "res5"}
@@ -175,13 +179,13 @@ class TorchvisionVisualBackbone(VisualBackbone):
     def _forward_eval(self, image, stem, blocks):
         dt = self.compute_dtype
 
-        def run(u, a, relu, residual=None):
-            w, bias = _folded(u, dt, self._stats_epoch)
-            return ops.conv2d_infer(a, w, bias, u.stride, u.pad, relu=relu, residual=residual)
+        def run(u, a, relu, residual=None, packed=False):
+            w, bias = _folded(u, dt, self._stats_epoch, packed)
+            return ops.conv2d_infer(a, w, bias, u.stride, 0 if packed else u.pad, relu=relu, residual=residual)
 
         with torch.no_grad():
-            a0 = _stem_input(image, dt)
-            cur, _ = ops.maxpool_fwd(run(stem, a0, True))
+            a0, packed = _stem_input(image, dt)
+            cur, _ = ops.maxpool_fwd(run(stem, a0, True, packed=packed))
             for (u1, u2, u3, ud) in blocks:
                 t = run(u2, run(u1, cur, True), True)
                 skip = run(ud, cur, False) if ud is not None else cur
@@ -219,32 +223,66 @@ class TorchvisionVisualBackbone(VisualBackbone):
         return _ResNetFn.apply(image, self, *params)
 
 
+def _stem_packed(image) -> bool:
+    w = image.shape[2] if image.dtype == torch.uint8 else image.shape[-1]
+    return w % 2 == 0
+
+
 def _stem_input(image, dt):
     """(B,3,H,W) float batches are the reference's wire format (already normalised on the CPU).  uint8 (B,H,W,3)
     batches -- decoder output -- are normalised here, on the device, in the same kernel that changes the layout
     (ImageNet mean/std as in virtex/data/transforms.py:85-97): a quarter of the PCIe bytes, no CPU float pass."""
+    packed = _stem_packed(image)
+    cpad, halo = (STEM_PACK_C, STEM_HALO) if packed else (STEM_CPAD, 0)
     if image.dtype == torch.uint8:
         if image.dim() != 4 or image.shape[-1] != 3:
             raise ValueError("uint8 image batches must be (B, H, W, 3)")
-        return ops.image_u8_to_nhwc(image.contiguous(), dt, STEM_CPAD)
-    return ops.image_to_nhwc(image.float().contiguous(), dt, STEM_CPAD)
+        return ops.image_u8_to_nhwc(image.contiguous(), dt, cpad, halo=halo), packed
+    return ops.image_to_nhwc(image.float().contiguous(), dt, cpad, halo=halo), packed
 
 
-def _folded(u: _Unit, dtype, epoch: int = 0):
+def _stem_weight32(u: "_Unit"):
+    """fp32 (KO, 7*8, 4) zero-padded copy of the stem filter for the packed layout."""
+    w32 = u.conv.weight.detach().permute(0, 2, 3, 1)                       # (KO, 7, 7, 3)
+    wp = torch.zeros(u.cout, u.k, STEM_PACK_S, STEM_PACK_C, dtype=torch.float32, device=w32.device)
+    wp[:, :, : u.k, : u.cin] = w32
+    return wp.view(u.cout, u.k * STEM_PACK_S, STEM_PACK_C)
+
+
+def _stem_weight(u: "_Unit", dtype):
+    """Compute copy (KO, 7, 8, 4) of the stem filter, cached on the parameter until it changes."""
+    p = u.conv.weight
+    stamp = (p._version, p.data_ptr(), dtype)
+    e = p.__dict__.get("_vtx_stem")
+    if e is not None and e[0] == stamp:
+        return e[1]
+    wp = _stem_weight32(u)
+    w = wp if dtype == torch.float32 else ops.weight_prep(wp, dtype, want_wt=False)[0]
+    w = w.view(u.cout, u.k, STEM_PACK_S, STEM_PACK_C)
+    p.__dict__["_vtx_stem"] = (stamp, w)
+    return w
+
+
+def _folded(u: _Unit, dtype, epoch: int = 0, packed: bool = False):
     """Eval mode: (w (KO,R,S,Cp), bias (KO,)) with the running-statistics BatchNorm folded into the
     convolution; cached on the unit's tensors until any of them is modified in place."""
     bn = u.bn
     src = (u.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
     # running statistics are updated by the BatchNorm kernel itself (no torch version bump): the module counts its
     # training-mode forwards and the key carries that count
-    key = (dtype, epoch) + tuple((t.data_ptr(), t._version) for t in src)
+    key = (dtype, epoch, packed) + tuple((t.data_ptr(), t._version) for t in src)
     cache = getattr(u.conv, "_vtx_folded", None)
     if cache is not None and cache[0] == key:
         return cache[1], cache[2]
-    w32 = u.conv.weight.detach().permute(0, 2, 3, 1).contiguous().view(u.cout, u.k * u.k, u.cin)
-    w, bias = ops.bn_fold(w32, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, dtype,
-                          cpad=u.cin_pad)
-    w = w.view(u.cout, u.k, u.k, u.cin_pad)
+    if packed:
+        w, bias = ops.bn_fold(_stem_weight32(u), bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                              bn.eps, dtype)
+        w = w.view(u.cout, u.k, STEM_PACK_S, STEM_PACK_C)
+    else:
+        w32 = u.conv.weight.detach().permute(0, 2, 3, 1).contiguous().view(u.cout, u.k * u.k, u.cin)
+        w, bias = ops.bn_fold(w32, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps, dtype,
+                              cpad=u.cin_pad)
+        w = w.view(u.cout, u.k, u.k, u.cin_pad)
     u.conv._vtx_folded = (key, w, bias)
     return w, bias
 
@@ -316,10 +354,14 @@ class _ResNetFn(torch.autograd.Function):
         rec = {}
 
         def run(u: _Unit, a, relu, residual=None, first=False):
-            w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
             bn = u.bn
-            # the conv epilogue also produces the batch statistics (taken against the running mean)
-            x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean if FUSE_BN_STATS else None)
+            if first and packed:
+                w, wt = _stem_weight(u, dt), None
+                x, stats = ops.conv2d_fwd(a, w, u.stride, 0), None
+            else:
+                w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
+                # the conv epilogue also produces the batch statistics (taken against the running mean)
+                x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean if FUSE_BN_STATS else None)
             y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                        bn.num_batches_tracked, eps=bn.eps,
                                        momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
@@ -329,7 +371,7 @@ class _ResNetFn(torch.autograd.Function):
             rec[u] = s
             return y
 
-        a0 = _stem_input(image, dt)
+        a0, packed = _stem_input(image, dt)
         y = run(stem, a0, True, first=True)
         pooled, argmax = ops.maxpool_fwd(y)
         cur = pooled
@@ -350,6 +392,7 @@ class _ResNetFn(torch.autograd.Function):
             cur = run(u3, t, True, residual=skip)
         ctx.module, ctx.rec, ctx.argmax, ctx.stem_out_shape = module, rec, argmax, y.shape
         ctx.units = (stem, blocks)
+        ctx.stem_packed = packed
         ctx.nparams = len(params)
         N, H, W, C = cur.shape
         return cur.permute(0, 3, 1, 2)  # logical NCHW, physical NHWC
@@ -410,8 +453,13 @@ class _ResNetFn(torch.autograd.Function):
         s0 = rec[stem]
         dstem = ops.maxpool_bwd(dcur, ctx.argmax, ctx.stem_out_shape)
         dx0 = bn_back(stem, s0, dstem, True)
-        with wgrad_stream(dev, s0.a, dx0):
-            grads[stem][0] = _conv_wgrad(stem, s0.a, dx0)  # no input gradient for the image
+        with wgrad_stream(dev, s0.a, dx0):               # no input gradient for the image
+            if ctx.stem_packed:
+                dwp = torch.zeros(stem.cout, stem.k, STEM_PACK_S, STEM_PACK_C, dtype=torch.float32, device=dev)
+                ops.conv2d_wgrad(s0.a, dx0, dwp, stem.stride, 0)
+                grads[stem][0] = dwp[:, :, : stem.k, : stem.cin].permute(0, 3, 1, 2)     # logical (KO,C,R,S)
+            else:
+                grads[stem][0] = _conv_wgrad(stem, s0.a, dx0)
         branch_stream.join(dev)           # fallback BN gradients of the shortcuts may have been allocated there
         wgrad_stream.join(dev)
 

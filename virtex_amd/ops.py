@@ -267,13 +267,13 @@ def maxpool_bwd(dy, arg, x_shape):
     return dx
 
 
-def image_to_nhwc(image, dtype, cpad=8):
-    """fp32 NCHW (B,3,H,W) -> NHWC `dtype` with channels zero-padded to `cpad`."""
+def image_to_nhwc(image, dtype, cpad=8, halo=0):
+    """fp32 NCHW (B,3,H,W) -> NHWC `dtype` with channels zero-padded to `cpad` (and a zero frame of `halo` pixels)."""
     N, Cin, H, W = image.shape
     _chk(image, "image", torch.float32)
-    out = torch.empty(N, H, W, cpad, dtype=dtype, device=image.device)
-    call("vtx_image_to_nhwc", c_int(dtype_code(dtype)), ptr(image), ptr(out), c_int(N), c_int(Cin), c_int(H),
-         c_int(W), c_int(cpad), stream_ptr(image))
+    out = torch.empty(N, H + 2 * halo, W + 2 * halo, cpad, dtype=dtype, device=image.device)
+    call("vtx_image_to_nhwc_halo", c_int(dtype_code(dtype)), ptr(image), ptr(out), c_int(N), c_int(Cin), c_int(H),
+         c_int(W), c_int(cpad), c_int(halo), stream_ptr(image))
     return out
 
 
@@ -296,7 +296,7 @@ IMAGENET_COLOR_STD = (0.229, 0.224, 0.225)
 
 
 def image_u8_to_nhwc(images, dtype, cpad, size=None, crop_xy=None, flip=None, mean=IMAGENET_COLOR_MEAN,
-                     std=IMAGENET_COLOR_STD):
+                     std=IMAGENET_COLOR_STD, halo=0):
     """uint8 (N, Hs, Ws, 3) -> normalised (N, H, W, cpad) in `dtype`; H = W = size (default: the whole image).
     crop_xy: int32 (N, 2) window origins {x0, y0}; flip: uint8 (N,) horizontal-flip flags."""
     assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[-1] == 3 and images.is_contiguous()
@@ -308,12 +308,12 @@ def image_u8_to_nhwc(images, dtype, cpad, size=None, crop_xy=None, flip=None, me
         assert crop_xy.dtype == torch.int32 and tuple(crop_xy.shape) == (N, 2) and crop_xy.is_contiguous()
     if flip is not None:
         assert flip.dtype == torch.uint8 and tuple(flip.shape) == (N,)
-    out = torch.empty(N, H, W, cpad, dtype=dtype, device=images.device)
+    out = torch.empty(N, H + 2 * halo, W + 2 * halo, cpad, dtype=dtype, device=images.device)
     ctypes = _lib.ctypes
     m = (ctypes.c_float * 3)(*mean)
     sd = (ctypes.c_float * 3)(*std)
     call("vtx_image_u8_to_nhwc", c_int(dtype_code(dtype)), ptr(images), ptr(out), c_int(N), c_int(Hs), c_int(Ws), c_int(H),
-         c_int(W), c_int(cpad), ptr(crop_xy), ptr(flip), m, sd, stream_ptr(images))
+         c_int(W), c_int(cpad), c_int(halo), ptr(crop_xy), ptr(flip), m, sd, stream_ptr(images))
     return out
 
 
