@@ -65,9 +65,9 @@ def device_batch(B, dev, seed):
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v8.txt.
-TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v8.txt: (2 x 75.64e3 + 113.8e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false>, 32, 3>": 2.714e8,
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v9.txt.
+TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v9.txt: (2 x 74.02e3 + 113.7e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false>, 32, 3>": 2.680e8,
 }
 
 
