@@ -14,7 +14,7 @@ stream -- NHWC implicit-GEMM convolutions on MFMA, fused BatchNorm+ReLU(+residua
 torch supplies device memory and the autograd edge only.
 """
 import os
-from typing import List
+
 
 import torch
 from torch import nn
