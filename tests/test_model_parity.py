@@ -347,3 +347,19 @@ def test_uint8_image_batches_are_normalised_on_the_device_emulator():
         a = model.visual(u8.to(dev))
         b = model.visual(chw.to(dev))
     assert torch.equal(a.cpu(), b.cpu())
+
+
+@pytest.mark.emu
+def test_odd_image_width_uses_the_unpacked_stem_layout_emulator():
+    """Odd widths cannot use the two-pixels-per-chunk stem layout (the zero-framed row would have an odd length):
+    the backbone falls back to 8-channel pixels with in-kernel padding.  Train and eval forward against the oracle."""
+    dev = select("emu")
+    oracle_model, model, _ = _build_pair("r50_l2_h128_b3_small", dev, torch.float32)
+    image = synth.synthetic_batch(batch_size=2, image_size=63, max_len=8, vocab_size=1000, seed=9)["image"]
+    for mode in ("train", "eval"):
+        getattr(oracle_model, mode)(), getattr(model, mode)()
+        with torch.no_grad():
+            ref = oracle_model.visual(image)
+            out = model.visual(image.to(dev))
+        assert out.shape == ref.shape
+        assert rel_err(out.float().cpu(), ref) < 5e-4, mode      # 2x2x2 = 8 samples per channel in the last BatchNorms
