@@ -122,6 +122,7 @@ class GradientBuckets:
         if bcount:
             self.buckets.append((bstart, off, bcount))
         self.pending = [0] * len(self.buckets)
+        self.early = set()           # parameters announced by gradsink.mark_ready() in the current step
         self.handles = []
         self.world = world_size()
         self.side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
@@ -131,6 +132,8 @@ class GradientBuckets:
             # p.grad itself and returned None (virtex_amd/gradsink.py)
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+            from . import gradsink
+            gradsink.ready_callback = self._on_ready
         self.begin()
 
     # ---------------------------------------------------------------------------------
@@ -138,11 +141,23 @@ class GradientBuckets:
         """Call before each backward."""
         self.pending = [c for (_, _, c) in self.buckets]
         self.handles = []
+        self.early = set()
 
     def zero(self):
         self.flat.zero_()
 
+    def _on_ready(self, p):
+        """gradsink.mark_ready: p's gradient kernels are enqueued (compute or weight-gradient stream)."""
+        if p in self.bucket_of and p not in self.early:
+            self.early.add(p)
+            self._count(p)
+
     def _on_grad(self, p):
+        if p in self.early:          # already counted when its backward function announced it
+            return
+        self._count(p)
+
+    def _count(self, p):
         b = self.bucket_of[p]
         self.pending[b] -= 1
         if self.pending[b] == 0:

@@ -25,3 +25,17 @@ def target(p: torch.nn.Parameter, shape=None):
         v = g.permute(0, 2, 3, 1)
         return v if (v.is_contiguous() and tuple(v.shape) == tuple(shape)) else None
     return g if (g.is_contiguous() and tuple(g.shape) == tuple(shape)) else None
+
+
+# A backward function that accumulates in place may tell the data-parallel engine "the gradient kernels of these
+# parameters are enqueued" long before autograd visits the parameters (the whole ResNet backward is ONE autograd
+# node: without this its 161 gradients would all become visible at its end and their all-reduce could not overlap
+# with it).  The engine installs the callback; with no engine this is a no-op.
+ready_callback = None
+
+
+def mark_ready(params):
+    """Only parameters whose gradient was accumulated IN PLACE (target() returned a buffer) may be announced."""
+    if ready_callback is not None:
+        for p in params:
+            ready_callback(p)

@@ -450,6 +450,11 @@ class _ResNetFn(torch.autograd.Function):
                 dcur = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=dskip)
             else:
                 dcur = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=dz)
+            # this block's gradient kernels are all enqueued: let the data-parallel engine start exchanging the
+            # buckets they complete while the rest of the backbone's backward runs
+            for u in (u3, u2, u1, ud):
+                if u is not None:
+                    gradsink.mark_ready([p for p, g in zip((u.conv.weight, u.bn.weight, u.bn.bias), grads[u]) if g is None])
         s0 = rec[stem]
         dstem = ops.maxpool_bwd(dcur, ctx.argmax, ctx.stem_out_shape)
         dx0 = bn_back(stem, s0, dstem, True)
