@@ -363,3 +363,29 @@ def test_odd_image_width_uses_the_unpacked_stem_layout_emulator():
             out = model.visual(image.to(dev))
         assert out.shape == ref.shape
         assert rel_err(out.float().cpu(), ref) < 5e-4, mode      # 2x2x2 = 8 samples per channel in the last BatchNorms
+
+
+@pytest.mark.emu
+@pytest.mark.parametrize("cnn", ["wide_resnet50_2", "resnet101"])
+def test_other_backbones_features_and_input_gradient_path_emulator(cnn):
+    """The reference's backbone ablations (configs/backbone_ablations: resnet101, wide_resnet50_2) through the same
+    hand-scheduled forward/backward: features vs the oracle in train mode, and a finite, oracle-like loss gradient
+    on a text-side tensor after a full backward through the wider / deeper backbone."""
+    dev = select("emu")
+    kw = dict(visual=f"torchvision::{cnn}", textual="transdec_postnorm::L1_H128_A2_F256", vocab_size=300)
+    oracle_model = synth.seeded_model(port.build_model, seed=0, dropout=0.0, **kw).train()
+    model = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=torch.float32, max_caption_length=30, **kw)
+    missing = model.load_state_dict(oracle_model.state_dict())
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model = model.to(dev).train()
+    batch = synth.synthetic_batch(batch_size=3, image_size=64, max_len=8, vocab_size=300, seed=4, ragged=True)
+    with torch.no_grad():
+        ref = oracle_model.visual(batch["image"])
+        out = model.visual(batch["image"].to(dev))
+    assert out.shape == ref.shape and rel_err(out.float().cpu(), ref) < 2e-3     # 12 samples per channel in the last stage
+    oo = oracle_model(batch); oo["loss"].backward()
+    mo = model({k: v.to(dev) for k, v in batch.items()}); mo["loss"].backward()
+    assert abs(mo["loss"].item() - oo["loss"].item()) < 1e-4 * abs(oo["loss"].item())
+    a, b = model.textual.visual_projection.weight.grad.cpu(), oracle_model.textual.visual_projection.weight.grad
+    assert rel_err(a, b) < 5e-3
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
