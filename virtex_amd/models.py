@@ -159,20 +159,21 @@ class CaptioningModel(nn.Module):
         return output_dict
 
     def decoding_step(self, visual_features: torch.Tensor, partial_captions: torch.Tensor) -> torch.Tensor:
-        """Next-token logits for (possibly beam-expanded) partial captions
-        (reference: captioning.py:165-213)."""
-        batch_size, channels, height, width = visual_features.size()
-        beam_size = int(partial_captions.size(0) / batch_size)
-        if beam_size > 1:
-            visual_features = visual_features.unsqueeze(1).repeat(1, beam_size, 1, 1, 1)
-            visual_features = visual_features.view(batch_size * beam_size, channels, height, width)
-        caption_lengths = torch.ones_like(partial_captions)
-        if len(caption_lengths.size()) == 2:
-            caption_lengths = caption_lengths.sum(1)
+        """Next-token logits (N*beam, V) for the prefixes decoded so far -- the step function the caption decoders
+        call (reference semantics: captioning.py:165-213).  The whole prefix is re-run through the text head; the
+        lengths passed are the prefix length, whatever [EOS] / padding it already contains; a 1-D argument is the
+        first step (one token per image)."""
+        n_img = visual_features.size(0)
+        if partial_captions.dim() == 1:
+            prefix, lengths = partial_captions.unsqueeze(1), torch.ones_like(partial_captions)
         else:
-            partial_captions = partial_captions.unsqueeze(1)
-        logits = self.textual(visual_features, partial_captions, caption_lengths)
-        return logits[:, -1, :]
+            prefix = partial_captions
+            lengths = torch.full((prefix.size(0),), prefix.size(1), dtype=prefix.dtype, device=prefix.device)
+        beams = prefix.size(0) // n_img
+        if beams > 1:       # every beam of an image attends to that image's grid
+            visual_features = visual_features.unsqueeze(1).expand(-1, beams, -1, -1, -1).reshape(
+                n_img * beams, *visual_features.shape[1:])
+        return self.textual(visual_features, prefix, lengths)[:, -1, :]
 
 
 def _logits_loss(logits, tokens, padding_idx):
