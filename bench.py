@@ -33,7 +33,7 @@ PEAK_BF16_TFLOPS = 2500.0                                  # MI355X dense bf16 M
 PEAK_F32_TFLOPS = 157.3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -52,15 +52,17 @@ def parse():
                          "this mode shows every kernel un-contended, which is what the roofline object reports")
     ap.add_argument("--roofline-live", action="store_true",
                     help="take the per-launch events inside the timed region itself (adds the event overhead to `value`)")
+    ap.add_argument("--image-size", type=int, default=224)
+    ap.add_argument("--vocab-size", type=int, default=10000)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=8)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def device_batch(B, dev, seed):
+def device_batch(B, dev, seed, image_size=224, vocab_size=10000):
     from virtex_amd.synthetic import synthetic_batch
 
-    return synthetic_batch(B, dev, image_size=224, max_len=30, vocab_size=10000, seed=seed)
+    return synthetic_batch(B, dev, image_size=image_size, max_len=30, vocab_size=vocab_size, seed=seed)
 
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
@@ -176,8 +178,11 @@ def set_streams(concurrent: bool):
     models.HEAD_STREAMS = concurrent
 
 
-def main():
-    a = parse()
+def main(argv=None, device=None, backend=None):
+    """`device` / `backend` are for tests/bench_flow_runner.py only: it drives this exact control flow (single- and
+    multi-rank) on CPU tensors after pointing the bindings at the kernel emulator; normal runs leave them None."""
+    a = parse(argv)
+    injected = device is not None
     if a.serial_streams:
         set_streams(False)
     from virtex_amd import distributed as vd
@@ -189,21 +194,30 @@ def main():
         print(f"bench.py: --gpus {a.gpus} must be launched with torch.distributed.run (one rank per GPU)",
               file=sys.stderr)
         sys.exit(2)
-    local_rank = vd.init_process_group("nccl" if world > 1 else None)
-    if not torch.cuda.is_available():
-        raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if injected:
+        vd.init_process_group(backend if world > 1 else None)
+        dev = device
+    else:
+        local_rank = vd.init_process_group("nccl" if world > 1 else None)
+        if not torch.cuda.is_available():
+            raise RuntimeError("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+
+    def device_sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
     rank = vd.rank()
 
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)
-    model = vf.build_bicaptioning_model(visual=a.visual, textual=a.textual, dropout=a.dropout,
+    model = vf.build_bicaptioning_model(visual=a.visual, textual=a.textual, dropout=a.dropout, vocab_size=a.vocab_size,
                                         compute_dtype=dt).to(dev).train()
     vd.broadcast_parameters(model)
     buckets = vd.GradientBuckets(model)
     opt = FusedPretrainOptimizer(model, buckets, start_step=100)   # inside warm-up: non-zero LR
-    batches = [device_batch(a.batch, dev, seed=1000 * rank + i) for i in range(2)]
+    batches = [device_batch(a.batch, dev, 1000 * rank + i, a.image_size, a.vocab_size) for i in range(2)]
 
     def step(i):
         buckets.zero()
@@ -216,9 +230,9 @@ def main():
 
     for i in range(a.warmup):
         loss = step(i)
-    torch.cuda.synchronize()
+    device_sync()
     vd.synchronize()
-    torch.cuda.synchronize()
+    device_sync()
     from virtex_amd import ops
     live = a.roofline_live and not a.no_roofline and rank == 0
     if live:
@@ -226,9 +240,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(i)
-    torch.cuda.synchronize()
+    device_sync()
     vd.synchronize()
-    torch.cuda.synchronize()
+    device_sync()
     elapsed = time.perf_counter() - t0
     live_recs = None
     if live:
@@ -238,6 +252,44 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = loss.item()
+
+    # ---- roofline leg.  EVERY rank runs the same further steps (a step contains the gradient all-reduces: a rank
+    # stepping alone would wait for its peers forever); only rank 0 attaches events and reports.
+    # The roofline is about the kernel, so it is timed WITHOUT co-running kernels: the side streams are switched off
+    # for these steps (same kernels, same shapes, same order, one stream).
+    #   pass 1 (one step, every contraction launch timed): which kernel class dominates, and the totals;
+    #   pass 2 (roofline_steps steps, only that class timed): its per-launch duration;
+    #   pass 3 (streams back on, same class): what the same launches take while sharing the chip.
+    survey = focused = concurrent = None
+    if not a.no_roofline and live_recs is None:
+        prof = rank == 0
+        set_streams(False)
+        step(0)
+        if prof:
+            ops.profile_start()
+        step(0)
+        dom_cls = -1
+        if prof:
+            survey = ops.profile_stop()
+            dom_cls = max(survey, key=lambda r: r["seconds"])["cls"] if survey else -1
+            ops.profile_start(only_class=dom_cls)
+        for i in range(a.roofline_steps):
+            step(i)
+        if prof:
+            focused = [r for r in ops.profile_stop() if r["cls"] == dom_cls]
+        if not a.serial_streams:
+            set_streams(True)
+            step(0)
+            if prof:
+                ops.profile_start(only_class=dom_cls)
+            for i in range(a.roofline_steps):
+                step(i)
+            if prof:
+                concurrent = [r for r in ops.profile_stop() if r["cls"] == dom_cls]
+        if prof:
+            ops.profile_start(only_class=-1)
+            ops.profile_stop()
+        device_sync()
 
     if rank == 0:
         ips = a.batch * world * a.steps / elapsed
@@ -250,8 +302,8 @@ def main():
             "metric": "pretrain images/sec", "value": round(ips, 2), "unit": "images/sec", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype,
-            "data": "synthetic",
-            "config": {"workload": f"bicaptioning_{cnn}_{key} {a.dtype}, bs={a.batch}/GPU, 224x224 synthetic images + "
+            "data": "synthetic" if not injected else "synthetic (injected test device: control-flow test, not a measurement)",
+            "config": {"workload": f"bicaptioning_{cnn}_{key} {a.dtype}, bs={a.batch}/GPU, {a.image_size}x{a.image_size} synthetic images + "
                                    "30-tok captions, full step (fwd+bwd+clip+SGD+Lookahead), dropout "
                                    f"{a.dropout}", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
@@ -264,38 +316,16 @@ def main():
             default_workload = (a.batch, a.dtype, a.textual, a.visual, world) == (256, "bf16", "transdec_postnorm::L1_H1024_A16_F4096", "torchvision::resnet50", 1)
             if live_recs is not None:
                 rec["roofline"] = step_roofline(live_recs, a.dtype, default_workload)
-                rec["roofline"]["measured"] = "inside the timed region"
+                if rec["roofline"]:
+                    rec["roofline"]["measured"] = "inside the timed region"
             else:
-                # The roofline is about the kernel, so it is timed WITHOUT co-running kernels: the side streams are
-                # switched off for these steps (same kernels, same shapes, same order, one stream).
-                # pass 1 (one step, every contraction launch timed): which kernel class dominates, and the totals;
-                # pass 2 (roofline_steps steps, only that class timed): its per-launch duration;
-                # pass 3 (streams back on, same class): what the same launches take while sharing the chip.
-                set_streams(False)
-                step(0)
-                ops.profile_start()
-                step(0)
-                survey = ops.profile_stop()
-                dom = max(survey, key=lambda r: r["seconds"])
-                ops.profile_start(only_class=dom["cls"])
-                for i in range(a.roofline_steps):
-                    step(i)
-                focused = [r for r in ops.profile_stop() if r["cls"] == dom["cls"]]
-                concurrent = None
-                if not a.serial_streams:
-                    set_streams(True)
-                    step(0)
-                    ops.profile_start(only_class=dom["cls"])
-                    for i in range(a.roofline_steps):
-                        step(i)
-                    concurrent = [r for r in ops.profile_stop() if r["cls"] == dom["cls"]]
-                ops.profile_start(only_class=-1); ops.profile_stop()
                 rec["roofline"] = step_roofline(survey, a.dtype, default_workload, focused[0] if focused else None)
-                rec["roofline"]["measured"] = (f"{a.roofline_steps} further steps right after the timed region, side streams off, begin/end "
-                                               "HIP events on this kernel class only (class chosen from one fully timed step)")
-                if concurrent:
-                    c = concurrent[0]
-                    rec["roofline"]["concurrent_avg_launch_us"] = round(c["seconds"] / c["launches"] * 1e6, 1)
+                if rec["roofline"]:
+                    rec["roofline"]["measured"] = (f"{a.roofline_steps} further steps right after the timed region, side streams off, "
+                                                   "begin/end HIP events on this kernel class only (class chosen from one fully timed step)")
+                    if concurrent:
+                        c = concurrent[0]
+                        rec["roofline"]["concurrent_avg_launch_us"] = round(c["seconds"] / c["launches"] * 1e6, 1)
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps)
         print(json.dumps(rec), flush=True)

@@ -1,0 +1,45 @@
+"""bench.py's contract, exercised end to end on CPU (kernel emulator): one JSON line from rank 0 with the required
+fields, for N = 1 and for N = 2 launched exactly like the driver launches it (torch.distributed.run, one process per
+rank) -- in particular the roofline leg, whose extra steps contain gradient all-reduces and therefore must be run
+by every rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNNER = os.path.join(ROOT, "tests", "bench_flow_runner.py")
+ARGS = ["--steps", "2", "--warmup", "1", "--batch", "2", "--image-size", "64", "--vocab-size", "304", "--dtype", "bf16",
+        "--textual", "transdec_postnorm::L1_H128_A2_F256", "--no-cpu-baseline", "--roofline-steps", "1"]
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_rank_flow():
+    r = subprocess.run([sys.executable, RUNNER, "--gpus", "1"] + ARGS, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = _json_line(r.stdout)
+    assert REQUIRED <= set(rec) and rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["metric"] == "pretrain images/sec" and rec["value"] > 0 and rec["scaling"] == "weak"
+    roof = rec["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"} <= set(roof)
+    assert roof["kernel"].startswith("contraction") and roof["launches"] > 0
+
+
+def test_two_rank_flow_does_not_deadlock_in_the_roofline_leg():
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", RUNNER, "--gpus", "2"] + ARGS
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    rec = _json_line(r.stdout)
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
+    assert rec["roofline"] is not None and "cpu_baseline" not in rec
