@@ -313,7 +313,8 @@ def main(argv=None, device=None, backend=None):
             rec["step_mfma"] = {"gflop_per_image": gflop, "achieved_tflops": round(tf, 1),
                                 "peak_tflops": peak * world, "frac": round(tf / (peak * world), 4)}
         if not a.no_roofline:
-            default_workload = (a.batch, a.dtype, a.textual, a.visual, world) == (256, "bf16", "transdec_postnorm::L1_H1024_A16_F4096", "torchvision::resnet50", 1)
+            default_workload = (a.batch, a.dtype, a.textual, a.visual, world, a.image_size, a.vocab_size) == (
+                256, "bf16", "transdec_postnorm::L1_H1024_A16_F4096", "torchvision::resnet50", 1, 224, 10000)
             if live_recs is not None:
                 rec["roofline"] = step_roofline(live_recs, a.dtype, default_workload)
                 if rec["roofline"]:
