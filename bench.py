@@ -146,8 +146,9 @@ def cpu_baseline(batch, steps, budget_s=40.0):
     ncpu = os.cpu_count() or 1
     best_t, best_threads = None, 1
     t_start = time.time()
-    for threads in (16, 32, 64, 128, 256):
-        if threads > ncpu or time.time() - t_start > budget_s / 2:
+    candidates = [t for t in (16, 32, 64, 128, 256) if t <= ncpu] or [ncpu]      # a host with fewer than 16 CPUs
+    for threads in candidates:
+        if best_t is not None and time.time() - t_start > budget_s / 2:
             break
         torch.set_num_threads(threads)
         step(b)                                   # warm-up at this thread count
@@ -167,7 +168,7 @@ def cpu_baseline(batch, steps, budget_s=40.0):
     dt = time.time() - t0
     return {"value": round(batch * n / dt, 2), "unit": "images/sec", "cores": best_threads, "kind": "port",
             "sample": f"{n} steps of B={batch} (fp32, dropout 0.1, SGD+Lookahead+clip), oracle/bicaptioning.py; "
-                      f"thread count calibrated over 16..{ncpu} logical CPUs"}
+                      f"thread count calibrated over {candidates[0]}..{candidates[-1]} threads ({ncpu} logical CPUs)"}
 
 
 def set_streams(concurrent: bool):

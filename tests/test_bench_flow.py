@@ -24,7 +24,8 @@ def _json_line(out):
 
 
 def test_single_rank_flow():
-    r = subprocess.run([sys.executable, RUNNER, "--gpus", "1"] + ARGS, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    args = [x for x in ARGS if x != "--no-cpu-baseline"] + ["--cpu-batch", "1", "--cpu-steps", "1"]   # with the CPU baseline leg
+    r = subprocess.run([sys.executable, RUNNER, "--gpus", "1"] + args, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     rec = _json_line(r.stdout)
     assert REQUIRED <= set(rec) and rec["n_gpus"] == 1 and rec["steps"] == 2 and rec["warmup"] == 1
@@ -32,6 +33,8 @@ def test_single_rank_flow():
     roof = rec["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"} <= set(roof)
     assert roof["kernel"].startswith("contraction") and roof["launches"] > 0
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["unit"] == "images/sec"
 
 
 def test_two_rank_flow_does_not_deadlock_in_the_roofline_leg():
