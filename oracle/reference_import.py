@@ -56,6 +56,84 @@ def _install_stubs():
         cv2 = types.ModuleType("cv2")
         cv2.INTER_LINEAR = cv2.INTER_CUBIC = cv2.BORDER_CONSTANT = 0
         sys.modules["cv2"] = cv2
+    if "fvcore" not in sys.modules:
+        # virtex/config.py:3 needs fvcore.common.config.CfgNode (yacs underneath): attribute-style nested dict with
+        # merge_from_file (YAML, `_BASE_` chains), merge_from_list ("A.B.C", value pairs), freeze, dump, str.
+        fv, fvc, fvcc = (types.ModuleType(n) for n in ("fvcore", "fvcore.common", "fvcore.common.config"))
+        fvcc.CfgNode = _CfgNode
+        fv.common, fvc.config = fvc, fvcc
+        sys.modules.update({"fvcore": fv, "fvcore.common": fvc, "fvcore.common.config": fvcc})
+    if "loguru" not in sys.modules:
+        import logging
+        lg = types.ModuleType("loguru")
+        lg.logger = logging.getLogger("virtex-reference")
+        lg.logger.success = lg.logger.info
+        sys.modules["loguru"] = lg
+
+
+class _CfgNode(dict):
+    """Minimal stand-in for fvcore's CfgNode, enough for virtex/config.py:36-236."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        if self.__dict__.get("_frozen"):
+            raise AttributeError(f"config is frozen: cannot set {k}")
+        self[k] = v
+
+    def _merge(self, other):
+        for k, v in other.items():
+            if k not in self:
+                raise KeyError(f"non-existent config key: {k}")
+            if isinstance(self[k], _CfgNode):
+                self[k]._merge(v)
+            else:
+                self[k] = type(self[k])(v) if isinstance(self[k], (float, tuple)) and not isinstance(v, str) else v
+
+    def merge_from_file(self, path):
+        import yaml
+        with open(path) as f:
+            data = yaml.safe_load(f) or {}
+        base = data.pop("_BASE_", None)
+        if base:
+            self.merge_from_file(os.path.join(os.path.dirname(path), base))
+        self._merge(data)
+
+    def merge_from_list(self, lst):
+        import ast
+        assert len(lst) % 2 == 0
+        for key, val in zip(lst[0::2], lst[1::2]):
+            node = self
+            *parents, leaf = key.split(".")
+            for part in parents:
+                node = node[part]
+            if leaf not in node:
+                raise KeyError(f"non-existent config key: {key}")
+            if isinstance(val, str) and not isinstance(node[leaf], str):
+                try:
+                    val = ast.literal_eval(val)
+                except (ValueError, SyntaxError):
+                    pass
+            node[leaf] = type(node[leaf])(val) if isinstance(node[leaf], float) else val
+
+    def freeze(self):
+        self.__dict__["_frozen"] = True
+        for v in self.values():
+            if isinstance(v, _CfgNode):
+                v.freeze()
+
+    def dump(self, stream=None):
+        import yaml
+        def plain(n):
+            return {k: plain(v) if isinstance(v, _CfgNode) else v for k, v in n.items()}
+        return yaml.safe_dump(plain(self), stream)
+
+    def __str__(self):
+        return self.dump()
 
 
 def import_reference():
@@ -75,6 +153,19 @@ def import_reference():
         VirTexModel=VirTexModel, TransformerDecoderTextualHead=TransformerDecoderTextualHead,
         TorchvisionVisualBackbone=TorchvisionVisualBackbone, Lookahead=Lookahead,
         LinearWarmupCosineAnnealingLR=LinearWarmupCosineAnnealingLR)
+
+
+def import_reference_factories():
+    """The reference's own `virtex.factories` and `virtex.config.Config`, imported verbatim (registries the native
+    products are installed into: factories.py:317-319, 358-366, 418-426, 469-478)."""
+    if not available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    _install_stubs()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import virtex.factories as factories  # noqa
+    from virtex.config import Config  # noqa
+    return factories, Config
 
 
 def build_reference_model(visual="torchvision::resnet50",

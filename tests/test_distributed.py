@@ -19,7 +19,8 @@ class _Toy(torch.nn.Module):
 
     def __init__(self):
         super().__init__()
-        self.visual = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.Conv2d(8, 8, 3, padding=1))
+        self.visual = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8),
+                                          torch.nn.Conv2d(8, 8, 3, padding=1))
         self.textual = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
         self.unused = torch.nn.Parameter(torch.zeros(3))
 
@@ -40,14 +41,32 @@ def _worker(rank, world, port, q):
     buckets = vd.GradientBuckets(model, bucket_mb=0.0005)   # tiny buckets -> several collectives
     assert len(buckets.buckets) > 2
     results = []
+    # a second engine for another model in the same process must not steal the first one's announcements
+    other = _Toy()
+    other_buckets = vd.GradientBuckets(other, bucket_mb=0.0005)
     for step in range(2):
-        buckets.zero(); buckets.begin()
+        buckets.zero()
+        if step == 0:
+            buckets.begin()          # optional: finish() re-arms the counters, so step 1 runs without it
         x = torch.randn(4, 3, 6, 6, generator=torch.Generator().manual_seed(100 * step + rank))
         model(x).backward()
         scale = buckets.finish()
         results.append([(n, (p.grad * scale).tolist()) for n, p in model.named_parameters() if p.grad is not None])
-    avg = vd.average_across_processes({"a": torch.tensor(float(rank)), "b": torch.tensor(2.0 * rank + 1)})
-    q.put((rank, results, {k: v.item() for k, v in avg.items()}))
+    del other_buckets
+    # the reference helper averages IN PLACE and its callers ignore the return value (pretrain_virtex.py:213)
+    d = {"a": torch.tensor(float(rank)), "b": torch.tensor(2.0 * rank + 1)}
+    vd.average_across_processes(d)
+    bare = torch.tensor([float(rank), 10.0 * rank])
+    vd.average_across_processes(bare)
+    assert bare.tolist() == [0.5, 5.0]
+    # buffers: rank 0's running statistics everywhere, version counters bumped
+    bn = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    if bn:
+        bn[0].running_mean.fill_(float(rank) + 1.0)
+        v0 = bn[0].running_mean._version
+        vd.broadcast_buffers(model)
+        assert bn[0].running_mean.eq(1.0).all() and bn[0].running_mean._version > v0
+    q.put((rank, results, {k: v.item() for k, v in d.items()}))
     dist.barrier()
     dist.destroy_process_group()
 

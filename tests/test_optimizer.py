@@ -132,3 +132,73 @@ def test_checkpoint_resume_and_reference_interchange(backend, tmp_path):
     opt_a.restore_fast_weights()
     for p, b in zip(model_a.parameters(), before):
         assert torch.equal(p, b)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_state_dict_is_in_named_parameter_order(backend):
+    """The reference builds one param group per `model.named_parameters()` entry, in that order
+    (virtex/factories.py:529-533), and Lookahead.state_dict() is the wrapped SGD's.  The fused optimizer keeps
+    its buffers in backward-execution order internally, so its state dict must be re-indexed: compare momentum,
+    lr, weight decay PER PARAMETER NAME against the unfused optimizer (stock SGD over named order) stepped
+    with the same gradients, assert shapes, and load each one's state into the other."""
+    dev = select(backend)
+    torch.manual_seed(3)
+    model_f = _Toy().to(dev)
+    model_u = copy.deepcopy(model_f)
+    buckets = vd.GradientBuckets(model_f, bucket_mb=0.01)
+    assert [id(p) for p in buckets.params] != [id(p) for p in model_f.parameters()]      # the orders really differ
+    fused = FusedPretrainOptimizer(model_f, buckets, total_steps=40, warmup_steps=4, start_step=2)
+    unfused = PretrainOptimizer(model_u, total_steps=40, warmup_steps=4, start_step=2)
+    for it in range(3):
+        buckets.zero()
+        for p, q, g in zip(model_f.parameters(), model_u.parameters(), _grads(model_u, it)):
+            p.grad.add_(g.to(dev))
+            q.grad = g.to(dev).clone()
+        fused.step()
+        unfused.step()
+    sf, su = fused.state_dict(), unfused.state_dict()
+    names = [n for n, _ in model_f.named_parameters()]
+    assert len(sf["param_groups"]) == len(su["param_groups"]) == len(names)
+    for i, (n, p) in enumerate(model_f.named_parameters()):
+        gf, gu = sf["param_groups"][i], su["param_groups"][i]
+        assert gf["params"] == [i] and gu["params"] == [i]
+        assert gf["weight_decay"] == gu["weight_decay"], n
+        assert abs(gf["lr"] - gu["lr"]) <= 1e-12 + 1e-6 * gu["lr"], n
+        assert abs(gf["initial_lr"] - gu["initial_lr"]) <= 1e-9, n
+        mf, mu = sf["state"][i]["momentum_buffer"], su["state"][i]["momentum_buffer"]
+        assert tuple(mf.shape) == tuple(p.shape) == tuple(mu.shape), n
+        assert torch.allclose(mf.cpu(), mu.cpu(), rtol=2e-5, atol=1e-6), n
+    # cross-loading: the unfused state into a fresh fused optimizer and vice versa, then one more identical step
+    torch.manual_seed(4)
+    model_g = copy.deepcopy(model_u)
+    buckets_g = vd.GradientBuckets(model_g, bucket_mb=0.01)
+    fused_g = FusedPretrainOptimizer(model_g, buckets_g, total_steps=40, warmup_steps=4)
+    fused_g.load_state_dict(su)
+    model_v = copy.deepcopy(model_u)
+    unfused_v = PretrainOptimizer(model_v, total_steps=40, warmup_steps=4)
+    unfused_v.load_state_dict(sf)
+    gs = _grads(model_u, 9)
+    buckets_g.zero()
+    for p, q, g in zip(model_g.parameters(), model_v.parameters(), gs):
+        p.grad.add_(g.to(dev))
+        q.grad = g.to(dev).clone()
+    fused_g.step()
+    unfused_v.step()
+    for (n, p), q in zip(model_g.named_parameters(), model_v.parameters()):
+        assert torch.allclose(p.detach().cpu(), q.detach().cpu(), rtol=2e-5, atol=1e-6), n
+    # a stock SGD with the reference grouping takes the fused file without swapping hyper-parameters
+    model_c = copy.deepcopy(model_u).cpu()
+    sgd = torch.optim.SGD(port.param_groups(model_c.named_parameters()), momentum=0.9)
+    sgd.load_state_dict({"state": {k: {"momentum_buffer": v["momentum_buffer"].cpu()} for k, v in sf["state"].items()},
+                         "param_groups": sf["param_groups"]})
+    for (n, p), g in zip(model_c.named_parameters(), sgd.param_groups):
+        assert g["weight_decay"] == (0.0 if ("layer_norm" in n or n.endswith("transformer.bias")) else 1e-4), n
+        assert tuple(sgd.state[p]["momentum_buffer"].shape) == tuple(p.shape), n
+    # wrong shape / wrong group count are refused instead of broadcast
+    bad = copy.deepcopy(sf)
+    bad["state"][0]["momentum_buffer"] = torch.zeros(3)
+    with pytest.raises(ValueError):
+        fused_g.load_state_dict(bad)
+    bad2 = {**sf, "param_groups": sf["param_groups"][:-1]}
+    with pytest.raises(ValueError):
+        fused_g.load_state_dict(bad2)

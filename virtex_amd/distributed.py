@@ -17,8 +17,12 @@ a generic reducer:
   default: the bucket size is a parameter (default 64 MB -> 5 collectives per step);
 * ``finish()`` makes the compute stream wait for the side stream; the 1/world scaling is folded
   into the optimizer (``PretrainOptimizer.step(grad_scale=1/world)``), not a separate pass;
-* BatchNorm buffers are NOT broadcast every forward (DDP's default C4 traffic): per-rank
-  statistics are what the reference trains with, rank 0's are what it checkpoints.
+* DDP's default ``broadcast_buffers=True`` re-broadcasts rank 0's BatchNorm running statistics at
+  every forward (C4).  In training mode those buffers are write-only (batch statistics normalise),
+  so the per-step broadcast changes nothing a training step computes; it matters where the buffers
+  are READ: validation and checkpoints.  ``broadcast_buffers(model)`` does that one flat broadcast
+  -- call it before switching to eval and before saving -- and ``broadcast_parameters`` does it once
+  at start-up, so every rank validates on rank 0's statistics exactly like the reference.
 
 Works with any torch.distributed backend: ``nccl`` (= RCCL on ROCm) on GPUs, ``gloo`` on CPU for
 the world_size-2 tests.
@@ -66,23 +70,56 @@ def synchronize():
             dist.barrier()
 
 
-def average_across_processes(tensors: dict) -> dict:
-    """One fused all-reduce for a dict of scalars (the reference issues one per key)."""
+def average_across_processes(t):
+    """Averages a tensor, or every tensor of a dict, across processes IN PLACE, like the reference helper
+    (virtex/utils/distributed.py:141-160; its callers ignore the return value: scripts/pretrain_virtex.py:213).
+    A dict costs one fused all-reduce instead of one per key.  The argument is also returned."""
     if world_size() == 1:
-        return tensors
-    keys = sorted(tensors)
-    flat = torch.stack([tensors[k].detach().float().reshape(()) for k in keys])
+        return t
+    if isinstance(t, torch.Tensor):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t /= world_size()
+        return t
+    keys = sorted(t)
+    flat = torch.stack([t[k].detach().float().reshape(()) for k in keys])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= world_size()
-    return {k: flat[i] for i, k in enumerate(keys)}
+    with torch.no_grad():
+        for i, k in enumerate(keys):
+            t[k].copy_(flat[i].to(t[k].dtype).reshape(t[k].shape))
+    return t
+
+
+def _broadcast_flat(tensors, src):
+    """One broadcast per dtype instead of one per tensor; results are written back through `copy_`, which bumps
+    the tensors' version counters (the compute-weight caches are keyed on them)."""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype, ts in by_dtype.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off: off + n].view(t.shape))
+                off += n
 
 
 def broadcast_parameters(model: torch.nn.Module, src: int = 0):
     """What DDP's constructor does once (C3): rank-0 parameters and buffers everywhere."""
     if world_size() == 1:
         return
-    for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src)
+    _broadcast_flat(list(model.parameters()) + list(model.buffers()), src)
+
+
+def broadcast_buffers(model: torch.nn.Module, src: int = 0):
+    """Rank 0's buffers (BatchNorm running statistics, step counters) everywhere: what DDP's per-forward buffer
+    broadcast (C4) amounts to at the two places the buffers are read -- before validation and before a checkpoint."""
+    if world_size() == 1:
+        return
+    _broadcast_flat(list(model.buffers()), src)
 
 
 def execution_order(model: torch.nn.Module) -> List[torch.nn.Parameter]:
@@ -133,13 +170,15 @@ class GradientBuckets:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
             from . import gradsink
-            gradsink.ready_callback = self._on_ready
+            gradsink.register(params, self._on_ready)      # per instance: keyed by parameter
         self.begin()
 
     # ---------------------------------------------------------------------------------
     def begin(self):
-        """Call before each backward."""
+        """Re-arm the per-bucket counters.  Runs at construction and at the end of every finish(), so a training
+        loop that never calls it is still correct; calling it before each backward as well is harmless."""
         self.pending = [c for (_, _, c) in self.buckets]
+        self.launched = [False] * len(self.buckets)
         self.handles = []
         self.early = set()
 
@@ -160,10 +199,14 @@ class GradientBuckets:
     def _count(self, p):
         b = self.bucket_of[p]
         self.pending[b] -= 1
+        if self.pending[b] < 0:
+            raise RuntimeError("GradientBuckets: a parameter's gradient was announced twice in one step (a second "
+                               "backward without finish() in between?)")
         if self.pending[b] == 0:
             self._launch(b)
 
     def _launch(self, b):
+        self.launched[b] = True
         s, e, _ = self.buckets[b]
         chunk = self.flat[s:e]
         if self.side is not None:
@@ -188,13 +231,12 @@ class GradientBuckets:
         wgrad_stream.join(self.flat.device)
         if not self.enabled:
             return 1.0
-        for b, left in enumerate(self.pending):
-            if left > 0:            # parameters that received no gradient this step
-                self.pending[b] = 0
+        for b in range(len(self.buckets)):
+            if not self.launched[b]:    # buckets holding parameters that received no gradient this step
                 self._launch(b)
         for h in self.handles:
             h.wait()
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
-        self.handles = []
+        self.begin()                    # armed for the next backward
         return 1.0 / self.world

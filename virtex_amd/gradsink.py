@@ -31,11 +31,22 @@ def target(p: torch.nn.Parameter, shape=None):
 # parameters are enqueued" long before autograd visits the parameters (the whole ResNet backward is ONE autograd
 # node: without this its 161 gradients would all become visible at its end and their all-reduce could not overlap
 # with it).  The engine installs the callback; with no engine this is a no-op.
-ready_callback = None
+_ready_callbacks = {}        # id(parameter) -> (weakref to the parameter, engine callback)
+
+
+def register(params, callback):
+    """An engine (distributed.GradientBuckets) subscribes to the announcements of ITS parameters; several engines
+    (several models in one process) coexist because the table is keyed by parameter, not global."""
+    import weakref
+    for p in params:
+        _ready_callbacks[id(p)] = (weakref.ref(p), callback)
 
 
 def mark_ready(params):
     """Only parameters whose gradient was accumulated IN PLACE (target() returned a buffer) may be announced."""
-    if ready_callback is not None:
-        for p in params:
-            ready_callback(p)
+    if not _ready_callbacks:
+        return
+    for p in params:
+        e = _ready_callbacks.get(id(p))
+        if e is not None and e[0]() is p:
+            e[1](p)

@@ -6,9 +6,12 @@
 
 Parameter grouping follows the reference exactly: one group per named parameter, weight decay 0
 for names matching ``.*textual.(embedding|transformer).*(norm.*|bias)``, CNN_LR for names
-containing ``cnn``.  Round 1 drives stock ``torch.optim.SGD(foreach=True)`` for the elementwise
-update (SURVEY.md 8a row a9 / 8f row f1: the fused multi-tensor HIP kernel is the next row);
-everything is device-side, no host synchronisation happens inside ``step()``.
+containing ``cnn``.  `FusedPretrainOptimizer` (what bench.py drives) executes the whole tail with two HIP
+kernels over flat buffers (csrc/optim.hip); `PretrainOptimizer` is the same arithmetic on stock
+``torch.optim.SGD(foreach=True)`` for models without a flat gradient buffer.  Everything is device-side, no host
+synchronisation happens inside ``step()``.  State dicts of both are indexed in ``model.named_parameters()``
+order -- the order the reference's OptimizerFactory builds its one-tensor param groups in
+(virtex/factories.py:529-533) -- so checkpoints interchange with the reference's Lookahead(SGD).
 """
 import math
 import re
@@ -81,6 +84,8 @@ class PretrainOptimizer:
             torch._foreach_mul_(data, self.alpha)
             torch._foreach_add_(data, self.slow, alpha=1.0 - self.alpha)
             torch._foreach_copy_(self.slow, data)
+            for p in self.params:       # written through .data: tell the version-keyed caches
+                torch.autograd.graph.increment_version(p)
         self.step_idx += 1
         self._set_lr()
 
@@ -118,12 +123,12 @@ class PretrainOptimizer:
         self._backup = [p.detach().clone() for p in self.params]
         with torch.no_grad():
             for p, s_ in zip(self.params, self.slow):
-                p.data.copy_(s_)
+                p.copy_(s_)          # p.copy_ (not p.data.copy_): bumps p._version, which the compute-weight caches key on
 
     def restore_fast_weights(self):
         with torch.no_grad():
             for p, b in zip(self.params, self._backup):
-                p.data.copy_(b)
+                p.copy_(b)
         del self._backup
 
 
@@ -142,6 +147,10 @@ class FusedPretrainOptimizer:
         self.buckets = buckets
         names = {p: n for n, p in model.named_parameters()}
         params = buckets.params
+        # state dicts are indexed like the reference's param groups: model.named_parameters() order (frozen
+        # parameters included, they simply carry no momentum); slot = position in the flat buffers
+        self.named = [p for _, p in model.named_parameters()]
+        self._slot_of = {p: i for i, p in enumerate(params)}
         dev = buckets.flat.device
         lib = _lib.lib()
         chunk = lib.vtx_optim_chunk_elems()
@@ -177,6 +186,8 @@ class FusedPretrainOptimizer:
         self.momentum, self.clip_norm, self.k, self.alpha = momentum, clip_norm, lookahead_k, lookahead_alpha
         self.kc, self.step_idx = 0, start_step
         self.total_steps, self.warmup_steps = total_steps, warmup_steps
+        self.cnn_lr, self.lr, self.weight_decay, self.no_decay = cnn_lr, lr, weight_decay, no_decay
+        self.model_named = model.named_parameters
 
     def zero_grad(self):
         self.buckets.zero()
@@ -224,22 +235,40 @@ class FusedPretrainOptimizer:
 
     def state_dict(self):
         mult = lr_multiplier(self.step_idx, self.total_steps, self.warmup_steps)
-        lrs, wds = self.seg_lr.tolist(), self.seg_wd.tolist()
-        groups = [{"lr": lr * mult, "momentum": self.momentum, "dampening": 0, "weight_decay": wd, "nesterov": False,
-                   "maximize": False, "foreach": None, "differentiable": False, "fused": None,
-                   "initial_lr": lr, "params": [i]} for i, (lr, wd) in enumerate(zip(lrs, wds))]
-        state = {i: {"momentum_buffer": m} for i, m in enumerate(self._views(self.flat_m))}
+        names = {p: n for n, p in self.model_named()}
+        views = self._views(self.flat_m)
+        groups, state = [], {}
+        for i, p in enumerate(self.named):
+            name = names[p]
+            lr = self.cnn_lr if "cnn" in name else self.lr
+            wd = 0.0 if re.match(self.no_decay, name) else self.weight_decay
+            groups.append({"lr": lr * mult, "momentum": self.momentum, "dampening": 0, "weight_decay": wd,
+                           "nesterov": False, "maximize": False, "foreach": None, "differentiable": False,
+                           "fused": None, "initial_lr": lr, "params": [i]})
+            slot = self._slot_of.get(p)
+            if slot is not None:
+                state[i] = {"momentum_buffer": views[slot]}
         return {"state": state, "param_groups": groups,
                 "virtex_amd": {"step": self.step_idx, "k_counter": self.kc}}
 
     @torch.no_grad()
     def load_state_dict(self, sd):
-        for i, view in enumerate(self._views(self.flat_m)):
+        if len(sd["param_groups"]) != len(self.named):
+            raise ValueError(f"optimizer state has {len(sd['param_groups'])} parameter groups, the model has "
+                             f"{len(self.named)} named parameters")
+        views = self._views(self.flat_m)
+        for i, p in enumerate(self.named):
+            slot = self._slot_of.get(p)
+            if slot is None:
+                continue
             st = sd["state"].get(i, sd["state"].get(str(i)))
-            if st is not None and st.get("momentum_buffer") is not None:
-                view.copy_(st["momentum_buffer"])
+            buf = st.get("momentum_buffer") if st is not None else None
+            if buf is not None:
+                if tuple(buf.shape) != tuple(p.shape):
+                    raise ValueError(f"momentum buffer {i} has shape {tuple(buf.shape)}, parameter {tuple(p.shape)}")
+                views[slot].copy_(buf)
             else:
-                view.zero_()
+                views[slot].zero_()
         extra = sd.get("virtex_amd", {})
         self.step_idx = int(extra.get("step", self.step_idx))
         self.kc = int(extra.get("k_counter", 0))
