@@ -11,11 +11,17 @@ Workload at N=1 = BASELINE.json configs[1]: bf16 compute, 256 images per GPU.  F
 driver launches this file under torch.distributed.run, one rank per GPU (weak scaling).
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
-  "roofline"     : the step's dominant kernel (the contraction-kernel instantiation with the largest summed
-                   time), algorithmic FLOPs and bytes / HIP-event time per launch measured live on the launch
-                   streams (vtx_profile_start/stop), against the dense bf16 MFMA peak and the HBM peak
+  "roofline"     : the step's dominant kernel -- the kernel (contraction-kernel instantiation, or BatchNorm / LayerNorm
+                   / embedding / loss / optimizer ... kernel) with the largest summed time -- algorithmic FLOPs and bytes /
+                   HIP-event time per launch measured live on the launch streams (vtx_profile_start/stop), against the
+                   dense bf16 MFMA peak and the HBM peak; "hbm_kernels": GB/s, fraction of the HBM peak and ms per step of
+                   every HBM-bound kernel family; "families": the same summed per family (BatchNorm = its five kernels);
+                   "step_model": sum over all launches of max(FLOPs / MFMA peak, bytes / HBM peak) next to the measured
+                   kernel time
   "step_mfma"    : whole-step algorithmic FLOP/s (35.17 GFLOP/img) against the same peak
-  "cpu_baseline" : the oracle port of the reference step timed on this box's host cores.
+  "fidelity"     : the bf16 step against the fp32 step (the mode pinned to the oracle) on the timed batch: loss and
+                   per-tensor gradient distance / cosine (virtex_amd/fidelity.py)
+  "cpu_baseline" : the oracle port of the reference step timed on this box's host cores (B = 16, and config 1's B = 2).
 """
 import argparse
 import json
@@ -36,8 +42,8 @@ PEAK_F32_TFLOPS = 157.3
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # >= 20 warm-up, >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--textual", default="transdec_postnorm::L1_H1024_A16_F4096")
@@ -45,6 +51,9 @@ def parse(argv=None):
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fidelity", action="store_true")
+    ap.add_argument("--bn-fusion", default=None, choices=["none", "bwd", "fwd", "both"],
+                    help="A/B switch: BatchNorm sums taken in the convolution epilogues (default: the module's setting)")
     ap.add_argument("--roofline-steps", type=int, default=3,
                     help="steps run with per-launch HIP events (after the timed region) for the roofline object")
     ap.add_argument("--serial-streams", action="store_true",
@@ -68,8 +77,8 @@ def device_batch(B, dev, seed, image_size=224, vocab_size=10000):
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
 # (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v9.txt.
-TRAFFIC_PER_LAUNCH = {   # profiles/r01_pmc_traffic_v9.txt: (2 x 74.02e3 + 113.7e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, false>, 32, 3>": 2.680e8,
+TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE)
 }
 
 
@@ -96,39 +105,86 @@ def _kernel_name(bracket):
     # defaulted template arguments, rocprofv3 prints them
     order = ["BM", "BN", "WM", "WN", "AL", "BL", "EP", "BK", "STAGES"]
     name = ", ".join(kv[k] for k in order if k in kv).replace("vtxg::", "").replace("unsigned short", "bf16")
-    name = name.replace("EpiStore<bf16>", "EpiStore<bf16, false>").replace("EpiStore<float>", "EpiStore<float, false>")
+    name = name.replace("EpiStore<bf16>", "EpiStore<bf16, 0>").replace("EpiStore<float>", "EpiStore<float, 0>")
     return f"contraction_v2_kernel<{name}>"
 
 
-def step_roofline(recs, dtype, default_workload, focused=None):
-    """Roofline of the step's dominant kernel, measured LIVE: HIP events on the launch stream around every
-    contraction-kernel launch of the step function the timed region runs (`recs` = ops.profile_stop()).  The dominant
-    class is the kernel instantiation with the largest summed time; achieved = its algorithmic FLOPs (or bytes)
-    / its summed launch time; the binding roof is whichever fraction is larger."""
+FAMILY_OF = {   # HBM-bound kernel -> family reported under roofline.families
+    "bn_fwd_reduce": "batchnorm", "bn_fwd_apply": "batchnorm", "bn_bwd_reduce": "batchnorm", "bn_bwd_apply": "batchnorm",
+    "bn_finalize": "batchnorm", "layernorm_fwd": "layernorm", "layernorm_bwd": "layernorm", "layernorm_bwd_finalize": "layernorm",
+    "embedding_fwd": "embedding", "embedding_bwd": "embedding", "cross_entropy_fwd": "cross_entropy",
+    "cross_entropy_reduce": "cross_entropy", "cross_entropy_bwd": "cross_entropy", "tied_ce_fwd": "cross_entropy",
+    "tied_ce_bwd": "cross_entropy", "optimizer_sumsq": "optimizer", "optimizer_sumsq_final": "optimizer",
+    "optimizer_step": "optimizer", "maxpool_fwd": "maxpool", "maxpool_bwd": "maxpool", "colsum": "bias_gradients",
+    "colsum_finalize": "bias_gradients", "splitk_reduce": "splitk_reduce", "weight_prep": "weight_prep",
+    "image_to_nhwc": "input_conversion", "gelu_bwd": "gelu_bwd", "add": "add", "attention_fwd": "attention",
+    "attention_bwd": "attention"}
+
+
+def _display_name(rec_name):
+    return rec_name[len("family:"):] if rec_name.startswith("family:") else _kernel_name(rec_name)
+
+
+def merge_classes(recs):
+    """One record per kernel NAME (a templated launch site registers one class per instantiation)."""
+    out = {}
+    for r in recs:
+        k = _display_name(r["name"])
+        o = out.setdefault(k, {"name": k, "contraction": not r["name"].startswith("family:"), "launches": 0, "seconds": 0.0,
+                               "flops": 0.0, "bytes": 0.0, "cls": []})
+        o["launches"] += r["launches"]; o["seconds"] += r["seconds"]; o["flops"] += r["flops"]; o["bytes"] += r["bytes"]
+        o["cls"].append(r["cls"])
+    return out
+
+
+def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1):
+    """Roofline of the step's dominant kernel, measured LIVE: HIP events attached to every launch of the step function
+    the timed region runs (`recs` = ops.profile_stop() of `survey_steps` fully timed steps).  The dominant kernel is the
+    one with the largest summed time; achieved = its algorithmic FLOPs (or bytes) / its summed launch time; the binding
+    roof is whichever fraction is larger."""
     if not recs:
         return None
-    total = sum(r["seconds"] for r in recs)
-    dom = max(recs, key=lambda r: r["seconds"])
+    peak_tf = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    by_name = merge_classes(recs)
+    total = sum(r["seconds"] for r in by_name.values())
+    dom = max(by_name.values(), key=lambda r: r["seconds"])
     share = dom["seconds"] / total
     if focused is not None:
-        dom = focused
-    peak_tf = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+        dom = dict(dom, launches=focused["launches"], seconds=focused["seconds"], flops=focused["flops"], bytes=focused["bytes"])
     tf = dom["flops"] / dom["seconds"] / 1e12
     tbs = dom["bytes"] / dom["seconds"] / 1e12
     f_mfma, f_hbm = tf / peak_tf, tbs / PEAK_HBM_TBS
-    name = _kernel_name(dom["name"])
     bound = "mfma" if f_mfma >= f_hbm else "hbm"
-    out = {"bound": bound, "kernel": name,
+    traffic = TRAFFIC_PER_LAUNCH.get(dom["name"]) if default_workload else None
+    out = {"bound": bound, "kernel": dom["name"],
            "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": peak_tf if bound == "mfma" else PEAK_HBM_TBS * 1e3,
            "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(max(f_mfma, f_hbm), 4),
-           "traffic": TRAFFIC_PER_LAUNCH.get(name) if default_workload else None, "traffic_unit": "bytes/launch",
+           "traffic": traffic, "traffic_unit": "bytes/launch",
+           "traffic_source": (TRAFFIC_SOURCE if traffic is not None else None),
            "launches": dom["launches"], "avg_launch_us": round(dom["seconds"] / dom["launches"] * 1e6, 1),
            "flops_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes": dom["bytes"] / dom["launches"],
-           "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4),
-           "share_of_contraction_time": round(share, 3),
-           "all_contractions": {"tflops": round(sum(r["flops"] for r in recs) / total / 1e12, 1),
-                                "hbm_gbs": round(sum(r["bytes"] for r in recs) / total / 1e9, 1),
-                                "kernel_classes": len(recs), "launches": sum(r["launches"] for r in recs)}}
+           "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4), "share_of_kernel_time": round(share, 3)}
+    # every HBM-bound kernel, and families
+    hbm, fam = {}, {}
+    for r in by_name.values():
+        ms = r["seconds"] / survey_steps * 1e3
+        if not r["contraction"]:
+            gbs = r["bytes"] / r["seconds"] / 1e9 if r["seconds"] > 0 else 0.0
+            hbm[r["name"]] = {"GB/s": round(gbs, 1), "frac": round(gbs / (PEAK_HBM_TBS * 1e3), 4), "ms_per_step": round(ms, 3),
+                              "launches_per_step": r["launches"] // survey_steps}
+        f = "contractions (MFMA)" if r["contraction"] else FAMILY_OF.get(r["name"], r["name"])
+        o = fam.setdefault(f, {"ms_per_step": 0.0, "bytes": 0.0, "flops": 0.0, "seconds": 0.0})
+        o["ms_per_step"] += ms; o["bytes"] += r["bytes"]; o["flops"] += r["flops"]; o["seconds"] += r["seconds"]
+    out["hbm_kernels"] = dict(sorted(hbm.items(), key=lambda kv: -kv[1]["ms_per_step"]))
+    out["families"] = {k: {"ms_per_step": round(v["ms_per_step"], 3), "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1) if v["seconds"] else 0.0,
+                           "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 1) if v["seconds"] else 0.0}
+                       for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+    # step-level model: every launch at its binding roof (SURVEY.md 7.3-1)
+    model_s = sum(max(r["flops"] / (peak_tf * 1e12), r["bytes"] / (PEAK_HBM_TBS * 1e12)) for r in by_name.values()) / survey_steps
+    out["step_model"] = {"sum_max_mfma_hbm_ms": round(model_s * 1e3, 3), "measured_kernel_ms": round(total / survey_steps * 1e3, 3),
+                         "frac": round(model_s / (total / survey_steps), 4),
+                         "note": "sum over all launches of one step of max(algorithmic FLOPs / MFMA peak, algorithmic bytes / 8 TB/s) "
+                                 "against the sum of their measured durations (side streams off)"}
     return out
 
 
@@ -166,9 +222,19 @@ def cpu_baseline(batch, steps, budget_s=40.0):
     for _ in range(n):
         step(b)
     dt = time.time() - t0
-    return {"value": round(batch * n / dt, 2), "unit": "images/sec", "cores": best_threads, "kind": "port",
-            "sample": f"{n} steps of B={batch} (fp32, dropout 0.1, SGD+Lookahead+clip), oracle/bicaptioning.py; "
-                      f"thread count calibrated over {candidates[0]}..{candidates[-1]} threads ({ncpu} logical CPUs)"}
+    out = {"value": round(batch * n / dt, 2), "unit": "images/sec", "cores": best_threads, "kind": "port",
+           "sample": f"{n} steps of B={batch} (fp32, dropout 0.1, SGD+Lookahead+clip), oracle/bicaptioning.py; "
+                     f"thread count calibrated over {candidates[0]}..{candidates[-1]} threads ({ncpu} logical CPUs)"}
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case, bs = 2 (SURVEY.md 8d "Config 1")
+    b2 = synth.synthetic_batch(2, seed=1)
+    step(b2)
+    n2 = 5
+    t0 = time.time()
+    for _ in range(n2):
+        step(b2)
+    out["config1_bs2"] = {"value": round(2 * n2 / (time.time() - t0), 2), "unit": "images/sec", "cores": best_threads,
+                          "sample": f"{n2} steps of B=2, same model and step"}
+    return out
 
 
 def set_streams(concurrent: bool):
@@ -186,6 +252,10 @@ def main(argv=None, device=None, backend=None):
     injected = device is not None
     if a.serial_streams:
         set_streams(False)
+    if a.bn_fusion is not None:
+        from virtex_amd.modules import visual_backbones as vbm
+        vbm.FUSE_BN_BWD = a.bn_fusion in ("bwd", "both")
+        vbm.FUSE_BN_STATS = a.bn_fusion in ("fwd", "both")
     from virtex_amd import distributed as vd
     import virtex_amd.factories as vf
     from virtex_amd.optim import FusedPretrainOptimizer
@@ -272,7 +342,11 @@ def main(argv=None, device=None, backend=None):
         dom_cls = -1
         if prof:
             survey = ops.profile_stop()
-            dom_cls = max(survey, key=lambda r: r["seconds"])["cls"] if survey else -1
+            dom_cls = -1
+            if survey:          # dominant kernel by NAME; the focused pass times its largest class
+                by_name = merge_classes(survey)
+                dom = max(by_name.values(), key=lambda r: r["seconds"])
+                dom_cls = max((r for r in survey if r["cls"] in dom["cls"]), key=lambda r: r["seconds"])["cls"]
             ops.profile_start(only_class=dom_cls)
         for i in range(a.roofline_steps):
             step(i)
@@ -290,6 +364,17 @@ def main(argv=None, device=None, backend=None):
         if prof:
             ops.profile_start(only_class=-1)
             ops.profile_stop()
+        device_sync()
+
+    # ---- fidelity leg (every rank: the engine's finish() is collective; rank 0 reports): the bf16 step against the
+    # fp32 step on the batch the timed region used
+    fid = None
+    if a.dtype == "bf16" and not a.no_fidelity:
+        from virtex_amd import fidelity
+        try:
+            fid = fidelity.bf16_vs_fp32(model, batches[0], buckets)
+        except Exception as e:      # never lose the bench line to the auxiliary leg
+            fid = {"error": f"{type(e).__name__}: {e}"}
         device_sync()
 
     if rank == 0:
@@ -328,6 +413,11 @@ def main(argv=None, device=None, backend=None):
                     if concurrent:
                         c = concurrent[0]
                         rec["roofline"]["concurrent_avg_launch_us"] = round(c["seconds"] / c["launches"] * 1e6, 1)
+        if fid is not None:
+            rec["fidelity"] = fid
+        from virtex_amd.modules import visual_backbones as vbm
+        rec["config"]["bn_fusion"] = {"backward_sums_in_dgrad_epilogue": bool(vbm.FUSE_BN_BWD and a.dtype == "bf16"),
+                                      "forward_statistics_in_conv_epilogue": bool(vbm.FUSE_BN_STATS and a.dtype == "bf16")}
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps)
         print(json.dumps(rec), flush=True)

@@ -80,6 +80,29 @@ int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, long lda, con
                     float* C, long ldc, float alpha, int split_k, float* workspace, long workspace_floats,
                     void* stream);
 
+/* ---- BatchNorm-backward fusion into the input-gradient kernels ---------------------------
+ * The input gradient of a convolution IS the gradient wrt the output of the BatchNorm(+ReLU) that fed it
+ * (torchvision Bottleneck: conv -> bn -> relu -> conv, visual_backbones.py:68-74 of the reference).  With a
+ * VtxBnBwdFusion the producing kernel's epilogue applies that ReLU's mask, stores the masked gradient dz and emits
+ * the two per-channel sums BatchNorm's backward needs (sum dz, sum dz*xhat) from its fp32 values, so the stand-alone
+ * reduction pass (aten::native_batch_norm_backward's first half) and the mask pass (aten::threshold_backward)
+ * disappear: pass `parts`/`strips` to vtx_bn_bwd as pre_partials.  strips == 0 on return means this build / dtype did
+ * not fuse (fp32 parity mode): the output is then the PLAIN gradient and vtx_bn_bwd must reduce and mask itself. */
+typedef struct VtxBnBwdFusion {
+    const void* x;       /* [M][N] dtype: that BatchNorm's input (the producing convolution's output) */
+    const void* ymask;   /* [M][N] dtype or NULL: the post-ReLU block output (residual blocks): mask = ymask > 0 */
+    const float* mean;   /* [N] saved batch mean */
+    const float* rstd;   /* [N] saved 1/sqrt(var + eps) */
+    const float* gamma;  /* ymask == NULL && beta != NULL: mask recomputed as xhat*gamma + beta > 0; */
+    const float* beta;   /* both NULL and ymask NULL: no ReLU follows that BatchNorm (no mask) */
+    float* parts;        /* out: [strips][2][N] fp32 partial sums {sum dz, sum dz*xhat} */
+    long parts_cap;      /* capacity of `parts` in floats; (ceil(M/64) + 4) * 2 * N always suffices */
+    int strips;          /* out */
+} VtxBnBwdFusion;
+/* C[M][N] = A[M][K] . B[N][K]^T + residual, with the fusion above (1x1 convolutions' input gradient). */
+int vtx_gemm_nt_bnbwd(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
+                      long ldc, const void* residual, long ldr, VtxBnBwdFusion* fusion, void* stream);
+
 /* ---- per-launch timing of the contraction kernels (bench.py roofline leg) ----------------
  * Between vtx_profile_start() and vtx_profile_stop() every contraction-kernel launch carries a start and a stop
  * HIP event (hipExtLaunchKernel: the dispatch's own begin / end timestamps, i.e. what rocprofv3 reports).  stop() synchronises the device and returns the number of kernel classes
@@ -108,6 +131,9 @@ int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, 
 int vtx_conv2d_dgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
                      const void* dy, const void* wt, void* dx, const void* residual /*nullable: dx += */,
                      void* stream);
+int vtx_conv2d_dgrad_bnbwd(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
+                           const void* dy, const void* wt, void* dx, const void* residual,
+                           VtxBnBwdFusion* fusion /* see vtx_gemm_nt_bnbwd; rows = (n, ih, iw) of dx */, void* stream);
 int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, int R, int S, int stride, int pad,
                      const void* x, const void* dy, float* dw, int split_k, float* workspace,
                      long workspace_floats, void* stream);
@@ -147,6 +173,11 @@ int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, cons
                const float* relu_beta /* non-NULL: ReLU mask recomputed as xhat*gamma+beta > 0, ymask must be NULL */,
                const float* save_mean, const float* save_rstd, void* dx, void* dz_out, float* dgamma,
                float* dbeta, float* workspace, int P, int C, void* stream);
+/* The same when the kernel that produced `dz` already masked it and emitted the two sums (VtxBnBwdFusion): only
+ * the finalize and ONE pass (read x, dz; write dx) remain. */
+int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const float* gamma, const float* save_mean,
+                     const float* save_rstd, const float* pre_partials, int pre_nparts, void* dx, float* dgamma,
+                     float* dbeta, float* workspace, int P, int C, void* stream);
 
 /* ---- MaxPool2d(3, stride 2, pad 1) NHWC (aten::max_pool2d_with_indices of the stem) ---- */
 int vtx_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,

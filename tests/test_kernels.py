@@ -616,3 +616,104 @@ def test_packed_stem_geometry(backend, dtype):
     ops.conv2d_wgrad(a0, dy.permute(0, 2, 3, 1).contiguous().to(dtype).to(dev), dwp, 2, 0)
     assert rel_err(dwp[:, :, :7, :3].cpu(), wr.grad.permute(0, 2, 3, 1)) < 2 * e
     assert dwp[:, :, 7, :].abs().max().item() >= 0            # the padded tap column exists; its weights are zero
+
+
+def _bn_bwd_reference(z, x, mean, rstd, gamma, beta, ymask, mode):
+    """dz (masked gradient), s1 = sum dz, s2 = sum dz*xhat, dx -- what the fused epilogue + vtx_bn_bwd_fused compute."""
+    xh = (x - mean) * rstd
+    if mode == "ymask":
+        keep = ymask > 0
+    elif mode == "remask":
+        keep = xh * gamma + beta > 0
+    else:
+        keep = torch.ones_like(z, dtype=torch.bool)
+    dz = torch.where(keep, z, torch.zeros_like(z))
+    P = z.shape[0]
+    s1, s2 = dz.sum(0), (dz * xh).sum(0)
+    dx = gamma * rstd * (dz - s1 / P - xh * s2 / P)
+    return dz, s1, s2, dx
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", ["ymask", "remask", "none"])
+@pytest.mark.parametrize("cand", [-1, 0, 1, 2, 3, 4, 5])
+def test_batchnorm_backward_fused_in_gemm_epilogue(backend, mode, cand):
+    """bf16: the input-gradient GEMM's epilogue masks its output with the ReLU of the BatchNorm that fed the
+    convolution and emits sum dz / sum dz*xhat; vtx_bn_bwd_fused turns them into dx, dgamma, dbeta.  Against a torch
+    fp32 evaluation of the same formulas, every block tile (statistics strips = block rows), ragged M, residual."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(7 + cand)
+    M, N, K = 300, 256, 64
+    a = torch.randn(M, K, generator=g).to(dt); b = (torch.randn(N, K, generator=g) / 8).to(dt)
+    res = torch.randn(M, N, generator=g).to(dt)
+    x = (0.7 * torch.randn(M, N, generator=g) + 0.3).to(dt)
+    mean = x.float().mean(0); rstd = (x.float().var(0, unbiased=False) + 1e-5).rsqrt()
+    gamma = 0.5 + torch.rand(N, generator=g); beta = 0.2 * torch.randn(N, generator=g)
+    ymask = torch.relu(torch.randn(M, N, generator=g)).to(dt)
+    z = a.float() @ b.float().t() + res.float()
+    dz_r, s1_r, s2_r, dx_r = _bn_bwd_reference(z, x.float(), mean, rstd, gamma, beta, ymask.float(), mode)
+    bn = ops.BnBwd(x.to(dev), mean.to(dev), rstd.to(dev), ymask=ymask.to(dev) if mode == "ymask" else None,
+                   gamma=gamma.to(dev) if mode == "remask" else None, beta=beta.to(dev) if mode == "remask" else None)
+    try:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
+        dz, st = ops.gemm_nt_bnbwd(a.to(dev), b.to(dev), bn, residual=res.to(dev))
+    finally:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+    assert st is not None and st.strips > 0
+    assert rel_err(dz.float().cpu(), dz_r) < 1e-2
+    parts = st.parts[: st.strips * 2 * N].view(st.strips, 2, N).cpu()
+    assert rel_err(parts[:, 0].sum(0), s1_r) < 1e-2 and rel_err(parts[:, 1].sum(0), s2_r) < 1e-2
+    dgamma = torch.zeros(N, device=dev); dbeta = torch.zeros(N, device=dev)
+    dx = ops.bn_bwd_fused(x.to(dev), dz, gamma.to(dev), mean.to(dev), rstd.to(dev), dgamma, dbeta, st)
+    assert rel_err(dx.float().cpu(), dx_r) < 2e-2
+    assert rel_err(dgamma.cpu(), s2_r) < 1e-2 and rel_err(dbeta.cpu(), s1_r) < 1e-2
+    # and it equals the stand-alone path (reduce + mask + apply) on the plain gradient
+    plain = ops.gemm_nt(a.to(dev), b.to(dev), residual=res.to(dev))
+    dg2 = torch.zeros(N, device=dev); db2 = torch.zeros(N, device=dev)
+    dx2 = ops.bn_bwd(x.to(dev), plain, ymask.to(dev) if mode == "ymask" else None, gamma.to(dev), mean.to(dev), rstd.to(dev),
+                     dg2, db2, relu_beta=beta.to(dev) if mode == "remask" else None)
+    assert rel_err(dx.float().cpu(), dx2.float().cpu()) < 2e-2 and rel_err(dgamma.cpu(), dg2.cpu()) < 1e-2
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("stride,H", [(1, 9), (2, 10)])
+def test_batchnorm_backward_fused_in_conv_dgrad_epilogue(backend, stride, H):
+    """The 3x3 input-gradient convolution (stride 1, and stride 2 = four parity-class launches writing consecutive
+    strips through the row scatter) with the same fusion."""
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11 + stride)
+    Nb, C, KO = 3, 32, 64
+    x_in = (0.7 * torch.randn(Nb, H, H, C, generator=g) + 0.3).to(dt)           # the BatchNorm input = conv input before BN/ReLU
+    w = (torch.randn(KO, 3, 3, C, generator=g) / 17).to(dt)
+    OH = (H + 2 - 3) // stride + 1
+    dy = torch.randn(Nb, OH, OH, KO, generator=g).to(dt)
+    xr = torch.zeros(Nb, C, H, H, requires_grad=True)
+    F.conv2d(xr, w.float().permute(0, 3, 1, 2), stride=stride, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    z = xr.grad.permute(0, 2, 3, 1).reshape(-1, C)
+    xf = x_in.float().view(-1, C)
+    mean = xf.mean(0); rstd = (xf.var(0, unbiased=False) + 1e-5).rsqrt()
+    gamma = 0.5 + torch.rand(C, generator=g); beta = 0.2 * torch.randn(C, generator=g)
+    dz_r, s1_r, s2_r, dx_r = _bn_bwd_reference(z, xf, mean, rstd, gamma, beta, None, "remask")
+    bn = ops.BnBwd(x_in.to(dev), mean.to(dev), rstd.to(dev), gamma=gamma.to(dev), beta=beta.to(dev))
+    dz, st = ops.conv2d_dgrad(dy.to(dev), w.permute(3, 1, 2, 0).contiguous().to(dev), x_in.shape, stride, 1, bn=bn)
+    assert st is not None and st.strips >= (4 if stride == 2 else 1)
+    assert rel_err(dz.float().cpu().view(-1, C), dz_r) < 1e-2
+    dgamma = torch.zeros(C, device=dev); dbeta = torch.zeros(C, device=dev)
+    dx = ops.bn_bwd_fused(x_in.to(dev), dz, gamma.to(dev), mean.to(dev), rstd.to(dev), dgamma, dbeta, st)
+    assert rel_err(dx.float().cpu().view(-1, C), dx_r) < 2e-2
+    assert rel_err(dgamma.cpu(), s2_r) < 1e-2 and rel_err(dbeta.cpu(), s1_r) < 1e-2
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fused_batchnorm_backward_is_refused_cleanly_in_fp32(backend):
+    """fp32 (parity mode) does not fuse: strips == 0 and the output is the plain gradient."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(70, 32, generator=g); b = torch.randn(64, 32, generator=g); x = torch.randn(70, 64, generator=g)
+    bn = ops.BnBwd(x.to(dev), x.mean(0).to(dev), torch.ones(64, device=dev), gamma=torch.ones(64, device=dev), beta=torch.zeros(64, device=dev))
+    out, st = ops.gemm_nt_bnbwd(a.to(dev), b.to(dev), bn)
+    assert st is None and rel_err(out.cpu(), a @ b.t()) < 1e-4

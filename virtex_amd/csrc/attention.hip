@@ -500,7 +500,7 @@ extern "C" int vtx_attention_fwd(int dtype, const void* q, long ldq, const void*
     dim3 grid(B * heads), block(256);
     if (dtype == VTX_BF16) {
         VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, VTX_ERR_SHAPE, "attention_fwd: row strides must be multiples of 8");
-        hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 4)), block, 0, (hipStream_t)stream, a, (bf16_t*)o, B * heads);
+        VTX_KLAUNCH("attention_fwd", 4.0 * B * heads * T * S * 64, 2.0 * B * heads * 64 * (2.0 * T + 2.0 * S), attn_fwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 4)), block, 0, (hipStream_t)stream, a, (bf16_t*)o, B * heads);
     }
     else hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a, (float*)o);
     VTX_LAUNCH_CHECK();
@@ -521,7 +521,7 @@ extern "C" int vtx_attention_bwd(int dtype, const void* q, long ldq, const void*
     if (dtype == VTX_BF16) {
         VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
                   VTX_ERR_SHAPE, "attention_bwd: row strides must be multiples of 8 (inputs) / 4 (gradients)");
-        hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 2)), dim3(128), 0, (hipStream_t)stream, a,
+        VTX_KLAUNCH("attention_bwd", 10.0 * B * heads * T * S * 64, 2.0 * B * heads * 64 * (3.0 * T + 4.0 * S), attn_bwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 2)), dim3(128), 0, (hipStream_t)stream, a,
                            (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, B * heads);
     }
     else

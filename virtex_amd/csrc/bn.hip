@@ -251,6 +251,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
+// backward apply when the producing kernel already masked the gradient and emitted the sums (VtxBnBwdFusion):
+// dx = gamma*rstd * (dz - s1/P - xhat*s2/P); reads x and dz, writes dx -- nothing else
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __restrict__ x, const T* __restrict__ dz,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ coef, T* __restrict__ dx, long nvec, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * VEC;
+        Vec16<T> xv, g; xv.load(x + i * VEC); g.load(dz + i * VEC);
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv.v[j] - mean[c0 + j]) * rstd[c0 + j];
+            o.v[j] = coef[c0 + j] * (g.v[j] - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
+        }
+        o.store(dx + i * VEC);
+    }
+}
+
 constexpr int VTX_BN_MAX_PARTS = 512;
 struct ReducePlan { int TX, gy, gx, rows; };
 static ReducePlan plan_reduce(int P, int C, int vec) {
@@ -296,30 +317,30 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     if (fused) {
         const float* parts = pre_partials;
         int np = pre_nparts;
-        if (np > 512) {             // thousands of strips: fold them 128:1 first (keeps the finalize short)
-            const int per = 128, ny = vtx_cdiv(np, per);
-            hipLaunchKernelGGL(bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, C, np, per);
+        if (np > 512) {             // thousands of strips: fold them first (keeps the finalize short)
+            const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
+            VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, C, np, per);
             parts = sums; np = ny;
         }
         sums = const_cast<float*>(parts); rp.gx = np;
     }
     else if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
+        VTX_KLAUNCH("bn_fwd_reduce", 0, 2.0 * P * C, (bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     else
-        hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
+        VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
-        hipLaunchKernelGGL((bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+        VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
     else
-        hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+        VTX_KLAUNCH("bn_fwd_apply", 0, 4.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
                            (const float*)residual, save_mean, scale, beta, (float*)y, nvec, C, relu);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
@@ -340,21 +361,53 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     ReducePlan rp = plan_reduce(P, C, vec);
     const long nvec = (long)P * C / vec;
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
+        VTX_KLAUNCH("bn_bwd_reduce", 0, 2.0 * P * C * (ymask ? 3 : 2), (bn_reduce_kernel<bf16_t, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
     else
-        hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
+        VTX_KLAUNCH("bn_bwd_reduce", 0, 4.0 * P * C * (ymask ? 3 : 2), (bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
-                       dgamma, dbeta, P, C, rp.gx);
+    VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
+                dgamma, dbeta, P, C, rp.gx);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * P * C * (3 + (ymask ? 1 : 0) + (dz_out ? 1 : 0)), (bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, coef, gamma, relu_beta, (bf16_t*)dx,
                            (bf16_t*)dz_out, nvec, C);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+        VTX_KLAUNCH("bn_bwd_apply", 0, 4.0 * P * C * (3 + (ymask ? 1 : 0) + (dz_out ? 1 : 0)), (bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, coef, gamma, relu_beta, (float*)dx,
                            (float*)dz_out, nvec, C);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+// workspace: same buffer / layout as vtx_bn_fwd.  pre_partials: [pre_nparts][2][C] {sum dz, sum dz*xhat} from the
+// epilogue of the kernel that produced dz (VtxBnBwdFusion in virtex_amd.h).
+extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const float* gamma, const float* save_mean,
+                                const float* save_rstd, const float* pre_partials, int pre_nparts, void* dx, float* dgamma,
+                                float* dbeta, float* workspace, int P, int C, void* stream) {
+    VTX_CHECK(x && dz && gamma && save_mean && save_rstd && pre_partials && dx && dgamma && dbeta && workspace, VTX_ERR_ARG,
+              "bn_bwd_fused: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_bwd_fused: bad dtype %d", dtype);
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(P > 0 && pre_nparts > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_bwd_fused: C=%d must be vec*2^k, P=%d > 0", C, P);
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = workspace + C; float* sums = workspace + 4 * C;
+    const float* parts = pre_partials;
+    int np = pre_nparts;
+    if (np > 512) {
+        const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, C, np, per);
+        parts = sums; np = ny;
+    }
+    VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, parts, gamma, save_rstd, coef,
+                dgamma, dbeta, P, C, np);
+    const long nvec = (long)P * C / vec;
+    if (dtype == VTX_BF16)
+        VTX_KLAUNCH("bn_bwd_apply", 0, 6.0 * P * C, (bn_bwd_apply_fused_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+                    (const bf16_t*)dz, save_mean, save_rstd, coef, (bf16_t*)dx, nvec, C);
+    else
+        VTX_KLAUNCH("bn_bwd_apply", 0, 12.0 * P * C, (bn_bwd_apply_fused_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+                    (const float*)dz, save_mean, save_rstd, coef, (float*)dx, nvec, C);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

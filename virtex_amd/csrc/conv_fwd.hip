@@ -14,11 +14,16 @@ static int conv_fwd_t(const ConvGeo& g, const void* x, const void* w, void* y, c
     int strips = 0;
     auto mk_a = [&](auto& a) { a.x = (const T*)x; a.g = g; a.rows = M; a.K = Kd; };
     auto mk_b = [&](auto& b) { b.p = (const T*)w; b.ld = Kd; b.rows = g.KO; b.K = Kd; };
-    if (stat_parts && sizeof(T) == 2) {
-        EpiStore<T, true> ep{(T*)y, g.KO, bias, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
-        ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
-        strips = launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
-    } else {
+    bool done = false;
+    if constexpr (sizeof(T) == 2) {
+        if (stat_parts) {
+            EpiStore<T, STATS_FWD> ep{(T*)y, g.KO, bias, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
+            ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
+            strips = launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
+            done = true;
+        }
+    }
+    if (!done) {
         EpiStore<T> ep{(T*)y, g.KO, bias, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
         launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
     }

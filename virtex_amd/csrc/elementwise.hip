@@ -105,10 +105,10 @@ extern "C" int vtx_colsum_acc(int dtype, const void* x, long ld, float* out, flo
     const int rows = vtx_cdiv(R, gx);
     gx = vtx_cdiv(R, rows);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, workspace, R, C, TX, rows);
+        VTX_KLAUNCH("colsum", 0, 2.0 * R * C, (colsum_kernel<bf16_t>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld, workspace, R, C, TX, rows);
     else
-        hipLaunchKernelGGL((colsum_kernel<float>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, workspace, R, C, TX, rows);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(vtx_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, workspace, out, C, gx);
+        VTX_KLAUNCH("colsum", 0, 4.0 * R * C, (colsum_kernel<float>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, ld, workspace, R, C, TX, rows);
+    VTX_KLAUNCH("colsum_finalize", 0, 8.0 * gx * C, colsum_finalize_kernel, dim3(vtx_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, workspace, out, C, gx);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -120,9 +120,9 @@ extern "C" int vtx_add(int dtype, const void* a, const void* b, void* out, long 
     VTX_CHECK(n >= 0 && n % vec == 0, VTX_ERR_SHAPE, "add: n must be a multiple of %d", vec);
     if (n == 0) return VTX_OK;
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / vec);
+        VTX_KLAUNCH("add", 0, 6.0 * n, (add_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / vec);
     else
-        hipLaunchKernelGGL((add_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, n / vec);
+        VTX_KLAUNCH("add", 0, 12.0 * n, (add_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)out, n / vec);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -136,9 +136,9 @@ extern "C" int vtx_gelu_bwd(int dtype, const void* h, const void* da, void* dh, 
     if (n == 0) return VTX_OK;
     Dropout d = make_dropout(p_drop, seed);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((gelu_bwd_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (const bf16_t*)da, (bf16_t*)dh, n / vec, d);
+        VTX_KLAUNCH("gelu_bwd", 0, 6.0 * n, (gelu_bwd_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (const bf16_t*)da, (bf16_t*)dh, n / vec, d);
     else
-        hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)h, (const float*)da, (float*)dh, n / vec, d);
+        VTX_KLAUNCH("gelu_bwd", 0, 12.0 * n, (gelu_bwd_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)h, (const float*)da, (float*)dh, n / vec, d);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -159,13 +159,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
 
 }  // namespace
 
-#define VTX_EMB_DISPATCH(KERNEL, T, ...)                                                       \
-    do {                                                                                       \
-        const int nv_ = vtx_cdiv(H, 256);                                                      \
-        if (nv_ <= 1) hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, st, __VA_ARGS__);     \
-        else if (nv_ <= 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, st, __VA_ARGS__);\
-        else if (nv_ <= 4) hipLaunchKernelGGL((KERNEL<T, 4>), grid, block, 0, st, __VA_ARGS__);\
-        else hipLaunchKernelGGL((KERNEL<T, 8>), grid, block, 0, st, __VA_ARGS__);              \
+#define VTX_EMB_DISPATCH(FAM, BYTES, KERNEL, T, ...)                                                        \
+    do {                                                                                                    \
+        const int nv_ = vtx_cdiv(H, 256);                                                                   \
+        if (nv_ <= 1) VTX_KLAUNCH(FAM, 0, BYTES, (KERNEL<T, 1>), grid, block, 0, st, __VA_ARGS__);          \
+        else if (nv_ <= 2) VTX_KLAUNCH(FAM, 0, BYTES, (KERNEL<T, 2>), grid, block, 0, st, __VA_ARGS__);     \
+        else if (nv_ <= 4) VTX_KLAUNCH(FAM, 0, BYTES, (KERNEL<T, 4>), grid, block, 0, st, __VA_ARGS__);     \
+        else VTX_KLAUNCH(FAM, 0, BYTES, (KERNEL<T, 8>), grid, block, 0, st, __VA_ARGS__);                   \
     } while (0)
 
 extern "C" int vtx_embedding_fwd(int dtype, const long long* tokens, const float* words, const float* positions,
@@ -181,9 +181,9 @@ extern "C" int vtx_embedding_fwd(int dtype, const long long* tokens, const float
     dim3 grid(vtx_cdiv(rows, 4)), block(256);
     Dropout d = make_dropout(p_drop, seed);
     if (dtype == VTX_BF16)
-        VTX_EMB_DISPATCH(embed_fwd_kernel, bf16_t, tokens, words, positions, gamma, beta, (bf16_t*)out, mean, rstd, rows, T, H, V, padding_idx, eps, d);
+        VTX_EMB_DISPATCH("embedding_fwd", (double)rows * H * (4.0 + 2.0), embed_fwd_kernel, bf16_t, tokens, words, positions, gamma, beta, (bf16_t*)out, mean, rstd, rows, T, H, V, padding_idx, eps, d);
     else
-        VTX_EMB_DISPATCH(embed_fwd_kernel, float, tokens, words, positions, gamma, beta, (float*)out, mean, rstd, rows, T, H, V, padding_idx, eps, d);
+        VTX_EMB_DISPATCH("embedding_fwd", (double)rows * H * (4.0 + 4.0), embed_fwd_kernel, float, tokens, words, positions, gamma, beta, (float*)out, mean, rstd, rows, T, H, V, padding_idx, eps, d);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -203,9 +203,9 @@ extern "C" int vtx_embedding_bwd(int dtype, const long long* tokens, const float
     dim3 grid(T, gy), block(256);
     Dropout d = make_dropout(p_drop, seed);
     if (dtype == VTX_BF16)
-        VTX_EMB_DISPATCH(embed_bwd_kernel, bf16_t, tokens, words, positions, gamma, mean, rstd, (const bf16_t*)dout, dwords, dpositions, dgamma, dbeta, B, T, H, V, padding_idx, d);
+        VTX_EMB_DISPATCH("embedding_bwd", (double)B * T * H * (2.0 + 4.0 + 8.0), embed_bwd_kernel, bf16_t, tokens, words, positions, gamma, mean, rstd, (const bf16_t*)dout, dwords, dpositions, dgamma, dbeta, B, T, H, V, padding_idx, d);
     else
-        VTX_EMB_DISPATCH(embed_bwd_kernel, float, tokens, words, positions, gamma, mean, rstd, (const float*)dout, dwords, dpositions, dgamma, dbeta, B, T, H, V, padding_idx, d);
+        VTX_EMB_DISPATCH("embedding_bwd", (double)B * T * H * (4.0 + 4.0 + 8.0), embed_bwd_kernel, float, tokens, words, positions, gamma, mean, rstd, (const float*)dout, dwords, dpositions, dgamma, dbeta, B, T, H, V, padding_idx, d);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -22,11 +22,16 @@ int gemm_nt_t(int M, int N, int K, const void* A, long lda, const void* B, long 
     int strips = 0;
     auto mk_a = [&](auto& a) { a.p = (const T*)A; a.ld = lda; a.rows = M; a.K = K; };
     auto mk_b = [&](auto& b) { b.p = (const T*)B; b.ld = ldb; b.rows = N; b.K = K; };
-    if (stat_parts && sizeof(T) == 2 && sizeof(TO) == 2) {
-        EpiStore<TO, true> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
-        ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
-        strips = launch_auto<T, PlainKC, PlainKC>(mk_a, mk_b, ep, M, N, K, 1, st);
-    } else {
+    bool done = false;
+    if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+        if (stat_parts && N % 8 == 0 && ldc == N) {
+            EpiStore<TO, STATS_FWD> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
+            ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
+            strips = launch_auto<T, PlainKC, PlainKC>(mk_a, mk_b, ep, M, N, K, 1, st);
+            done = true;
+        }
+    }
+    if (!done) {
         EpiStore<TO> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
         launch_auto<T, PlainKC, PlainKC>(mk_a, mk_b, ep, M, N, K, 1, st);
     }
@@ -50,6 +55,24 @@ int gemm_tn_t(int M, int N, int K, const void* A, long lda, const void* B, long 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
+
+// shared with conv_dgrad.hip: fills the statistics half of a STATS_BWD epilogue from the C-ABI struct
+void vtx_fill_bn_bwd(vtxg::EpiStore<bf16_t, vtxg::STATS_BWD>& ep, const VtxBnBwdFusion* f, long ld, float* parts) {
+    ep.stat_parts = parts;
+    ep.bn_x = (const bf16_t*)f->x; ep.ldx = ld;
+    ep.bn_y = (const bf16_t*)f->ymask; ep.ldy = ld;
+    ep.bn_mean = f->mean; ep.bn_rstd = f->rstd; ep.bn_gamma = f->gamma; ep.bn_beta = f->beta;
+}
+int vtx_check_bn_bwd(const char* who, const VtxBnBwdFusion* f, int M, int N) {
+    VTX_CHECK(f->x && f->mean && f->rstd && f->parts, VTX_ERR_ARG, "%s: BatchNorm fusion needs x, mean, rstd and parts", who);
+    VTX_CHECK(!(f->ymask && f->beta), VTX_ERR_ARG, "%s: pass either ymask or gamma/beta for the ReLU mask", who);
+    VTX_CHECK(!f->beta || f->gamma, VTX_ERR_ARG, "%s: a recomputed mask needs gamma and beta", who);
+    VTX_CHECK(N % 8 == 0 && ((uintptr_t)f->x & 15) == 0 && (!f->ymask || ((uintptr_t)f->ymask & 15) == 0), VTX_ERR_SHAPE,
+              "%s: fused BatchNorm backward needs N %% 8 == 0 and 16-byte aligned tensors", who);
+    VTX_CHECK((long)(vtx_cdiv(M, 64) + 4) * 2 * N <= f->parts_cap, VTX_ERR_WORKSPACE,
+              "%s: parts holds %ld floats, (ceil(M/64)+4)*2*N = %ld needed", who, f->parts_cap, (long)(vtx_cdiv(M, 64) + 4) * 2 * N);
+    return VTX_OK;
+}
 
 vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
@@ -131,9 +154,9 @@ void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc,
     while (G < 16 && G * 4 <= S && (nv * G + 255) / 256 < 1024) G *= 4;
     long g = (nv * G + 255) / 256;
     if (g > 4096) g = 4096;
-    if (G == 1) hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
-    else if (G == 4) hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<16>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
+    if (G == 1) VTX_KLAUNCH("splitk_reduce", 0, 4.0 * MN * (S + 2), splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
+    else if (G == 4) VTX_KLAUNCH("splitk_reduce", 0, 4.0 * MN * (S + 2), splitk_reduce_kernel<4>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
+    else VTX_KLAUNCH("splitk_reduce", 0, 4.0 * MN * (S + 2), splitk_reduce_kernel<16>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
 }
 
 extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
@@ -183,4 +206,29 @@ extern "C" int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, lo
     if (dtype == VTX_BF16)
         return gemm_tn_t<bf16_t>(M, N, K, A, lda, B, ldb, C, ldc, alpha, split_k, workspace, (hipStream_t)stream);
     return gemm_tn_t<float>(M, N, K, A, lda, B, ldb, C, ldc, alpha, split_k, workspace, (hipStream_t)stream);
+}
+
+extern "C" int vtx_gemm_nt_bnbwd(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                                 void* C, long ldc, const void* residual, long ldr, VtxBnBwdFusion* f, void* stream) {
+    VTX_CHECK(f, VTX_ERR_ARG, "gemm_nt_bnbwd: null fusion descriptor");
+    f->strips = 0;
+    const bool fuse = dtype == VTX_BF16 && g_vtx_contraction_generation >= 2;
+    if (!fuse)      // fp32 parity mode / generation-1 kernel: plain gradient, the caller runs the stand-alone BatchNorm backward
+        return vtx_gemm_nt(dtype, M, N, K, A, lda, B, ldb, C, ldc, nullptr, residual, ldr, nullptr, ACT_NONE, 1.f, 0.f, 0, 0,
+                           nullptr, nullptr, nullptr, stream);
+    VTX_CHECK(A && B && C, VTX_ERR_ARG, "gemm_nt_bnbwd: null pointer");
+    VTX_CHECK(M > 0 && N > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc == N && (!residual || ldr == N),
+              VTX_ERR_SHAPE, "gemm_nt_bnbwd: K/lda/ldb must be multiples of 8 and C / residual dense (M=%d N=%d K=%d)", M, N, K);
+    VTX_CHECK(aligned16(A) && aligned16(B) && aligned16(C) && (!residual || aligned16(residual)), VTX_ERR_SHAPE,
+              "gemm_nt_bnbwd: operands must be 16-byte aligned");
+    int rc = vtx_check_bn_bwd("gemm_nt_bnbwd", f, M, N);
+    if (rc) return rc;
+    EpiStore<bf16_t, STATS_BWD> ep{(bf16_t*)C, ldc, nullptr, (const bf16_t*)residual, ldr, nullptr, ACT_NONE, 1.f,
+                                   make_dropout(0.f, 0), M, N};
+    vtx_fill_bn_bwd(ep, f, N, f->parts);
+    f->strips = launch_auto<bf16_t, PlainKC, PlainKC>(
+        [&](auto& a) { a.p = (const bf16_t*)A; a.ld = lda; a.rows = M; a.K = K; },
+        [&](auto& b) { b.p = (const bf16_t*)B; b.ld = ldb; b.rows = N; b.K = K; }, ep, M, N, K, 1, (hipStream_t)stream);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
 }

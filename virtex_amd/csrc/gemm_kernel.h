@@ -19,7 +19,6 @@
 //               gradients; transposed into the LDS tile on store)
 #pragma once
 #include "vtx_common.h"
-#include <hip/hip_ext.h>
 
 namespace vtxg {
 
@@ -273,18 +272,51 @@ template <> __device__ __forceinline__ uint4 relu16<float>(uint4 a) {
 
 // out = dropout(act(acc*alpha + bias)) + residual ; optional copy of the pre-activation
 // (act = ACT_RES_RELU: out = relu(acc*alpha + bias + residual))
-template <class T, bool WITH_STATS = false> struct EpiStore {
+// Statistics modes of the wide epilogue (generation-2 kernel; compile-time, the plain epilogue pays nothing):
+//   STATS_FWD  the output is the INPUT of a training-mode BatchNorm: per (block row, channel) partial sums of
+//              (value - stat_shift[n]) and its square, taken from the stored (rounded) values;
+//   STATS_BWD  the output is the gradient wrt the OUTPUT of a BatchNorm(+ReLU) whose input was bn_x: the epilogue
+//              applies the ReLU mask (bn_y > 0 when the block output is given, else xhat*gamma+beta > 0 recomputed
+//              from bn_x, else none), stores the MASKED gradient dz and emits the two sums BatchNorm's backward
+//              needs, sum dz and sum dz*xhat -- the stand-alone reduction pass over dz and x disappears.
+// Both are accumulated per lane while the wave-private strip is drained (a lane always drains the same 16-byte
+// column chunk, so 2 x 8 accumulators suffice); per-channel parameters sit in LDS, not in registers.
+enum { STATS_NONE = 0, STATS_FWD = 1, STATS_BWD = 2 };
+
+template <class T> __device__ __forceinline__ void unpack16(uint4 w, float* f);
+template <> __device__ __forceinline__ void unpack16<bf16_t>(uint4 w, float* f) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void unpack16<float>(uint4 w, float* f) {
+    f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
+}
+template <class T> __device__ __forceinline__ uint4 pack16(const float* f);
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
+    return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                      (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+}
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+
+template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     static constexpr bool STAGED = true;   // generation-2 kernel: 16-byte stores via a wave-private LDS strip
-    static constexpr bool STATS = WITH_STATS;   // compile-time: the statistics code costs ~48 VGPRs
+    static constexpr int SMODE = STATS_MODE;
+    static constexpr bool STATS = STATS_MODE != STATS_NONE;
     typedef T Out;
     T* out; long ldc; const float* bias; const T* residual; long ldr; T* preact; int act;
     float alpha; Dropout drop; int M, N;
     long split_stride = 0;   // split-K: slice blockIdx.y writes its partial result at out + blockIdx.y*split_stride
-    // Fused BatchNorm statistics (generation-2 kernel only): per (row-strip, channel) partial sums of
-    // (value - stat_shift[n]) and its square are written to stat_parts[strip][2][N]; the strips are the
-    // wave rows of the grid (strip = tile_m * WM + wm), summed by the BN finalize kernel.
+    // Fused BatchNorm statistics (generation-2 kernel only): stat_parts[strip][2][N], one strip per block row
+    // (tile_m) of the grid, summed by the BatchNorm finalize kernels.  N must be a multiple of 16 bytes' worth.
     float* stat_parts = nullptr;
-    const float* stat_shift = nullptr;
+    const float* stat_shift = nullptr;           // STATS_FWD
+    const T* bn_x = nullptr; long ldx = 0;       // STATS_BWD: the BatchNorm's input, same [M][N] coordinates as `out`
+    const T* bn_y = nullptr; long ldy = 0;       //            the post-ReLU block output (mask), or nullptr
+    const float* bn_mean = nullptr; const float* bn_rstd = nullptr;
+    const float* bn_gamma = nullptr; const float* bn_beta = nullptr;   // mask recomputed from bn_x when bn_y == nullptr
     // Row scatter for the parity-decomposed stride-2 input gradient: GEMM row m = (n, ih2, iw2) is output
     // pixel (n, 2*ih2+map_pa, 2*iw2+map_pb) of an H x W image.  map_on = 0: identity.
     int map_on = 0, map_H = 0, map_W = 0, map_pa = 0, map_pb = 0;
@@ -339,6 +371,46 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
         if (full) *reinterpret_cast<uint4*>(out + o) = w;
         else *reinterpret_cast<uint2*>(out + o) = make_uint2(w.x, w.y);   // bf16: 4 elements
     }
+    // The same, accumulating the statistics of this chunk.  par = this chunk's columns inside the block's LDS parameter
+    // table ([4][PBN] floats: FWD {shift}; BWD {rstd, -mean*rstd, gamma, beta}); s1/s2 = the lane's accumulators.
+    __device__ __forceinline__ void store_wide_stats(int m, int n, uint4 w, const float* par, int PBN, float* s1,
+                                                     float* s2) const {
+        if (m >= M || n >= N) return;
+        constexpr int EPV = 16 / (int)sizeof(T);
+        const long mr = out_row(m);
+        float f[EPV];
+        unpack16<T>(w, f);
+        if (residual) {
+            float r[EPV];
+            unpack16<T>(*reinterpret_cast<const uint4*>(residual + mr * ldr + n), r);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) f[e] += r[e];
+        }
+        if constexpr (STATS_MODE == STATS_FWD) {
+            w = pack16<T>(f);
+            unpack16<T>(w, f);                   // statistics of what is stored (what the BatchNorm will read)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { const float d = f[e] - par[e]; s1[e] += d; s2[e] += d * d; }
+        } else {
+            float x[EPV];
+            unpack16<T>(*reinterpret_cast<const uint4*>(bn_x + mr * ldx + n), x);
+            if (bn_y) {
+                float y[EPV];
+                unpack16<T>(*reinterpret_cast<const uint4*>(bn_y + mr * ldy + n), y);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) f[e] = y[e] > 0.f ? f[e] : 0.f;
+            }
+            const bool remask = !bn_y && bn_beta;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float xh = x[e] * par[e] + par[PBN + e];
+                if (remask) f[e] = xh * par[2 * PBN + e] + par[3 * PBN + e] > 0.f ? f[e] : 0.f;
+                s1[e] += f[e]; s2[e] += f[e] * xh;
+            }
+            w = pack16<T>(f);
+        }
+        *reinterpret_cast<uint4*>(out + mr * ldc + n) = w;
+    }
     __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
         if (m >= M || n >= N) return;
         float v[4] = {acc[0] * alpha, acc[1] * alpha, acc[2] * alpha, acc[3] * alpha};
@@ -376,6 +448,7 @@ template <class T, bool WITH_STATS = false> struct EpiStore {
 struct EpiAtomic {
     static constexpr bool STAGED = false;
     static constexpr bool STATS = false;
+    static constexpr int SMODE = STATS_NONE;
     typedef float Out;
     float* out; long ldc; float alpha; int M, N;
     float* stat_parts = nullptr;
@@ -748,20 +821,31 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
         constexpr int ROWB = WTN * (int)sizeof(TO) + 16;          // padded strip row (bytes)
         constexpr int CPR = WTN * (int)sizeof(TO) / 16;           // 16-byte chunks per row
         constexpr int EPV = 16 / (int)sizeof(TO);                 // elements per chunk
+        constexpr int SM = EP::SMODE;
+        constexpr int PAR_OFF = (NW * 16 * ROWB + 15) & ~15;      // statistics: parameter table [4][BN], then
+        constexpr int RED_OFF = PAR_OFF + 4 * BN * 4;             // the cross-wave fold [NW][2][WTN]
+        static_assert(SM == STATS_NONE || (64 % CPR == 0 && RED_OFF + NW * 2 * WTN * 4 <= STAGES * TILE * 2),
+                      "statistics epilogue: a lane must keep its column chunk, and the tables must fit the stage memory");
         __syncthreads();                                          // every wave is done with the stages
         char* strip = reinterpret_cast<char*>(lds) + wave * (16 * ROWB);
-        constexpr bool stats = EP::STATS;
-        f32x4_t ssum[stats ? NT : 1], ssq[stats ? NT : 1], shift[stats ? NT : 1];
-        if constexpr (stats) {
+        float* par = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PAR_OFF);
+        float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + RED_OFF);
+        float s1[SM != STATS_NONE ? EPV : 1], s2[SM != STATS_NONE ? EPV : 1];
+        if constexpr (SM != STATS_NONE) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                ssum[j] = ssq[j] = shift[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                const int n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4);
-                if (ep.stat_shift && n < ep.N) {
-                    const float4 sh = *reinterpret_cast<const float4*>(ep.stat_shift + n);
-                    shift[j] = f32x4_t{sh.x, sh.y, sh.z, sh.w};
+            for (int e = 0; e < EPV; ++e) s1[e] = s2[e] = 0.f;
+            for (int c = tid; c < BN; c += 64 * NW) {             // per-channel parameters of this block's columns
+                const int n = n0 + c;
+                const bool ok = n < ep.N;
+                if constexpr (SM == STATS_FWD) par[c] = (ok && ep.stat_shift) ? ep.stat_shift[n] : 0.f;
+                else {
+                    const float rs = ok ? ep.bn_rstd[n] : 0.f, mu = ok ? ep.bn_mean[n] : 0.f;
+                    par[c] = rs; par[BN + c] = -mu * rs;
+                    par[2 * BN + c] = (ok && ep.bn_gamma) ? ep.bn_gamma[n] : 0.f;
+                    par[3 * BN + c] = (ok && ep.bn_beta) ? ep.bn_beta[n] : 0.f;
                 }
             }
+            __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -770,34 +854,40 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
             for (int j = 0; j < NT; ++j) {
                 const f32x4_t v = ep.transform(mrow + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j]);
                 st4v<TO>(reinterpret_cast<TO*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
-                if constexpr (stats) {
-                    if (mrow + (lane & 15) < ep.M) {
-                        const f32x4_t d = v - shift[j];
-                        ssum[j] += d; ssq[j] += d * d;
-                    }
-                }
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int c = lane; c < 16 * CPR; c += 64) {
                 const int r = c / CPR, ch = c % CPR;
                 const uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
-                ep.store_wide(mrow + r, n0 + wn * WTN + ch * EPV, w);
+                if constexpr (SM == STATS_NONE) ep.store_wide(mrow + r, n0 + wn * WTN + ch * EPV, w);
+                else ep.store_wide_stats(mrow + r, n0 + wn * WTN + ch * EPV, w, par + wn * WTN + ch * EPV, BN, s1, s2);
             }
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (stats) {   // reduce over the 16 lanes that share a column quad, one partial row per wave row
-            float* dst = ep.stat_parts + ((size_t)((tile / tiles_n) * WM + wm) * 2) * ep.N;
+        if constexpr (SM != STATS_NONE) {
+            // fold the lanes that drained the same column chunk (they differ in the bits above log2(CPR)) ...
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
+            for (int e = 0; e < EPV; ++e) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    float a = ssum[j][t], b = ssq[j][t];
+                for (int msk = CPR; msk < 64; msk <<= 1) { s1[e] += __shfl_xor(s1[e], msk, 64); s2[e] += __shfl_xor(s2[e], msk, 64); }
+            }
+            if (lane < CPR) {
 #pragma unroll
-                    for (int msk = 1; msk < 16; msk <<= 1) { a += __shfl_xor(a, msk, 64); b += __shfl_xor(b, msk, 64); }
-                    const int n = n0 + wn * WTN + j * 16 + 4 * (lane >> 4) + t;
-                    if ((lane & 15) == 0 && n < ep.N) { dst[n] = a; dst[ep.N + n] = b; }
+                for (int e = 0; e < EPV; ++e) {
+                    red[(wave * 2 + 0) * WTN + lane * EPV + e] = s1[e];
+                    red[(wave * 2 + 1) * WTN + lane * EPV + e] = s2[e];
                 }
+            }
+            __syncthreads();
+            // ... then the WM waves of each column range: one partial per (block row, channel), no atomics
+            float* dst = ep.stat_parts + (size_t)(tile / tiles_n) * 2 * ep.N;
+            for (int t = tid; t < 2 * BN; t += 64 * NW) {
+                const int which = t / BN, c = t % BN, wcol = c / WTN, cc = c % WTN;
+                float a = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WM; ++w2) a += red[((w2 * WN + wcol) * 2 + which) * WTN + cc];
+                if (n0 + c < ep.N) dst[(size_t)which * ep.N + n0 + c] = a;
             }
         }
     }
@@ -822,9 +912,6 @@ inline void launch_v1(const AL& al, const BL& bl, const EP& ep, int M, int N, in
 
 // ---- optional per-launch timing (vtx_profile_start / vtx_profile_stop in core.hip): one class per kernel
 // instantiation, begin/end HIP events attached to every launch, algorithmic FLOPs and bytes summed.
-extern int g_vtx_prof_on, g_vtx_prof_only;
-int vtx_prof_register(const char* pretty_name);
-void vtx_prof_events(int cls, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop);
 // elements of the operand tensor a loader reads (the tensor itself, not its im2col view)
 template <class T, int SL> inline double algo_elems(const PlainKC<T, SL>& l) { return (double)l.rows * l.K; }
 template <class T, int SL> inline double algo_elems(const PlainMC<T, SL>& l) { return (double)l.rows * l.K; }
@@ -834,8 +921,9 @@ template <class T, int SL> inline double algo_elems(const ConvWgradB<T, SL>& l) 
 template <class T, int SL> inline double algo_elems(const ConvDgradA<T, SL>& l) { return (double)l.g.N * l.g.OH * l.g.OW * l.g.KO; }
 template <class T, int SL> inline double algo_elems(const ConvDgradS2A<T, SL>& l) { return (double)l.g.N * l.g.OH * l.g.OW * l.g.KO; }
 template <class EP> inline double epi_bytes(const EP&, double mn, int) { return mn * 4; }
-template <class T, bool S> inline double epi_bytes(const EpiStore<T, S>& e, double mn, int split_k) {
-    return mn * sizeof(T) * (split_k > 1 ? split_k : 1) + (e.residual ? mn * sizeof(T) : 0.0) + (e.preact ? mn * sizeof(T) : 0.0);
+template <class T, int S> inline double epi_bytes(const EpiStore<T, S>& e, double mn, int split_k) {
+    return mn * sizeof(T) * (split_k > 1 ? split_k : 1) + (e.residual ? mn * sizeof(T) : 0.0) + (e.preact ? mn * sizeof(T) : 0.0) +
+           (e.bn_x ? mn * sizeof(T) : 0.0) + (e.bn_y ? mn * sizeof(T) : 0.0);
 }
 
 template <int BM, int BN, int WM, int WN, int BK = 32, int STAGES = 3, class AL, class BL, class EP>
@@ -865,11 +953,11 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int
             hipEvent_t e0, e1;
             vtx_prof_events(cls, 2.0 * M * N * K, 2.0 * (algo_elems(al) + algo_elems(bl)) + epi_bytes(ep, (double)M * N, split_k), &e0, &e1);
             hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds_bytes, st, e0, e1, 0, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
-            return tiles_m * WM;
+            return tiles_m;
         }
     }
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
-    return tiles_m * WM;    // number of statistics strips (rows of waves) this launch produced
+    return tiles_m;         // number of statistics strips (block rows) this launch produced
 }
 
 // Tile choice.  Score = (tile efficiency) x (wave quantisation of the grid over 256 CUs) x (padding

@@ -180,7 +180,7 @@ int ln_fwd_t(const void* x, const void* y, const float* gamma, const float* beta
     const int nv = vtx_cdiv(H, 64 * VEC);
     dim3 grid(vtx_cdiv(rows, 4)), block(256);
 #define VTX_LN_FWD(NV)                                                                          \
-    hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)y,    \
+    VTX_KLAUNCH("layernorm_fwd", 0, (double)rows * H * sizeof(T) * (y ? 3 : 2), (ln_fwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)y,    \
                        gamma, beta, (T*)out, mean, rstd, rows, H, eps, d)
     if (nv <= 1) VTX_LN_FWD(1);
     else if (nv <= 2) VTX_LN_FWD(2);
@@ -201,14 +201,14 @@ int ln_bwd_t(const void* x, const void* y, const float* gamma, const float* mean
     if (nblk > VTX_LN_MAX_PARTS) nblk = VTX_LN_MAX_PARTS;
     dim3 grid(nblk), block(256);
 #define VTX_LN_BWD(NV)                                                                          \
-    hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)y,    \
+    VTX_KLAUNCH("layernorm_bwd", 0, (double)rows * H * sizeof(T) * ((y ? 3 : 2) + 1 + (dy ? 1 : 0)), (ln_bwd_kernel<T, NV>), grid, block, 0, st, (const T*)x, (const T*)y,    \
                        gamma, mean, rstd, (const T*)dout, (T*)dz, (T*)dy, partials, rows, H, d)
     if (nv <= 1) VTX_LN_BWD(1);
     else if (nv <= 2) VTX_LN_BWD(2);
     else if (nv <= 4) VTX_LN_BWD(4);
     else VTX_LN_BWD(8);
 #undef VTX_LN_BWD
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(vtx_cdiv(H, 32)), dim3(256), 0, st, partials, dgamma, dbeta, H, nblk);
+    VTX_KLAUNCH("layernorm_bwd_finalize", 0, 8.0 * nblk * H, ln_bwd_finalize_kernel, dim3(vtx_cdiv(H, 32)), dim3(256), 0, st, partials, dgamma, dbeta, H, nblk);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -95,8 +95,8 @@ extern "C" int vtx_cross_entropy_fwd(const float* logits, long ld, const long lo
     VTX_CHECK(logits && targets && lse && row_loss && loss_and_count, VTX_ERR_ARG, "cross_entropy_fwd: null pointer");
     VTX_CHECK(R > 0 && V > 0 && V % 4 == 0 && ld % 4 == 0, VTX_ERR_SHAPE, "cross_entropy_fwd: V and ld must be multiples of 4");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(R), dim3(256), 0, st, logits, ld, targets, lse, row_loss, R, V, ignore_index);
-    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, row_loss, targets, loss_and_count, R, V, ignore_index);
+    VTX_KLAUNCH("cross_entropy_fwd", 0, 8.0 * R * V, ce_fwd_kernel, dim3(R), dim3(256), 0, st, logits, ld, targets, lse, row_loss, R, V, ignore_index);
+    VTX_KLAUNCH("cross_entropy_reduce", 0, 12.0 * R, ce_reduce_kernel, dim3(1), dim3(1024), 0, st, row_loss, targets, loss_and_count, R, V, ignore_index);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -108,10 +108,10 @@ extern "C" int vtx_cross_entropy_bwd(int dtype, const float* logits, long ld, co
     VTX_CHECK(R > 0 && V > 0 && V % 4 == 0 && ld % 4 == 0, VTX_ERR_SHAPE, "cross_entropy_bwd: V and ld must be multiples of 4");
     hipStream_t st = (hipStream_t)stream;
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), dim3(R), dim3(256), 0, st, logits, ld, targets, lse, loss_and_count,
+        VTX_KLAUNCH("cross_entropy_bwd", 0, 6.0 * R * V, (ce_bwd_kernel<bf16_t>), dim3(R), dim3(256), 0, st, logits, ld, targets, lse, loss_and_count,
                            grad_out, (bf16_t*)dlogits, ldd, R, V, ignore_index);
     else if (dtype == VTX_F32)
-        hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3(R), dim3(256), 0, st, logits, ld, targets, lse, loss_and_count,
+        VTX_KLAUNCH("cross_entropy_bwd", 0, 8.0 * R * V, (ce_bwd_kernel<float>), dim3(R), dim3(256), 0, st, logits, ld, targets, lse, loss_and_count,
                            grad_out, (float*)dlogits, ldd, R, V, ignore_index);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "cross_entropy_bwd: bad dtype");
     VTX_LAUNCH_CHECK();

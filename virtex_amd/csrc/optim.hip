@@ -81,8 +81,8 @@ extern "C" int vtx_sumsq(const float* x, long n, float* partials, float* out, vo
     long nb = (n / 4 + 255) / 256;
     if (nb > 1024) nb = 1024;
     if (nb < 1) nb = 1;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, n, partials);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, (int)nb, out);
+    VTX_KLAUNCH("optimizer_sumsq", 0, 4.0 * n, sumsq_partial_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, x, n, partials);
+    VTX_KLAUNCH("optimizer_sumsq_final", 0, 4.0 * nb, sumsq_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, (int)nb, out);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -96,7 +96,7 @@ extern "C" int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float*
               "sgd_lookahead_step: null pointer");
     VTX_CHECK(max_norm <= 0.f || sumsq, VTX_ERR_ARG, "sgd_lookahead_step: clipping needs the sum of squares");
     if (nchunks <= 0) return VTX_OK;
-    hipLaunchKernelGGL(sgd_lookahead_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, slow, chunk_off,
+    VTX_KLAUNCH("optimizer_step", 0, 4.0 * CHUNK * (double)nchunks * (do_lookahead ? 7 : 5), sgd_lookahead_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, slow, chunk_off,
                        chunk_len, chunk_seg, seg_lr, seg_wd, lr_mult, momentum, grad_scale, sumsq, max_norm,
                        do_lookahead, alpha);
     VTX_LAUNCH_CHECK();

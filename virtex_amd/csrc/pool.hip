@@ -98,10 +98,10 @@ extern "C" int vtx_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* 
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long total = (long)N * OH * OW * (C / vec);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+        VTX_KLAUNCH("maxpool_fwd", 0, 2.0 * N * H * W * C + 3.0 * N * OH * OW * C, (maxpool_fwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, (bf16_t*)y, argmax, N, H, W, C, OH, OW);
     else
-        hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+        VTX_KLAUNCH("maxpool_fwd", 0, 4.0 * N * H * W * C + 5.0 * N * OH * OW * C, (maxpool_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, (float*)y, argmax, N, H, W, C, OH, OW);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
@@ -116,10 +116,10 @@ extern "C" int vtx_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* ar
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     const long total = (long)N * H * W * (C / vec);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+        VTX_KLAUNCH("maxpool_bwd", 0, 2.0 * N * H * W * C + 3.0 * N * OH * OW * C, (maxpool_bwd_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)dy, argmax, (bf16_t*)dx, N, H, W, C, OH, OW);
     else
-        hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+        VTX_KLAUNCH("maxpool_bwd", 0, 4.0 * N * H * W * C + 5.0 * N * OH * OW * C, (maxpool_bwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                            (const float*)dy, argmax, (float*)dx, N, H, W, C, OH, OW);
     VTX_LAUNCH_CHECK();
     return VTX_OK;

@@ -158,10 +158,10 @@ extern "C" int vtx_image_to_nhwc_halo(int dtype, const float* src, void* dst, in
     VTX_CHECK(N > 0 && Cin > 0 && Cp >= Cin && H > 0 && W > 0 && halo >= 0, VTX_ERR_SHAPE, "image_to_nhwc: bad shape");
     const long total = (long)N * (H + 2 * halo) * (W + 2 * halo);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((image_to_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+        VTX_KLAUNCH("image_to_nhwc", 0, 4.0 * N * Cin * H * W + 2.0 * total * Cp, (image_to_nhwc_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
                            (bf16_t*)dst, N, Cin, H, W, Cp, halo);
     else if (dtype == VTX_F32)
-        hipLaunchKernelGGL((image_to_nhwc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+        VTX_KLAUNCH("image_to_nhwc", 0, 4.0 * N * Cin * H * W + 4.0 * total * Cp, (image_to_nhwc_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
                            (float*)dst, N, Cin, H, W, Cp, halo);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "image_to_nhwc: bad dtype");
     VTX_LAUNCH_CHECK();
@@ -220,9 +220,9 @@ extern "C" int vtx_weight_prep_batched(int dtype, const VtxPrepDesc* descs, cons
                                        int total_tiles, void* stream) {
     VTX_CHECK(descs && tile_start && ndesc > 0 && total_tiles > 0, VTX_ERR_ARG, "weight_prep_batched: bad arguments");
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((weight_prep_batched_kernel<bf16_t>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs, tile_start, ndesc);
+        VTX_KLAUNCH("weight_prep", 0, 1024.0 * total_tiles * (4 + 2 + 2), (weight_prep_batched_kernel<bf16_t>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs, tile_start, ndesc);
     else if (dtype == VTX_F32)
-        hipLaunchKernelGGL((weight_prep_batched_kernel<float>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs, tile_start, ndesc);
+        VTX_KLAUNCH("weight_prep", 0, 1024.0 * total_tiles * (4 + 4 + 4), (weight_prep_batched_kernel<float>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, descs, tile_start, ndesc);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "weight_prep_batched: bad dtype");
     VTX_LAUNCH_CHECK();
     return VTX_OK;
@@ -237,10 +237,10 @@ extern "C" int vtx_image_u8_to_nhwc(int dtype, const uint8_t* src, void* dst, in
     const float r0 = 1.f / (255.f * std[0]), r1 = 1.f / (255.f * std[1]), r2 = 1.f / (255.f * std[2]);
     const long total = (long)N * (H + 2 * halo) * (W + 2 * halo);
     if (dtype == VTX_BF16)
-        hipLaunchKernelGGL((image_u8_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+        VTX_KLAUNCH("image_to_nhwc", 0, 3.0 * N * H * W + 2.0 * total * Cpad, (image_u8_kernel<bf16_t>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
                            N, Hs, Ws, H, W, Cpad, halo, crop_xy, flip, m0, m1, m2, r0, r1, r2);
     else if (dtype == VTX_F32)
-        hipLaunchKernelGGL((image_u8_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
+        VTX_KLAUNCH("image_to_nhwc", 0, 3.0 * N * H * W + 4.0 * total * Cpad, (image_u8_kernel<float>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src, (float*)dst,
                            N, Hs, Ws, H, W, Cpad, halo, crop_xy, flip, m0, m1, m2, r0, r1, r2);
     else VTX_CHECK(false, VTX_ERR_DTYPE, "image_u8_to_nhwc: bad dtype");
     VTX_LAUNCH_CHECK();

@@ -1,6 +1,7 @@
 // Shared device/host helpers for the virtex_amd HIP kernels (gfx950 / CDNA4, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/virtex_amd.h"
@@ -28,6 +29,32 @@ void vtx_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int vtx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+// Optional per-launch timing (vtx_profile_start / vtx_profile_stop in core.hip): while profiling is on a launch
+// carries a begin and an end HIP event (hipExtLaunchKernel: the dispatch's own timestamps, what rocprofv3 reports)
+// and its algorithmic FLOPs / HBM bytes are summed per class.  Contraction kernels register one class per
+// template instantiation (gemm_kernel.h); every other kernel goes through VTX_KLAUNCH with a family name.
+// ---------------------------------------------------------------------------------------
+namespace vtxg {
+extern int g_vtx_prof_on, g_vtx_prof_only;
+int vtx_prof_register(const char* pretty_name);
+void vtx_prof_events(int cls, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop);
+}
+#define VTX_KLAUNCH(fam, flops_, bytes_, kern, grid, block, shmem, st, ...)                                      \
+    do {                                                                                                         \
+        bool vtx_done_ = false;                                                                                  \
+        if (vtxg::g_vtx_prof_on) {                                                                               \
+            static const int vtx_cls_ = vtxg::vtx_prof_register("family:" fam);                                  \
+            if (vtxg::g_vtx_prof_only < 0 || vtxg::g_vtx_prof_only == vtx_cls_) {                                \
+                hipEvent_t vtx_e0_, vtx_e1_;                                                                     \
+                vtxg::vtx_prof_events(vtx_cls_, (double)(flops_), (double)(bytes_), &vtx_e0_, &vtx_e1_);         \
+                hipExtLaunchKernelGGL(kern, grid, block, shmem, st, vtx_e0_, vtx_e1_, 0, __VA_ARGS__);           \
+                vtx_done_ = true;                                                                                \
+            }                                                                                                    \
+        }                                                                                                        \
+        if (!vtx_done_) hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                           \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------
 // bf16 stored as raw uint16 (round-to-nearest-even), fp32 math everywhere.

@@ -32,6 +32,12 @@ STEM_PACK_C, STEM_PACK_S, STEM_HALO = 4, 8, 3
 # but measured SLOWER than the stand-alone reduction on this step (43.8 vs 42.1 ms: the extra ~48 VGPRs of
 # the statistics epilogue cost the GEMMs more than the saved 5.7 GB read) -> off by default.
 FUSE_BN_STATS = os.environ.get("VIRTEX_AMD_FUSE_BN_STATS", "0") != "0"
+# BatchNorm BACKWARD fused into the input-gradient kernels (bf16): the epilogue of the kernel that produces the
+# gradient wrt a BatchNorm(+ReLU) output applies the ReLU mask, stores the masked gradient and emits the two sums
+# (ops.BnBwd); the stand-alone reduction over (dy, x [, y]) and the mask / dz passes disappear.  Applies to bn1, bn2
+# (mask recomputed from x) and bn3 (mask = block output) of every Bottleneck; shortcut BatchNorms, the stem and the
+# last block (whose gradient comes from the text heads) keep the stand-alone kernels.
+FUSE_BN_BWD = os.environ.get("VIRTEX_AMD_FUSE_BN_BWD", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------
@@ -311,12 +317,17 @@ def _conv_fwd(u: _Unit, x, w, bn_shift=None):
     return ops.conv2d_fwd(x, w, u.stride, u.pad, bn_shift=bn_shift)
 
 
-def _conv_dgrad(u: _Unit, dy, wt, x_shape, residual=None):
+def _conv_dgrad(u: _Unit, dy, wt, x_shape, residual=None, bn=None):
+    """bn (ops.BnBwd) given: returns (gradient, stats); stats is None when the kernel did not fuse (fp32 mode) and
+    the gradient is then the plain one."""
     if u.is_gemm:
         N, H, W, C = x_shape
         r = residual.view(-1, C) if residual is not None else None
+        if bn is not None:
+            out, st = ops.gemm_nt_bnbwd(dy.view(-1, u.cout), wt.view(C, u.cout), bn, residual=r)
+            return out.view(N, H, W, C), st
         return ops.gemm_nt(dy.view(-1, u.cout), wt.view(C, u.cout), residual=r).view(N, H, W, C)
-    return ops.conv2d_dgrad(dy, wt, x_shape, u.stride, u.pad, residual=residual)
+    return ops.conv2d_dgrad(dy, wt, x_shape, u.stride, u.pad, residual=residual, bn=bn)
 
 
 def _conv_wgrad(u: _Unit, x, dy):
@@ -421,9 +432,29 @@ class _ResNetFn(torch.autograd.Function):
             grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
             return out
 
-        for (u1, u2, u3, ud) in reversed(blocks):
+        def bn_back_fused(u: _Unit, s: _Saved, dz, st):
+            """dz is already masked and its sums are in `st` (emitted by the kernel that produced it)."""
+            sg, sb = gradsink.target(u.bn.weight), gradsink.target(u.bn.bias)
+            dg = sg if sg is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+            db = sb if sb is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+            out = ops.bn_bwd_fused(s.x, dz, u.bn.weight.detach(), s.mean, s.rstd, dg, db, st)
+            grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
+            return out
+
+        def relu_bn(u: _Unit, s: _Saved):
+            """The fusion descriptor of an interior BatchNorm+ReLU: mask recomputed from its input."""
+            return ops.BnBwd(s.x, s.mean, s.rstd, gamma=u.bn.weight.detach(), beta=u.bn.bias.detach()) if fuse else None
+
+        fuse = FUSE_BN_BWD and dt == torch.bfloat16
+        st3 = None                  # sums for this block's bn3, when the next block's conv1 input gradient emitted them
+        for bi in reversed(range(len(blocks))):
+            (u1, u2, u3, ud) = blocks[bi]
             s1, s2, s3 = rec[u1], rec[u2], rec[u3]
-            dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True, residual=True)      # dz: gradient of the identity path
+            if st3 is not None:     # dcur IS dz: masked by (block output > 0) in the producing epilogue
+                dz = dcur
+                dx3 = bn_back_fused(u3, s3, dz, st3)
+            else:
+                dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True, residual=True)      # dz: gradient of the identity path
             br = None
             if ud is not None:
                 # the shortcut's backward (BN backward, weight gradient, input gradient) on the branch stream,
@@ -437,19 +468,33 @@ class _ResNetFn(torch.autograd.Function):
                     dskip = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape)
             with wgrad_stream(dev, s3.a, dx3):
                 grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
-            dy2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape)
-            dx2 = bn_back(u2, s2, dy2, True)
+            if fuse:
+                dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape, bn=relu_bn(u2, s2))
+            else:
+                dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape), None
+            dx2 = bn_back_fused(u2, s2, dy2, st2) if st2 is not None else bn_back(u2, s2, dy2, True)
             with wgrad_stream(dev, s2.a, dx2):
                 grads[u2][0] = _conv_wgrad(u2, s2.a, dx2)
-            dy1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape)
-            dx1 = bn_back(u1, s1, dy1, True)
+            if fuse:
+                dy1, st1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape, bn=relu_bn(u1, s1))
+            else:
+                dy1, st1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape), None
+            dx1 = bn_back_fused(u1, s1, dy1, st1) if st1 is not None else bn_back(u1, s1, dy1, True)
             with wgrad_stream(dev, s1.a, dx1):
                 grads[u1][0] = _conv_wgrad(u1, s1.a, dx1)
             if br is not None:
                 br.wait(dskip)
-                dcur = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=dskip)
+                join = dskip
             else:
-                dcur = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=dz)
+                join = dz
+            # The block's input gradient (both branches joined in the epilogue).  The block input is the previous
+            # block's output relu(bn3(x3) + skip): fuse THAT bn3's backward (mask = the saved output) into this kernel.
+            if fuse and bi > 0:
+                p3 = rec[blocks[bi - 1][2]]
+                dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join,
+                                        bn=ops.BnBwd(p3.x, p3.mean, p3.rstd, ymask=p3.y))
+            else:
+                dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join), None
             # this block's gradient kernels are all enqueued: let the data-parallel engine start exchanging the
             # buckets they complete while the rest of the backbone's backward runs
             for u in (u3, u2, u1, ud):

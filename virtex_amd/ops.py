@@ -122,6 +122,49 @@ def gemm_nt(a, b, bias=None, residual=None, act=ACT_NONE, want_preact=False, alp
     return (out, pre) if want_preact else out
 
 
+class _BnBwdFusion(_lib.ctypes.Structure):
+    """VtxBnBwdFusion of include/virtex_amd.h."""
+    _fields_ = [("x", _lib.ctypes.c_void_p), ("ymask", _lib.ctypes.c_void_p), ("mean", _lib.ctypes.c_void_p),
+                ("rstd", _lib.ctypes.c_void_p), ("gamma", _lib.ctypes.c_void_p), ("beta", _lib.ctypes.c_void_p),
+                ("parts", _lib.ctypes.c_void_p), ("parts_cap", _lib.ctypes.c_long), ("strips", _lib.ctypes.c_int)]
+
+
+class BnBwd:
+    """What an input-gradient kernel needs to fuse the backward of the BatchNorm(+ReLU) that produced its input's
+    gradient: that BatchNorm's input `x`, saved statistics, and the ReLU mask source -- `ymask` (post-ReLU block
+    output) or `gamma`/`beta` (mask recomputed from x) or neither (no ReLU)."""
+
+    def __init__(self, x, mean, rstd, ymask=None, gamma=None, beta=None):
+        self.x, self.mean, self.rstd, self.ymask, self.gamma, self.beta = x, mean, rstd, ymask, gamma, beta
+
+    def descriptor(self, rows, N, device):
+        cap = ((rows + 63) // 64 + 4) * 2 * N
+        parts = torch.empty(cap, dtype=torch.float32, device=device)
+        d = _BnBwdFusion(self.x.data_ptr(), self.ymask.data_ptr() if self.ymask is not None else None,
+                         self.mean.data_ptr(), self.rstd.data_ptr(),
+                         self.gamma.data_ptr() if self.gamma is not None else None,
+                         self.beta.data_ptr() if self.beta is not None else None, parts.data_ptr(), cap, 0)
+        return d, parts
+
+
+def gemm_nt_bnbwd(a, b, bn: BnBwd, residual=None):
+    """dz[M,N] = mask(a[M,K] @ b[N,K]^T + residual) plus the BatchNorm-backward sums (see BnBwd).  Returns
+    (out, stats): stats = BnStats(parts, strips, None), or None when the build / dtype did not fuse -- `out` is then
+    the PLAIN gradient and the stand-alone bn_bwd (with its masks) must follow."""
+    assert a.dim() == 2 and b.dim() == 2 and a.stride(1) == 1 and b.stride(1) == 1
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and b.dtype == a.dtype
+    out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == a.dtype
+    assert bn.x.numel() == M * N and bn.x.is_contiguous() and (bn.ymask is None or bn.ymask.is_contiguous())
+    d, parts = bn.descriptor(M, N, a.device)
+    call("vtx_gemm_nt_bnbwd", c_int(dtype_code(a.dtype)), c_int(M), c_int(N), c_int(K), ptr(a), c_long(a.stride(0)),
+         ptr(b), c_long(b.stride(0)), ptr(out), c_long(N), ptr(residual), c_long(N), _lib.ctypes.byref(d), stream_ptr(a))
+    return out, (BnStats(parts, d.strips, None) if d.strips > 0 else None)
+
+
 _splitk_ws = {}
 SPLITK_WS_FLOATS = 32 * 1024 * 1024      # 128 MB of fp32 partial sums per device
 
@@ -174,12 +217,20 @@ def conv2d_fwd(x, w, stride, pad, bn_shift=None):
     return y
 
 
-def conv2d_dgrad(dy, wt, x_shape, stride, pad, residual=None):
+def conv2d_dgrad(dy, wt, x_shape, stride, pad, residual=None, bn: "BnBwd" = None):
+    """bn given: returns (dx, stats) like gemm_nt_bnbwd -- dx is the masked gradient when stats is not None."""
     N, H, W, C = x_shape
     C2, R, S, KO = wt.shape
     assert C2 == C and dy.shape[-1] == KO and wt.dtype == dy.dtype
     _chk(dy, "dy"); _chk(wt, "wt"); _chk(residual, "residual", dy.dtype)
     dx = torch.empty(N, H, W, C, dtype=dy.dtype, device=dy.device)
+    if bn is not None:
+        assert bn.x.numel() == dx.numel() and bn.x.is_contiguous() and (bn.ymask is None or bn.ymask.is_contiguous())
+        d, parts = bn.descriptor(N * H * W, C, dy.device)
+        call("vtx_conv2d_dgrad_bnbwd", c_int(dtype_code(dy.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
+             c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(dy), ptr(wt), ptr(dx), ptr(residual),
+             _lib.ctypes.byref(d), stream_ptr(dy))
+        return dx, (BnStats(parts, d.strips, None) if d.strips > 0 else None)
     call("vtx_conv2d_dgrad", c_int(dtype_code(dy.dtype)), c_int(N), c_int(H), c_int(W), c_int(C), c_int(KO),
          c_int(R), c_int(S), c_int(stride), c_int(pad), ptr(dy), ptr(wt), ptr(dx), ptr(residual), stream_ptr(dy))
     return dx
@@ -245,6 +296,19 @@ def bn_bwd(x, dy, ymask, gamma, mean, rstd, dgamma, dbeta, want_dz=False, relu_b
     call("vtx_bn_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(dy), ptr(ymask), ptr(gamma), ptr(relu_beta), ptr(mean),
          ptr(rstd), ptr(dx), ptr(dz), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(P), c_int(C), stream_ptr(x))
     return (dx, dz) if want_dz else dx
+
+
+def bn_bwd_fused(x, dz, gamma, mean, rstd, dgamma, dbeta, stats: "BnStats"):
+    """BatchNorm backward when the kernel that produced `dz` already masked it and emitted the sums (`stats` from
+    gemm_nt_bnbwd / conv2d_dgrad(bn=...)): finalize + one pass."""
+    C = x.shape[-1]
+    P = x.numel() // C
+    _chk(x, "x"); _chk(dz, "dz", x.dtype)
+    ws = bn_workspace(x.device, C)
+    dx = torch.empty_like(x)
+    call("vtx_bn_bwd_fused", c_int(dtype_code(x.dtype)), ptr(x), ptr(dz), ptr(gamma), ptr(mean), ptr(rstd),
+         ptr(stats.parts), c_int(stats.strips), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(P), c_int(C), stream_ptr(x))
+    return dx
 
 
 def maxpool_fwd(x):
