@@ -55,3 +55,15 @@ def test_two_rank_flow_does_not_deadlock_in_the_roofline_leg():
     rec = _json_line(r.stdout)
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["parallelism"] == "dp2"
     assert rec["roofline"] is not None and "cpu_baseline" not in rec and "error" not in rec["fidelity"]
+
+
+def test_single_rank_flow_through_the_data_parallel_engine():
+    """VIRTEX_AMD_FORCE_DIST keeps the engine (process group, parameter broadcast, bucket all-reduces, barriers) in the
+    loop with one rank -- the CPU twin of tests/test_distributed_gpu.py::test_bench_through_rccl_with_one_rank."""
+    env = dict(os.environ, VIRTEX_AMD_FORCE_DIST="gloo", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29633", VIRTEX_AMD_DP_PAYLOAD="bf16")
+    r = subprocess.run([sys.executable, RUNNER, "--gpus", "1"] + ARGS + ["--no-roofline"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rec = _json_line(r.stdout)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and "error" not in rec["fidelity"]

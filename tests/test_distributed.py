@@ -53,6 +53,16 @@ def _worker(rank, world, port, q):
         scale = buckets.finish()
         results.append([(n, (p.grad * scale).tolist()) for n, p in model.named_parameters() if p.grad is not None])
     del other_buckets
+    # bf16 wire format: same step, gradients rounded to bf16 before the exchange and widened back afterwards
+    torch.manual_seed(0)
+    model16 = _Toy()
+    vd.broadcast_parameters(model16)
+    b16 = vd.GradientBuckets(model16, bucket_mb=0.0005, payload="bf16")
+    b16.zero()
+    x = torch.randn(4, 3, 6, 6, generator=torch.Generator().manual_seed(rank))
+    model16(x).backward()
+    sc = b16.finish()
+    results.append([(n, (p.grad * sc).tolist()) for n, p in model16.named_parameters() if p.grad is not None])
     # the reference helper averages IN PLACE and its callers ignore the return value (pretrain_virtex.py:213)
     d = {"a": torch.tensor(float(rank)), "b": torch.tensor(2.0 * rank + 1)}
     vd.average_across_processes(d)
@@ -98,5 +108,25 @@ def test_gradient_buckets_match_averaged_gradients():
             for n in grads[0]:
                 exp = (grads[0][n] + grads[1][n]) / 2
                 assert torch.allclose(torch.tensor(got[n]), exp, rtol=1e-5, atol=1e-7), (step, r, n)
+    # bf16 payload (third result = step 0 again through the bf16 wire): relative L2 error per tensor <= 4e-3
+    for r in range(world):
+        got = dict(outs[r][1][2])
+        ref.zero_grad()
+        gs = []
+        for rr in range(world):
+            ref.zero_grad()
+            x = torch.randn(4, 3, 6, 6, generator=torch.Generator().manual_seed(rr))
+            ref(x).backward()
+            gs.append({n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None})
+        differs = 0
+        for n in gs[0]:
+            exp = (gs[0][n] + gs[1][n]) / 2
+            g = torch.tensor(got[n])
+            if exp.norm() > 0:
+                # two roundings of the addends + one of the bf16 sum, 2^-9 each at worst: <= 4e-3 relative L2 on any
+                # tensor large enough to average (tiny bias vectors can sit at the worst case of their largest element)
+                assert ((g - exp).norm() / exp.norm()).item() <= (4e-3 if exp.numel() >= 64 else 8e-3), (r, n)
+                differs += int(not torch.equal(g, exp))
+        assert differs > 0                                           # it really went through bf16
     for r in range(world):
         assert outs[r][2] == {"a": pytest.approx(0.5), "b": pytest.approx(2.0)}

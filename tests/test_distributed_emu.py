@@ -41,7 +41,7 @@ batch = synth.synthetic_batch(seed=40 + rank, **bk)
 buckets.zero(); buckets.begin()
 model({k: v.to(dev) for k, v in batch.items()})["loss"].backward()
 scale = buckets.finish()
-early = len(buckets.early)
+early = buckets.last_early
 out = {n: (p.grad * scale).flatten()[:: max(1, p.numel() // 64)][:64].tolist() + [float((p.grad * scale).double().norm())]
        for n, p in model.named_parameters()}
 with open(os.environ["VTX_OUT"] + f".{rank}", "w") as f:      # a file, not the pipe: the parent reads the ranks one after the other

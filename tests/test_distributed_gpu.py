@@ -76,3 +76,32 @@ def test_two_ranks_one_gpu_full_step():
     assert a["gnorm"] == pytest.approx(b["gnorm"], rel=1e-6)
     assert a["losses"] != b["losses"]
     assert a["avg_loss"] == pytest.approx((a["losses"][-1] + b["losses"][-1]) / 2, rel=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_bench_through_rccl_with_one_rank(payload):
+    """The whole N > 1 path of bench.py on the ONE GPU of the test box, through RCCL: `init_process_group("nccl")`
+    (communicator creation), `broadcast_parameters`, the bucketed all-reduces on the communication stream fenced by
+    events against the compute / weight-gradient / branch streams, the barrier with `device_ids`, the roofline and
+    fidelity legs (collective: every rank takes part).  VIRTEX_AMD_FORCE_DIST=nccl keeps the data-parallel engine
+    enabled at world size 1, so the first multi-GPU run of the driver does not execute any line for the first time.
+    The result must equal the plain single-process run bit for bit in fp32 payload mode (a 1-rank SUM is the identity)."""
+    import json
+    args = ["--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8", "--image-size", "64", "--vocab-size", "1000",
+            "--textual", "transdec_postnorm::L1_H128_A2_F256", "--no-cpu-baseline", "--roofline-steps", "1", "--dropout", "0.0"]
+    def run(extra_env):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                           timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    plain = run({})
+    dist_env = {"VIRTEX_AMD_FORCE_DIST": "nccl", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port()), "VIRTEX_AMD_DP_PAYLOAD": payload}
+    rccl = run(dist_env)
+    assert rccl["n_gpus"] == 1 and rccl["value"] > 0 and "error" not in rccl.get("fidelity", {})
+    if payload == "fp32":       # (the embedding's fp32 atomics make runs differ at 1e-7, nothing more)
+        assert abs(rccl["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-4
+    else:
+        assert abs(rccl["config"]["final_loss"] - plain["config"]["final_loss"]) < 2e-3 * abs(plain["config"]["final_loss"])
