@@ -28,10 +28,11 @@ STEM_CPAD = 8  # generic stem layout: the 3 input channels zero-padded to 8 (one
 # input conversion, filter padded 7x7 -> 7x8.  The 7x7/s2/p3 convolution becomes a "valid" 7x8/s2 one whose 16-byte
 # chunks hold two adjacent pixels: K = 7*8*4 = 224 instead of 7*7*8 = 392, no bounds logic, half the input bytes.
 STEM_PACK_C, STEM_PACK_S, STEM_HALO = 4, 8, 3
-# BatchNorm statistics from the convolution epilogue: implemented and tested (ops.conv2d_fwd(bn_shift=...)),
-# but measured SLOWER than the stand-alone reduction on this step (43.8 vs 42.1 ms: the extra ~48 VGPRs of
-# the statistics epilogue cost the GEMMs more than the saved 5.7 GB read) -> off by default.
-FUSE_BN_STATS = os.environ.get("VIRTEX_AMD_FUSE_BN_STATS", "0") != "0"
+# BatchNorm statistics from the convolution epilogue (ops.conv2d_fwd(bn_shift=...)).  Round 1 accumulated them in
+# the accumulator layout (~48 extra VGPRs: the GEMMs lost more than the saved 5.7 GB read, 43.8 vs 42.1 ms); the
+# round-2 epilogue takes them while the wave-private strip is drained (16 accumulators, parameters in LDS, same
+# VGPR count as the plain kernel): 35.7 -> 35.0 ms alone, 33.4 -> 32.8 ms on top of the backward fusion.
+FUSE_BN_STATS = os.environ.get("VIRTEX_AMD_FUSE_BN_STATS", "1") != "0"
 # BatchNorm BACKWARD fused into the input-gradient kernels (bf16): the epilogue of the kernel that produces the
 # gradient wrt a BatchNorm(+ReLU) output applies the ReLU mask, stores the masked gradient and emits the two sums
 # (ops.BnBwd); the stand-alone reduction over (dy, x [, y]) and the mask / dz passes disappear.  Applies to bn1, bn2
