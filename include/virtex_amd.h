@@ -179,6 +179,14 @@ int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const float* gamm
                      const float* save_rstd, const float* pre_partials, int pre_nparts, void* dx, float* dgamma,
                      float* dbeta, float* workspace, int P, int C, void* stream);
 
+int vtx_set_bn_apply_unroll(int vectors_per_thread);   /* measurement switch: 0 = by tensor size (default), 1, 2, 4 */
+/* The stem's backward tail fused: dx = BatchNormBackward(ReLUBackward(MaxPool3x3s2Backward(dpool))), x:[N][H][W][C] the
+ * stem convolution's output, dpool:[N][OH][OW][C], argmax from vtx_maxpool3x3s2_fwd; the pre-pool gradient is gathered
+ * on the fly by the reduction and the apply pass and never written (visual_backbones.py:68-74: conv1-bn1-relu-maxpool). */
+int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, const uint8_t* argmax, const float* gamma,
+                       const float* beta, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
+                       float* dbeta, float* workspace, int N, int H, int W, int C, void* stream);
+
 /* ---- MaxPool2d(3, stride 2, pad 1) NHWC (aten::max_pool2d_with_indices of the stem) ---- */
 int vtx_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,
                          void* stream);
@@ -250,6 +258,23 @@ int vtx_cross_entropy_fwd(const float* logits, long ld, const long long* targets
 int vtx_cross_entropy_bwd(int dtype, const float* logits, long ld, const long long* targets,
                           const float* lse, const float* loss_and_count, const float* grad_out,
                           void* dlogits, long ldd, int R, int V, int ignore_index, void* stream);
+
+/* ---- tied output projection + cross-entropy, logits never in HBM (csrc/tied_ce.hip) -----
+ * Replaces aten::linear of the tied output layer (textual_heads.py:199-200,277) + nn.CrossEntropyLoss(ignore_index)
+ * (captioning.py:69,111-114,127-132) and their backward on the TRAINING path (the reference writes (B,T,V) fp32 logits).
+ * hidden:[R][H] dtype (row stride ldh), weight:[V][H] dtype (the tied word matrix in compute dtype, row stride ldw),
+ * bias:[V] fp32 or NULL, targets:[R] int64 (row r predicts targets[r]; ignore_index rows do not count).
+ * fwd: the projection GEMM's epilogue emits per-row log-sum-exp partials (pmax/psum: vtx_tied_ce_partial_floats(R,V)
+ *      floats each, scratch) and the target logit; outputs lse[R], row_loss[R], loss_and_count[2] = {mean loss, count}.
+ * bwd: recomputes the GEMM and writes dlogits[R][V] (dtype, dense) = grad_out[0]/count * (softmax - onehot), the
+ *      operand of the two gradient GEMMs (vtx_gemm_nt for d(hidden), vtx_gemm_tn_acc for d(weight)). */
+long vtx_tied_ce_partial_floats(int R, int V);
+int vtx_tied_ce_fwd(int dtype, int R, int V, int H, const void* hidden, long ldh, const void* weight, long ldw,
+                    const float* bias, const long long* targets, int ignore_index, float* pmax, float* psum,
+                    long partial_floats, float* tgt_logit, float* lse, float* row_loss, float* loss_and_count, void* stream);
+int vtx_tied_ce_bwd(int dtype, int R, int V, int H, const void* hidden, long ldh, const void* weight, long ldw,
+                    const float* bias, const long long* targets, int ignore_index, const float* lse,
+                    const float* loss_and_count, const float* grad_out, void* dlogits, void* stream);
 
 /* ---- small helpers -------------------------------------------------------------------- */
 long vtx_colsum_workspace_floats(int C);

@@ -717,3 +717,65 @@ def test_fused_batchnorm_backward_is_refused_cleanly_in_fp32(backend):
     bn = ops.BnBwd(x.to(dev), x.mean(0).to(dev), torch.ones(64, device=dev), gamma=torch.ones(64, device=dev), beta=torch.zeros(64, device=dev))
     out, st = ops.gemm_nt_bnbwd(a.to(dev), b.to(dev), bn)
     assert st is None and rel_err(out.cpu(), a @ b.t()) < 1e-4
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("R,V,H", [(150, 1000, 64), (70, 304, 128)])
+def test_tied_projection_cross_entropy_without_logits(backend, dtype, R, V, H):
+    """vtx_tied_ce_fwd / _bwd against F.cross_entropy(h @ W^T + b) evaluated in fp32 on the same (rounded) operands:
+    loss, log-sum-exp per row, the gradient wrt the logits incl. ignored rows and the row-0 (padding index) COLUMN,
+    which the tied matrix does receive.  V is not a multiple of any tile."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(R + V)
+    h = torch.randn(R, H, generator=g).to(dtype); w = (0.3 * torch.randn(V, H, generator=g)).to(dtype)
+    bias = 0.2 * torch.randn(V, generator=g)
+    tgt = torch.randint(1, V, (R,), generator=g)
+    tgt[::7] = 0                                               # ignored rows
+    logits = (h.float() @ w.float().t() + bias).requires_grad_()
+    ref = F.cross_entropy(logits, tgt, ignore_index=0)
+    ref.backward()
+    lc, lse = ops.tied_ce_fwd(h.to(dev), w.to(dev), bias.to(dev), tgt.to(dev), 0)
+    tol = 2e-5 if dtype == torch.float32 else 2e-4
+    assert abs(lc[0].item() - ref.item()) < tol * abs(ref.item())
+    assert lc[1].item() == (tgt != 0).sum().item()
+    assert torch.allclose(lse.cpu(), torch.logsumexp(logits.detach(), 1), rtol=tol, atol=tol)
+    gout = torch.tensor([1.7])
+    d = ops.tied_ce_bwd(h.to(dev), w.to(dev), bias.to(dev), tgt.to(dev), lse, lc, gout.to(dev), 0)
+    dref = 1.7 * logits.grad
+    assert rel_err(d.float().cpu(), dref) < (2e-5 if dtype == torch.float32 else 1e-2)
+    assert d.float().cpu()[::7].abs().max().item() == 0.0       # ignored rows contribute nothing
+    assert d.float().cpu()[:, 0].abs().sum().item() > 0         # ... but column 0 of the others does
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (3, 9, 11, 16)])
+def test_stem_tail_maxpool_backward_inside_batchnorm_backward(backend, dtype, N, H, W, C):
+    """vtx_bn_bwd_maxpool == maxpool backward -> ReLU mask -> BatchNorm backward of torch, on the stem's layout."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(N * H + C)
+    x = (torch.randn(N, H, W, C, generator=g) * 0.8 + 0.1).to(dtype)
+    gamma = 0.5 + torch.rand(C, generator=g); beta = 0.2 * torch.randn(C, generator=g)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    y = F.relu(F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5))
+    pooled = F.max_pool2d(y, 3, 2, 1)
+    dpool = torch.randn(pooled.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dtype)
+    pooled.backward(dpool.float().permute(0, 3, 1, 2))
+    # our forward pieces give the saved statistics, the activations and the argmax
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    yk, mean, rstd = ops.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rm, rv, None, relu=True)
+    pk, arg = ops.maxpool_fwd(yk)
+    dgamma = torch.zeros(C, device=dev); dbeta = torch.zeros(C, device=dev)
+    dx = ops.bn_bwd_maxpool(x.to(dev), dpool.to(dev), arg, gamma.to(dev), beta.to(dev), mean, rstd, dgamma, dbeta)
+    if dtype == torch.float32:          # (in bf16 the rounded activations tie differently in the pooling windows than torch's fp32 ones)
+        assert rel_err(dx.cpu(), xr.grad.permute(0, 2, 3, 1)) < 2e-4
+        assert rel_err(dgamma.cpu(), gr.grad) < 2e-4 and rel_err(dbeta.cpu(), br.grad) < 2e-4
+    # and it equals the three-kernel path (max-pool backward, then BatchNorm backward with the mask recomputed from x)
+    dstem = ops.maxpool_bwd(dpool.to(dev), arg, tuple(x.shape))
+    dg2 = torch.zeros(C, device=dev); db2 = torch.zeros(C, device=dev)
+    dx2 = ops.bn_bwd(x.to(dev), dstem, None, gamma.to(dev), mean, rstd, dg2, db2, relu_beta=beta.to(dev))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(dx.float().cpu(), dx2.float().cpu()) < tol
+    assert rel_err(dgamma.cpu(), dg2.cpu()) < tol and rel_err(dbeta.cpu(), db2.cpu()) < tol

@@ -253,25 +253,136 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 
 // backward apply when the producing kernel already masked the gradient and emitted the sums (VtxBnBwdFusion):
 // dx = gamma*rstd * (dz - s1/P - xhat*s2/P); reads x and dz, writes dx -- nothing else
-template <class T>
+// UNR independent 16-byte vectors per thread and trip, all loads issued before the first use (memory-level parallelism)
+template <class T, int UNR>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __restrict__ x, const T* __restrict__ dz,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ coef, T* __restrict__ dx, long nvec, int C) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nvec; i0 += UNR * stride) {
+        Vec16<T> xv[UNR], g[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long i = i0 + u * stride;
+            if (i < nvec) { xv[u].load(x + i * VEC); g[u].load(dz + i * VEC); }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const long i = i0 + u * stride;
+            if (i >= nvec) break;
+            const int c0 = (int)(i % cv) * VEC;
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (xv[u].v[j] - mean[c0 + j]) * rstd[c0 + j];
+                o.v[j] = coef[c0 + j] * (g[u].v[j] - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
+            }
+            o.store(dx + i * VEC);
+        }
+    }
+}
+
+// ---- the stem's tail: MaxPool2d(3,2,1) backward gathered on the fly inside the BatchNorm backward -------------
+// gradient wrt the pre-pool tensor at pixel (n, ih, iw): the dy of the (<= 2x2) pooling windows whose argmax is this
+// pixel (same gather as maxpool_bwd_kernel in pool.hip; first-maximum tie rule lives in the forward's argmax)
+template <class T>
+__device__ __forceinline__ void pool_gather(const T* __restrict__ dpool, const uint8_t* __restrict__ argmax, int n, int ih,
+                                            int iw, int c0, int C, int OH, int OW, float* g) {
+    constexpr int VEC = Elem<T>::VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) g[j] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int th = ih + 1 - kh;
+        if (th < 0 || (th & 1) || (th >> 1) >= OH) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tw = iw + 1 - kw;
+            if (tw < 0 || (tw & 1) || (tw >> 1) >= OW) continue;
+            const long off = (((long)n * OH + (th >> 1)) * OW + (tw >> 1)) * C + c0;
+            Vec16<T> d; d.load(dpool + off);
+            const uint2 am = *reinterpret_cast<const uint2*>(argmax + off);      // VEC <= 8 argmax bytes
+            const uint32_t aw[2] = {am.x, am.y};
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                if (((aw[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)(kh * 3 + kw)) g[j] += d.v[j];
+        }
+    }
+}
+
+// reduce: s1 = sum dz, s2 = sum dz*xhat with dz = pool-gathered gradient masked by relu(xhat*gamma+beta) > 0
+template <class T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(
+    const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ argmax, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sums,
+    int N, int H, int W, int C, int OH, int OW, int TX, int rows_per_block) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
+    const int c0 = (blockIdx.y * TX + tx) * VEC;
+    const int P = N * H * W;
+    const int p0 = blockIdx.x * rows_per_block;
+    const int p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
+    float a[VEC], b[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { a[j] = b[j] = 0.f; mu[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
+    for (int p = p0 + ty; p < p1; p += TY) {
+        const int iw = p % W, t = p / W, ih = t % H, n = t / H;
+        Vec16<T> xv; xv.load(x + (size_t)p * C + c0);
+        float g[VEC];
+        pool_gather<T>(dpool, argmax, n, ih, iw, c0, C, OH, OW, g);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv.v[j] - mu[j]) * rs[j];
+            const float d = xh * ga[j] + be[j] > 0.f ? g[j] : 0.f;
+            a[j] += d; b[j] += d * xh;
+        }
+    }
+    __shared__ float red[2][256 * VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { red[0][(ty * TX + tx) * VEC + j] = a[j]; red[1][(ty * TX + tx) * VEC + j] = b[j]; }
+    __syncthreads();
+    if (ty == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int r = 0; r < TY; ++r) { s0 += red[0][(r * TX + tx) * VEC + j]; s1 += red[1][(r * TX + tx) * VEC + j]; }
+            sums[(size_t)blockIdx.x * 2 * C + c0 + j] = s0;
+            sums[(size_t)blockIdx.x * 2 * C + C + c0 + j] = s1;
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(
+    const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ argmax, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ coef, const float* __restrict__ gamma, const float* __restrict__ beta,
+    T* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long total = (long)N * H * W * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % cv) * VEC;
-        Vec16<T> xv, g; xv.load(x + i * VEC); g.load(dz + i * VEC);
+        long p = i / cv;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int n = (int)(p / H);
+        Vec16<T> xv; xv.load(x + i * VEC);
+        float g[VEC];
+        pool_gather<T>(dpool, argmax, n, ih, iw, c0, C, OH, OW, g);
         Vec16<T> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xh = (xv.v[j] - mean[c0 + j]) * rstd[c0 + j];
-            o.v[j] = coef[c0 + j] * (g.v[j] - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
+            const float d = xh * gamma[c0 + j] + beta[c0 + j] > 0.f ? g[j] : 0.f;
+            o.v[j] = coef[c0 + j] * (d - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
         }
         o.store(dx + i * VEC);
     }
 }
 
+int g_bn_apply_unroll = 0;      // vectors in flight per thread of the fused backward apply kernel: 0 = by size, or 1, 2, 4
 constexpr int VTX_BN_MAX_PARTS = 512;
 struct ReducePlan { int TX, gy, gx, rows; };
 static ReducePlan plan_reduce(int P, int C, int vec) {
@@ -402,12 +513,65 @@ extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const 
     VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, parts, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, np);
     const long nvec = (long)P * C / vec;
-    if (dtype == VTX_BF16)
-        VTX_KLAUNCH("bn_bwd_apply", 0, 6.0 * P * C, (bn_bwd_apply_fused_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
-                    (const bf16_t*)dz, save_mean, save_rstd, coef, (bf16_t*)dx, nvec, C);
-    else
-        VTX_KLAUNCH("bn_bwd_apply", 0, 12.0 * P * C, (bn_bwd_apply_fused_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
-                    (const float*)dz, save_mean, save_rstd, coef, (float*)dx, nvec, C);
+    // measured (tools/bench_bn_apply.py, profiles/r02_bn_apply_unroll.txt): two vectors in flight +5 % on the >= 50 MB
+    // tensors of stages 1-2, -10 % on the small ones; four are slower everywhere
+    const int unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (6L << 20) ? 2 : 1);
+    const int grid = apply_grid(vtx_cdiv(nvec, unr));
+#define VTX_BWD_APPLY(T, U, BYTES)                                                                                              \
+    VTX_KLAUNCH("bn_bwd_apply", 0, BYTES, (bn_bwd_apply_fused_kernel<T, U>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dz, \
+                save_mean, save_rstd, coef, (T*)dx, nvec, C)
+    if (dtype == VTX_BF16) {
+        if (unr == 4) VTX_BWD_APPLY(bf16_t, 4, 6.0 * P * C); else if (unr == 2) VTX_BWD_APPLY(bf16_t, 2, 6.0 * P * C); else VTX_BWD_APPLY(bf16_t, 1, 6.0 * P * C);
+    } else VTX_BWD_APPLY(float, 1, 12.0 * P * C);
+#undef VTX_BWD_APPLY
     VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+// The stem's backward tail in two passes instead of three kernels and an intermediate tensor:
+//   dx = BatchNormBackward(ReLUBackward(MaxPoolBackward(dpool)))   with x = the stem convolution's output [N][H][W][C].
+// Replaces aten::max_pool2d_with_indices_backward + threshold_backward + native_batch_norm_backward of the stem
+// (/root/reference/virtex/modules/visual_backbones.py:68-74: conv1 -> bn1 -> relu -> maxpool).  The pre-pool gradient
+// (411 MB at B = 256) is gathered on the fly by both passes and never written.
+extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, const uint8_t* argmax, const float* gamma,
+                                  const float* beta, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
+                                  float* dbeta, float* workspace, int N, int H, int W, int C, void* stream) {
+    VTX_CHECK(x && dpool && argmax && gamma && beta && save_mean && save_rstd && dx && dgamma && dbeta && workspace, VTX_ERR_ARG,
+              "bn_bwd_maxpool: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_bwd_maxpool: bad dtype %d", dtype);
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(N > 0 && H > 0 && W > 0 && bn_shape_ok(C, vec) && C % 8 == 0, VTX_ERR_SHAPE, "bn_bwd_maxpool: C=%d must be 8*2^k", C);
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long Pl = (long)N * H * W;
+    VTX_CHECK(Pl < (1L << 31), VTX_ERR_SHAPE, "bn_bwd_maxpool: too many pixels");
+    const int P = (int)Pl;
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = workspace + C; float* sums = workspace + 4 * C;
+    ReducePlan rp = plan_reduce(P, C, vec);
+    const double el = dtype == VTX_BF16 ? 2.0 : 4.0;
+    const double pool_bytes = (double)N * OH * OW * C * (el + 1.0);
+    if (dtype == VTX_BF16)
+        VTX_KLAUNCH("bn_bwd_reduce", 0, el * P * C + pool_bytes, (pool_bn_bwd_reduce_kernel<bf16_t>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
+                    (const bf16_t*)dpool, argmax, save_mean, save_rstd, gamma, beta, sums, N, H, W, C, OH, OW, rp.TX, rp.rows);
+    else
+        VTX_KLAUNCH("bn_bwd_reduce", 0, el * P * C + pool_bytes, (pool_bn_bwd_reduce_kernel<float>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
+                    (const float*)dpool, argmax, save_mean, save_rstd, gamma, beta, sums, N, H, W, C, OH, OW, rp.TX, rp.rows);
+    VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
+                dgamma, dbeta, P, C, rp.gx);
+    const long nvec = (long)P * C / vec;
+    if (dtype == VTX_BF16)
+        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+                    (const bf16_t*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (bf16_t*)dx, N, H, W, C, OH, OW);
+    else
+        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+                    (const float*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (float*)dx, N, H, W, C, OH, OW);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+// measurement switch (tools/bench_bn_apply.py): vectors in flight per thread of the fused backward apply kernel
+extern "C" int vtx_set_bn_apply_unroll(int n) {
+    VTX_CHECK(n == 0 || n == 1 || n == 2 || n == 4, VTX_ERR_ARG, "bn apply unroll must be 0 (automatic), 1, 2 or 4");
+    g_bn_apply_unroll = n;
     return VTX_OK;
 }

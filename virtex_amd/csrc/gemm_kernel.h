@@ -214,7 +214,8 @@ template <class T, int SL> struct ConvWgradB {
 };
 
 // ------------------------------------------------------------------ epilogues
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RES_RELU = 3 };   // 3: ReLU AFTER the residual add (inference Bottleneck tail)
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_RES_RELU = 3,      // 3: ReLU AFTER the residual add (inference Bottleneck tail)
+       ACT_SOFTMAX_GRAD = 4 };   // out = g[m] * (exp(v - lse[m]) - [n == target[m]]): the cross-entropy gradient wrt the logits v
 
 template <class T> __device__ __forceinline__ void st4(T* p, const float* v);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float* v) {
@@ -305,6 +306,7 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     static constexpr bool STAGED = true;   // generation-2 kernel: 16-byte stores via a wave-private LDS strip
     static constexpr int SMODE = STATS_MODE;
     static constexpr bool STATS = STATS_MODE != STATS_NONE;
+    static constexpr bool ROWLSE = false;
     typedef T Out;
     T* out; long ldc; const float* bias; const T* residual; long ldr; T* preact; int act;
     float alpha; Dropout drop; int M, N;
@@ -317,6 +319,17 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     const T* bn_y = nullptr; long ldy = 0;       //            the post-ReLU block output (mask), or nullptr
     const float* bn_mean = nullptr; const float* bn_rstd = nullptr;
     const float* bn_gamma = nullptr; const float* bn_beta = nullptr;   // mask recomputed from bn_x when bn_y == nullptr
+    // ACT_SOFTMAX_GRAD (tied projection + cross-entropy backward: the logits are recomputed, never stored)
+    const float* ce_lse = nullptr; const long long* ce_targets = nullptr;
+    const float* ce_gout = nullptr; const float* ce_lc = nullptr; int ce_ignore = 0;
+    __device__ __forceinline__ void softmax_grad(int m, int n, float* v) const {
+        const long long t = ce_targets[m];
+        const bool ignored = t == ce_ignore || t < 0 || t >= N;
+        const float g = ignored ? 0.f : ce_gout[0] / ce_lc[1];
+        const float l = ce_lse[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = g * (__expf(v[j] - l) - ((long long)(n + j) == t ? 1.f : 0.f));
+    }
     // Row scatter for the parity-decomposed stride-2 input gradient: GEMM row m = (n, ih2, iw2) is output
     // pixel (n, 2*ih2+map_pa, 2*iw2+map_pb) of an H x W image.  map_on = 0: identity.
     int map_on = 0, map_H = 0, map_W = 0, map_pa = 0, map_pb = 0;
@@ -343,6 +356,10 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         } else if (act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (act == ACT_SOFTMAX_GRAD) {
+            float t4[4] = {v[0], v[1], v[2], v[3]};
+            softmax_grad(m, n, t4);
+            v = f32x4_t{t4[0], t4[1], t4[2], t4[3]};
         }
         if (drop.thresh) {
 #pragma unroll
@@ -427,7 +444,7 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         } else if (act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        }
+        } else if (act == ACT_SOFTMAX_GRAD) softmax_grad(m, n, v);
         if (drop.thresh) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = drop.apply(v[j], (uint64_t)(o + j));
@@ -449,6 +466,7 @@ struct EpiAtomic {
     static constexpr bool STAGED = false;
     static constexpr bool STATS = false;
     static constexpr int SMODE = STATS_NONE;
+    static constexpr bool ROWLSE = false;
     typedef float Out;
     float* out; long ldc; float alpha; int M, N;
     float* stat_parts = nullptr;
@@ -462,6 +480,68 @@ struct EpiAtomic {
         for (int j = 0; j < 4; ++j) atomicAdd(o + j, alpha * acc[j]);
     }
 };
+
+// Row-wise log-sum-exp partials of v = alpha*acc + bias over the columns of a WAVE tile -- the forward of the tied
+// output projection + cross-entropy without ever writing the [M][N] logits: every wave emits, per row, the maximum
+// and the sum of exp(v - max) over its own columns into pmax/psum[column group][M]; a tiny kernel folds the groups
+// into lse[m].  The lane that holds column target[m] also records that logit.  Nothing else is stored.
+struct EpiRowLse {
+    static constexpr bool STAGED = false;
+    static constexpr bool STATS = false;
+    static constexpr int SMODE = STATS_NONE;
+    static constexpr bool ROWLSE = true;
+    typedef float Out;
+    const float* bias; float alpha; int M, N;
+    const long long* targets; float* tgt_logit; float* pmax; float* psum;
+    float* stat_parts = nullptr; const float* stat_shift = nullptr;
+    const void* residual = nullptr; const void* preact = nullptr; const void* bn_x = nullptr; const void* bn_y = nullptr;
+    __device__ __forceinline__ f32x4_t transform(int, int, f32x4_t v) const { return v; }
+    __device__ __forceinline__ void store_wide(int, int, uint4) const {}
+    __device__ __forceinline__ void operator()(int, int, f32x4_t) const {}
+};
+
+// mw / nw: first row / column of the wave tile; group: index of this column range (tile_n * waves-per-row + wn)
+template <int MT, int NT, class EP>
+__device__ __forceinline__ void rowlse_epilogue(const EP& ep, f32x4_t (&acc)[MT][NT], int mw, int nw, int lane, int group) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mw + i * 16 + (lane & 15);
+        const bool mok = m < ep.M;
+        const long long t = mok ? ep.targets[m] : -1;
+        float v[NT][4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nw + j * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool nok = n + q < ep.N;
+                const float x = acc[i][j][q] * ep.alpha + ((nok && ep.bias) ? ep.bias[n + q] : 0.f);
+                v[j][q] = x;
+                if (nok) {
+                    mx = fmaxf(mx, x);
+                    if (mok && t == (long long)(n + q)) ep.tgt_logit[m] = x;
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = nw + j * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (n + q < ep.N) sm += __expf(v[j][q] - mx);
+        }
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if ((lane >> 4) == 0 && mok) {
+            ep.pmax[(size_t)group * ep.M + m] = mx;
+            ep.psum[(size_t)group * ep.M + m] = sm;
+        }
+    }
+}
 
 // ------------------------------------------------------------------ the kernel
 // LDS image of one operand tile.
@@ -620,12 +700,16 @@ __global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP 
         }
     }
     // D = Btile x Atile  =>  lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
+    if constexpr (EP::ROWLSE) {
+        rowlse_epilogue<MT, NT>(ep, acc, m0 + wm * (BM / 2), n0 + wn * (BN / 2), lane, (tile % tiles_n) * 2 + wn);
+    } else {
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-            ep(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4),
-               acc[i][j]);
+            for (int j = 0; j < NT; ++j)
+                ep(m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + 4 * (lane >> 4),
+                   acc[i][j]);
+    }
 }
 
 // ------------------------------------------------------------------ bf16 kernel, generation 2
@@ -807,7 +891,9 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
         }
     }
     // D = Btile x Atile  =>  lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
-    if constexpr (!EP::STAGED) {
+    if constexpr (EP::ROWLSE) {
+        rowlse_epilogue<MT, NT>(ep, acc, m0 + wm * WTM, n0 + wn * WTN, lane, (tile % tiles_n) * WN + wn);
+    } else if constexpr (!EP::STAGED) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -894,6 +980,7 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
 }
 
 extern int g_vtx_contraction_generation;   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
+extern thread_local int g_vtx_last_colgroups;   // column groups (tiles_n x waves per tile row) of this thread's last launch: EpiRowLse partials
 extern int g_vtx_ablate;   // measurement only: bit0 no MFMA, bit1 no fragment reads, bit2 no DMA, bit3 no barrier
 
 // ------------------------------------------------------------------ host-side launch
@@ -907,6 +994,7 @@ inline void launch_v1(const AL& al, const BL& bl, const EP& ep, int M, int N, in
     const int per = vtx_cdiv(nkt, split_k);       // K == 0: no K steps, the epilogue alone runs
     split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
     dim3 grid(tiles_m * tiles_n, split_k), block(NTHREADS);
+    g_vtx_last_colgroups = tiles_n * 2;
     hipLaunchKernelGGL((contraction_kernel<T, BM, BN, AL, BL, EP>), grid, block, 0, st, al, bl, ep, K, tiles_n, per);
 }
 
@@ -921,6 +1009,7 @@ template <class T, int SL> inline double algo_elems(const ConvWgradB<T, SL>& l) 
 template <class T, int SL> inline double algo_elems(const ConvDgradA<T, SL>& l) { return (double)l.g.N * l.g.OH * l.g.OW * l.g.KO; }
 template <class T, int SL> inline double algo_elems(const ConvDgradS2A<T, SL>& l) { return (double)l.g.N * l.g.OH * l.g.OW * l.g.KO; }
 template <class EP> inline double epi_bytes(const EP&, double mn, int) { return mn * 4; }
+inline double epi_bytes(const EpiRowLse& e, double, int) { return 0.0; }     // the logits are never written
 template <class T, int S> inline double epi_bytes(const EpiStore<T, S>& e, double mn, int split_k) {
     return mn * sizeof(T) * (split_k > 1 ? split_k : 1) + (e.residual ? mn * sizeof(T) : 0.0) + (e.preact ? mn * sizeof(T) : 0.0) +
            (e.bn_x ? mn * sizeof(T) : 0.0) + (e.bn_y ? mn * sizeof(T) : 0.0);
@@ -942,6 +1031,7 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int
         attr_set = true;
     }
     dim3 grid(tiles_m * tiles_n, split_k), block(64 * WM * WN);
+    g_vtx_last_colgroups = tiles_n * WN;
     bool prof = g_vtx_prof_on != 0;
     if (prof) {
         static const int cls = vtx_prof_register(__PRETTY_FUNCTION__);

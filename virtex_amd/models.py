@@ -6,9 +6,11 @@ Same constructor, attribute tree (``visual``, ``textual``, ``backward_textual``,
 ``{"loss", "loss_components": {"captioning_forward", "captioning_backward"}, ["predictions"]}``.
 
 Training takes a fused path the reference does not have: decoder hidden states go straight
-into the tied-projection + cross-entropy op (`_TiedCrossEntropyFn`) whose fp32 logits live
-only between two kernels, never as an autograd-visible (B,T,V) tensor.  The eval branch and
-``decoding_step`` keep the reference semantics through ``textual(...)`` which returns logits.
+into the tied-projection + cross-entropy op (`_FusedTiedCrossEntropyFn`, csrc/tied_ce.hip): the
+(B,T,V) logits exist only as MFMA accumulators -- the projection's epilogue emits log-sum-exp
+partials, the backward recomputes the projection and emits the logit gradient in the compute
+dtype.  The eval branch and ``decoding_step`` keep the reference semantics through
+``textual(...)`` which returns logits.
 """
 import copy
 import functools
@@ -25,9 +27,44 @@ from .modules.textual_heads import TextualHead, tied_projection_grads
 from .modules.visual_backbones import VisualBackbone
 
 
+# Training path: tied projection + cross-entropy with the logits living only in MFMA accumulators (csrc/tied_ce.hip).
+# "0" selects the round-1 path (fp32 logits written by the GEMM, read twice by the loss kernels) for A/B runs.
+FUSED_TIED_CE = os.environ.get("VIRTEX_AMD_FUSED_CE", "1") != "0"
+
+
+class _FusedTiedCrossEntropyFn(torch.autograd.Function):
+    """mean_{tok[b,t+1] != pad} CE(hidden[b,t] @ words^T + bias, tok[b,t+1]) without (B,T,V) logits in HBM
+    (reference: captioning.py:111-114 on textual_heads.py:277 logits; SURVEY.md 7.1 step 4)."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, tokens, padding_idx):
+        B, T, H = hidden.shape
+        dt = hidden.dtype
+        targets = torch.full((B, T), padding_idx, dtype=torch.int64, device=tokens.device)
+        targets[:, :-1] = tokens[:, 1:]                    # row (b,t) predicts token t+1; the last step has no target
+        targets = targets.view(-1)
+        w, _ = ops.prepped(weight, dt, want_wt=False)
+        h2 = hidden.reshape(B * T, H)
+        lc, lse = ops.tied_ce_fwd(h2, w.view(weight.shape), bias.detach(), targets, padding_idx)
+        ctx.weight_param, ctx.bias_param = weight, bias
+        ctx.save_for_backward(h2, targets, lse, lc)
+        ctx.cfg = (B, T, H, weight.shape[0], padding_idx, dt)
+        return lc[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        h2, targets, lse, lc = ctx.saved_tensors
+        B, T, H, V, padding_idx, dt = ctx.cfg
+        g = gout.reshape(1).to(torch.float32).contiguous()
+        w, wt = ops.prepped(ctx.weight_param, dt)
+        d = ops.tied_ce_bwd(h2, w.view(V, H), ctx.bias_param.detach(), targets, lse, lc, g, padding_idx)     # (B*T, V) compute dtype
+        dh = ops.gemm_nt(d, wt.view(H, V)).view(B, T, H)
+        rW, rb = tied_projection_grads(d, h2, ctx.weight_param, ctx.bias_param)
+        return dh, rW, rb, None, None
+
+
 class _TiedCrossEntropyFn(torch.autograd.Function):
-    """mean_{tok[b,t+1] != pad} CE(hidden[b,t] @ words^T + bias, tok[b,t+1])
-    (reference: captioning.py:111-114 on textual_heads.py:277 logits)."""
+    """The same with materialised fp32 logits (round-1 path; A/B reference for the fused one)."""
 
     @staticmethod
     def forward(ctx, hidden, weight, bias, tokens, padding_idx):
@@ -87,8 +124,8 @@ class CaptioningModel(nn.Module):
 
     def _head_loss(self, head, visual_features, tokens, lengths):
         hidden = head.features(visual_features, tokens, lengths)
-        return _TiedCrossEntropyFn.apply(hidden, head.output.weight, head.output.bias, tokens,
-                                         self.padding_idx)
+        fn = _FusedTiedCrossEntropyFn if FUSED_TIED_CE else _TiedCrossEntropyFn
+        return fn.apply(hidden, head.output.weight, head.output.bias, tokens, self.padding_idx)
 
     def _refresh_compute_weights(self):
         """One launch for all the bf16/fp32 compute copies (and their transposes) the step will use; weights whose

@@ -39,6 +39,10 @@ FUSE_BN_STATS = os.environ.get("VIRTEX_AMD_FUSE_BN_STATS", "1") != "0"
 # (mask recomputed from x) and bn3 (mask = block output) of every Bottleneck; shortcut BatchNorms, the stem and the
 # last block (whose gradient comes from the text heads) keep the stand-alone kernels.
 FUSE_BN_BWD = os.environ.get("VIRTEX_AMD_FUSE_BN_BWD", "1") != "0"
+# the stem's tail (max-pool backward -> ReLU mask -> BatchNorm backward) in two passes without the pre-pool gradient
+# tensor (vtx_bn_bwd_maxpool).  Measured SLOWER (1.19 vs 1.11 ms of kernel time, step 33.4 vs 33.1 ms): the 3x3/s2
+# gather is instruction-bound (0.9 TB/s) and the fusion runs it twice to save 1 GB of traffic -> off by default.
+FUSE_STEM_TAIL = os.environ.get("VIRTEX_AMD_FUSE_STEM_TAIL", "0") != "0"
 
 
 # ----------------------------------------------------------------------------------------
@@ -502,8 +506,16 @@ class _ResNetFn(torch.autograd.Function):
                 if u is not None:
                     gradsink.mark_ready([p for p, g in zip((u.conv.weight, u.bn.weight, u.bn.bias), grads[u]) if g is None])
         s0 = rec[stem]
-        dstem = ops.maxpool_bwd(dcur, ctx.argmax, ctx.stem_out_shape)
-        dx0 = bn_back(stem, s0, dstem, True)
+        if FUSE_STEM_TAIL and dcur.is_contiguous():
+            # max-pool backward gathered inside the stem's BatchNorm backward: this chain is the exposed end of the step
+            sg, sb = gradsink.target(stem.bn.weight), gradsink.target(stem.bn.bias)
+            dg = sg if sg is not None else torch.zeros(stem.cout, dtype=torch.float32, device=dev)
+            db = sb if sb is not None else torch.zeros(stem.cout, dtype=torch.float32, device=dev)
+            dx0 = ops.bn_bwd_maxpool(s0.x, dcur, ctx.argmax, stem.bn.weight.detach(), stem.bn.bias.detach(), s0.mean, s0.rstd, dg, db)
+            grads[stem] = [None, None if sg is not None else dg, None if sb is not None else db]
+        else:
+            dstem = ops.maxpool_bwd(dcur, ctx.argmax, ctx.stem_out_shape)
+            dx0 = bn_back(stem, s0, dstem, True)
         with wgrad_stream(dev, s0.a, dx0):               # no input gradient for the image
             if ctx.stem_packed:
                 dwp = torch.zeros(stem.cout, stem.k, STEM_PACK_S, STEM_PACK_C, dtype=torch.float32, device=dev)

@@ -311,6 +311,17 @@ def bn_bwd_fused(x, dz, gamma, mean, rstd, dgamma, dbeta, stats: "BnStats"):
     return dx
 
 
+def bn_bwd_maxpool(x, dpool, argmax, gamma, beta, mean, rstd, dgamma, dbeta):
+    """Stem tail: BatchNorm+ReLU backward with the max-pool backward gathered on the fly (no pre-pool gradient tensor)."""
+    N, H, W, C = x.shape
+    _chk(x, "x"); _chk(dpool, "dpool", x.dtype); _chk(argmax, "argmax", torch.uint8)
+    ws = bn_workspace(x.device, C)
+    dx = torch.empty_like(x)
+    call("vtx_bn_bwd_maxpool", c_int(dtype_code(x.dtype)), ptr(x), ptr(dpool), ptr(argmax), ptr(gamma), ptr(beta), ptr(mean),
+         ptr(rstd), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(N), c_int(H), c_int(W), c_int(C), stream_ptr(x))
+    return dx
+
+
 def maxpool_fwd(x):
     N, H, W, C = x.shape
     _chk(x, "x")
@@ -586,6 +597,46 @@ def cross_entropy_bwd(logits, targets, lse, lc, grad_out, dtype, ignore_index=0)
     call("vtx_cross_entropy_bwd", c_int(dtype_code(dtype)), ptr(logits), c_long(logits.stride(0)), ptr(targets),
          ptr(lse), ptr(lc), ptr(grad_out), ptr(d), c_long(V), c_int(R), c_int(V), c_int(ignore_index),
          stream_ptr(logits))
+    return d
+
+
+_tied_ce_ws = {}
+
+
+def tied_ce_fwd(hidden, weight, bias, targets, ignore_index=0):
+    """Tied projection + cross-entropy forward without logits: hidden [R,H], weight [V,H] (same dtype), bias fp32 [V],
+    targets int64 [R].  Returns (loss_and_count[2], lse[R])."""
+    assert hidden.dim() == 2 and weight.dim() == 2 and hidden.stride(1) == 1 and weight.stride(1) == 1
+    R, H = hidden.shape
+    V = weight.shape[0]
+    assert weight.shape[1] == H and weight.dtype == hidden.dtype
+    _chk(targets, "targets", torch.int64); _chk(bias, "bias", torch.float32)
+    lib = _lib.lib()
+    lib.vtx_tied_ce_partial_floats.restype = _lib.ctypes.c_long
+    need = lib.vtx_tied_ce_partial_floats(c_int(R), c_int(V))
+    key = _ws_key(hidden.device)
+    ws = _tied_ce_ws.get(key)
+    if ws is None or ws.numel() < 2 * need + 2 * R:
+        ws = torch.empty(2 * need + 2 * R, dtype=torch.float32, device=hidden.device)
+        _tied_ce_ws[key] = ws
+    pmax, psum, tgt, row_loss = ws[:need], ws[need: 2 * need], ws[2 * need: 2 * need + R], ws[2 * need + R: 2 * need + 2 * R]
+    lse = torch.empty(R, dtype=torch.float32, device=hidden.device)
+    lc = torch.empty(2, dtype=torch.float32, device=hidden.device)
+    call("vtx_tied_ce_fwd", c_int(dtype_code(hidden.dtype)), c_int(R), c_int(V), c_int(H), ptr(hidden), c_long(hidden.stride(0)),
+         ptr(weight), c_long(weight.stride(0)), ptr(bias), ptr(targets), c_int(ignore_index), ptr(pmax), ptr(psum), c_long(need),
+         ptr(tgt), ptr(lse), ptr(row_loss), ptr(lc), stream_ptr(hidden))
+    return lc, lse
+
+
+def tied_ce_bwd(hidden, weight, bias, targets, lse, lc, grad_out, ignore_index=0):
+    """d(logits) [R,V] in the compute dtype, recomputing the projection (the logits are never stored)."""
+    R, H = hidden.shape
+    V = weight.shape[0]
+    _chk(grad_out, "grad_out", torch.float32)
+    d = torch.empty(R, V, dtype=hidden.dtype, device=hidden.device)
+    call("vtx_tied_ce_bwd", c_int(dtype_code(hidden.dtype)), c_int(R), c_int(V), c_int(H), ptr(hidden), c_long(hidden.stride(0)),
+         ptr(weight), c_long(weight.stride(0)), ptr(bias), ptr(targets), c_int(ignore_index), ptr(lse), ptr(lc), ptr(grad_out),
+         ptr(d), stream_ptr(hidden))
     return d
 
 
