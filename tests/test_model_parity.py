@@ -431,3 +431,44 @@ def test_bf16_batchnorm_fusions_match_the_standalone_kernels(backend):
     for n in bufs0:       # running statistics after the step; only the first stage: deeper layers of this 3-image toy amplify the ulp-level differences
         if n.startswith("visual.cnn.bn1") or n.startswith("visual.cnn.layer1"):
             assert rel_err(bufs[n], bufs0[n]) < 5e-3, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_amp_loop_is_transparent_gpu(dtype):
+    """the reference wraps the forward in `amp.autocast` and the backward / step in a `GradScaler`
+    (scripts/pretrain_virtex.py:107,150-161).  The native modules compute in their own dtype and keep fp32 parameter
+    gradients, so that loop must be numerically transparent: the (2^16-scaled) backward neither overflows nor loses
+    bits, `unscale_` restores the gradients, no step is skipped, and three steps with the reference's optimizer
+    grouping reproduce the oracle's un-scaled fp32 loop (loss per step; the 2nd and 3rd depend on the updates)."""
+    dev = select("gpu")
+    kw = dict(textual="transdec_postnorm::L1_H128_A2_F256", vocab_size=1000)
+    oracle_model = synth.seeded_model(port.build_model, seed=0, dropout=0.0, max_caption_length=12, **kw)
+    model = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=dtype, max_caption_length=12, **kw)
+    model.load_state_dict(oracle_model.state_dict())
+    model = model.to(dev).train()
+    oracle_step = port.TrainStep(oracle_model.train(), total_steps=2000, warmup_steps=200)
+    groups = port.param_groups(model.named_parameters())
+    base = [g["lr"] for g in groups]
+    optimizer = torch.optim.SGD(groups, momentum=0.9)
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    tol = 2e-4 if dtype == torch.float32 else 5e-3
+    for it in range(3):
+        batch = synth.synthetic_batch(4, image_size=128, max_len=12, vocab_size=1000, seed=60 + it, ragged=True)
+        expect = oracle_step(batch).item()
+        mult = port.lr_multiplier(it, 2000, 200)
+        for g, b in zip(optimizer.param_groups, base):
+            g["lr"] = b * mult
+        optimizer.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=True):
+            out = model({k: v.to(dev) for k, v in batch.items()})
+            loss = out["loss"]
+        assert loss.dtype == torch.float32
+        scaler.scale(loss).backward()
+        scaler.unscale_(optimizer)
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        scaler.step(optimizer)
+        scaler.update()
+        assert scaler.get_scale() == 65536.0                    # no inf/nan was found: nothing skipped, scale untouched
+        assert abs(loss.item() - expect) < tol * abs(expect), (it, loss.item(), expect)
