@@ -472,3 +472,31 @@ def test_reference_amp_loop_is_transparent_gpu(dtype):
         scaler.update()
         assert scaler.get_scale() == 65536.0                    # no inf/nan was found: nothing skipped, scale untouched
         assert abs(loss.item() - expect) < tol * abs(expect), (it, loss.item(), expect)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_shared_visual_projection_equals_the_per_head_evaluation(backend):
+    """The tied `visual_projection` evaluated once for both heads (models.SHARE_VISUAL_PROJECTION) against the
+    reference's order (once per head, textual_heads.py:245): same loss, same gradients up to fp32 summation order,
+    incl. the projection's own weight / bias gradient, which now comes from ONE weight-gradient GEMM on the summed
+    memory gradient."""
+    from virtex_amd import models
+    dev = select(backend)
+    _, model, batch = _build_pair("r50_l2_h128_b3_small", dev, torch.float32)
+    saved = models.SHARE_VISUAL_PROJECTION
+    try:
+        runs = {}
+        for mode in (False, True):
+            models.SHARE_VISUAL_PROJECTION = mode
+            model.zero_grad(set_to_none=True)
+            out = _run(model, batch, dev)
+            runs[mode] = (out["loss"].item(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()})
+    finally:
+        models.SHARE_VISUAL_PROJECTION = saved
+    assert abs(runs[True][0] - runs[False][0]) <= 1e-6 * abs(runs[False][0])
+    for n, g in runs[False][1].items():
+        if "cnn" not in n:
+            assert rel_err(runs[True][1][n], g) < 1e-5, n
+    assert rel_err(runs[True][1]["textual.visual_projection.weight"], runs[False][1]["textual.visual_projection.weight"]) < 1e-5
+    worst = max(rel_err(runs[True][1][n], g) for n, g in runs[False][1].items() if "cnn" in n and g.norm() > 0)
+    assert worst < 2e-2          # the backbone sees d(features) through one GEMM instead of two: fp32 summation order, amplified by the toy's conditioning

@@ -171,8 +171,18 @@ class TransformerDecoderTextualHead(TextualHead):
                 layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
                 layer.norm3.weight, layer.norm3.bias]
 
-    def features(self, visual_features, caption_tokens, caption_lengths):
-        """(B,C,h,w) visual grid + (B,T) tokens -> decoder hidden states (B,T,H) in compute dtype."""
+    def project_visual_features(self, visual_features):
+        """The projected visual grid (B*S, H) of `visual_projection` as its own autograd node, so that a model whose
+        heads SHARE the projection (CaptioningModel ties it, captioning.py:57-63) evaluates it -- forward, input
+        gradient and weight gradient -- once per step instead of once per head (legal because the
+        gradients add linearly; the reference's order, one evaluation per head, stays available as the faithful
+        mode: `features(...)` without `memory`)."""
+        return _VisualProjectionFn.apply(visual_features, self.visual_projection.weight, self.visual_projection.bias,
+                                         self.compute_dtype)
+
+    def features(self, visual_features, caption_tokens, caption_lengths, memory=None):
+        """(B,C,h,w) visual grid + (B,T) tokens -> decoder hidden states (B,T,H) in compute dtype.
+        memory: the output of `project_visual_features` when the caller shares it between heads."""
         emb = self.embedding
         emb.compute_dtype = self.compute_dtype
         x0 = emb(caption_tokens)
@@ -180,7 +190,10 @@ class TransformerDecoderTextualHead(TextualHead):
         for layer in self.transformer.layers:
             params += self._layer_params(layer)
         p = self.dropout if self.training else 0.0
-        return _DecoderFn.apply(visual_features, x0, caption_lengths, self, p, *params)
+        if memory is not None:
+            B, _, h, w = visual_features.shape
+            return _DecoderFn.apply(memory, x0, caption_lengths, self, p, (B, h * w), *params)
+        return _DecoderFn.apply(visual_features, x0, caption_lengths, self, p, None, *params)
 
     def forward(self, visual_features, caption_tokens, caption_lengths):
         """Returns (B,T,V) fp32 logits, like the reference (textual_heads.py:216-278)."""
@@ -213,23 +226,67 @@ def _nhwc_rows(visual_features, dtype):
     return m.view(B * h * w, C), B, h * w
 
 
+class _VisualProjectionFn(torch.autograd.Function):
+    """mem = visual_grid @ Wv^T + bv as (B*S, H) rows (reference: textual_heads.py:240-245), shared by both heads."""
+
+    @staticmethod
+    def forward(ctx, visual_features, weight, bias, dt):
+        mem_in, B, S = _nhwc_rows(visual_features, dt)
+        Wv, _ = ops.prepped(weight, dt)
+        mem = ops.gemm_nt(mem_in, Wv.view(weight.shape), bias=bias.detach())
+        ctx.mem_in, ctx.owner, ctx.dt = mem_in, (weight, bias), dt
+        ctx.vshape, ctx.needs_vis_grad = visual_features.shape, visual_features.requires_grad
+        return mem
+
+    @staticmethod
+    def backward(ctx, dmem):
+        weight, bias = ctx.owner
+        dt = ctx.dt
+        if dmem.dtype != dt or not dmem.is_contiguous():
+            dmem = dmem.to(dt).contiguous()
+        dW, rW = _sink_or_zeros(weight)
+        db, rb = _sink_or_zeros(bias)
+        if rW is None and rb is None:
+            with wgrad_stream(dmem.device, dmem, ctx.mem_in):
+                ops.gemm_tn_acc(dmem, ctx.mem_in, dW)
+                ops.colsum_acc(dmem, db)
+        else:
+            ops.gemm_tn_acc(dmem, ctx.mem_in, dW)
+            ops.colsum_acc(dmem, db)
+        dvis = None
+        if ctx.needs_vis_grad:
+            _, Wv_t = ops.prepped(weight, dt)
+            Bv, C, h, w = ctx.vshape
+            dvis = ops.gemm_nt(dmem, Wv_t.view(C, -1)).view(Bv, h, w, C).permute(0, 3, 1, 2)
+        return dvis, rW, rb, None
+
+
 class _DecoderFn(torch.autograd.Function):
     """visual_projection + L post-norm decoder layers (reference: textual_heads.py:240-275 and
     torch/nn/modules/transformer.py:1143-1199), forward and hand-written backward."""
 
     @staticmethod
-    def forward(ctx, visual_features, x0, lengths, head, p, *params):
+    def forward(ctx, visual_features, x0, lengths, head, p, shared_memory, *params):
+        """shared_memory = (B, S): `visual_features` already IS the projected memory (B*S, H) of
+        `_VisualProjectionFn` (the projection's own parameters are then not touched here)."""
         dt = head.compute_dtype
         A = head.attention_heads
         H = head.hidden_size
-        mem_in, B, S = _nhwc_rows(visual_features, dt)
+        ctx.shared = shared_memory is not None
+        if ctx.shared:
+            B, S = shared_memory
+            mem, mem_in, Wv_t = visual_features, None, None
+            if mem.dtype != dt or not mem.is_contiguous():
+                mem = mem.to(dt).contiguous()
+        else:
+            mem_in, B, S = _nhwc_rows(visual_features, dt)
+            bv = params[1].detach()
+            Wv, Wv_t = ops.prepped(params[0], dt)
+            Wv, Wv_t = Wv.view(H, -1), Wv_t.view(-1, H)
+            mem = ops.gemm_nt(mem_in, Wv, bias=bv)                   # (B*S, H)
         T = x0.shape[1]
         x = x0.reshape(B * T, H)
         lengths = lengths.contiguous()
-        bv = params[1].detach()
-        Wv, Wv_t = ops.prepped(params[0], dt)
-        Wv, Wv_t = Wv.view(H, -1), Wv_t.view(-1, H)
-        mem = ops.gemm_nt(mem_in, Wv, bias=bv)                       # (B*S, H)
         saved_layers = []
         for li in range(head.num_layers):
             raw = params[2 + 18 * li: 2 + 18 * (li + 1)]
@@ -358,6 +415,8 @@ class _DecoderFn(torch.autograd.Function):
             dx = ops.gemm_nt(dqkv, cw["Win"][1], residual=dz1)
             pgrads = [dWin, dbin, dWo, dbo, rdg1, rdb1, rWin2, rbin2, dWo2, dbo2, rdg2, rdb2, dW1, dbf1, dW2, dbf2,
                       rdg3, rdb3] + pgrads
+        if ctx.shared:          # the projection is its own node: hand the memory's gradient back to it
+            return (dmem, dx.view(B, T, H), None, None, None, None, None, None, *pgrads)
         # ---- visual projection
         dWv, rWv = sink(ctx.vis_owner[0])
         dbv, rbv = sink(ctx.vis_owner[1])
@@ -372,7 +431,7 @@ class _DecoderFn(torch.autograd.Function):
         if ctx.needs_vis_grad:
             Bv, C, h, w = ctx.vshape
             dvis = ops.gemm_nt(dmem, ctx.Wv_t).view(Bv, h, w, C).permute(0, 3, 1, 2)
-        return (dvis, dx.view(B, T, H), None, None, None, rWv, rbv, *pgrads)
+        return (dvis, dx.view(B, T, H), None, None, None, None, rWv, rbv, *pgrads)
 
 
 def _sink_or_zeros(p):
