@@ -276,6 +276,18 @@ int vtx_tied_ce_bwd(int dtype, int R, int V, int H, const void* hidden, long ldh
                     const float* bias, const long long* targets, int ignore_index, const float* lse,
                     const float* loss_and_count, const float* grad_out, void* dlogits, void* stream);
 
+/* ---- one beam-search step on the device (csrc/beam.hip) ----------------------------------
+ * Replaces the aten::log_softmax / scatter_ / where / topk / gather chain and the per-row Python loop of
+ * virtex/utils/beam_search.py:115-228.  logits:[rows = images*beams_in][V] fp32 (row stride ld); last:[rows] int64 the
+ * previous token of every row (NULL on the first step: no repetition penalty, no finished beams); score_in:[rows] fp32
+ * cumulative log-probabilities (NULL = 0).  Per row the `per_node` best of log_softmax(logits) with log-prob(last) :=
+ * -10000 and, for rows whose last token is `eos`, {eos: 0, everything else: -inf}; per image the `beam` best of the
+ * beams_in*per_node cumulative scores -> score_out/parent_out/token_out:[images][beam] (best first; parent = beam index
+ * inside the image).  cand_lp/cand_tok:[rows][per_node] scratch.  Ties: lowest index. */
+int vtx_beam_step(const float* logits, long ld, const long long* last, const float* score_in, int images, int beams_in,
+                  int V, int eos, int per_node, int beam, float* cand_lp, long long* cand_tok, float* score_out,
+                  long long* parent_out, long long* token_out, void* stream);
+
 /* ---- small helpers -------------------------------------------------------------------- */
 long vtx_colsum_workspace_floats(int C);
 int vtx_colsum_acc(int dtype, const void* x, long ld, float* out /*[C] +=*/, float* workspace, int R, int C,

@@ -111,3 +111,68 @@ def test_missing_decoder_raises_like_the_reference():
     model.visual.forward = lambda image: torch.zeros(image.size(0), 2048, 2, 2)
     with pytest.raises(ValueError, match="Decoder for predicting captions is missing"):
         model({"image": torch.zeros(1, 3, 64, 64)})
+
+
+from backends import BACKENDS  # noqa: E402
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [c for c in sorted(dc.CASES) if dc.CASES[c][0].startswith("beam")])
+def test_device_beam_step_reproduces_reference_goldens(backend, case):
+    """The same goldens (reference's own AutoRegressiveBeamSearch on a deterministic step function) with every step's
+    selection done by vtx_beam_step: tokens exact, log-probabilities to fp32 rounding."""
+    dev = select(backend)
+    with open(GOLDEN) as f:
+        gold = json.load(f)[case]
+    kind, kw, B, seed = dc.CASES[case]
+    step_cpu = dc.make_step(seed)
+    calls = []
+
+    def step(partial):
+        out = step_cpu(partial.cpu()).to(dev)
+        calls.append(out.device.type)
+        return out
+    start = torch.full((B,), dc.SOS, dtype=torch.long, device=dev)
+    tokens, lp = AutoRegressiveBeamSearch(**kw).search(start, step, only_return_best=(kind == "beam"))
+    assert tokens.cpu().tolist() == gold["tokens"]
+    assert torch.allclose(lp.cpu(), torch.tensor(gold["logprobs"]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_incremental_decoding_step_equals_full_prefix_recompute(backend, dtype):
+    """The KV-cached step (one token per call) against `model.decoding_step` (the reference's semantics: the whole
+    prefix through the head at every call) on the SAME model: logits of every step of a beam search with re-ordered,
+    duplicated and dropped beams, driven by the prefixes alone (no `reorder` hint -- what a foreign decoder gives)."""
+    from oracle import synth
+    import virtex_amd.factories as vf
+    from virtex_amd.decoding import IncrementalDecodingStep
+    dev = select(backend)
+    torch.manual_seed(3)
+    model = vf.build_bicaptioning_model(textual="transdec_postnorm::L2_H128_A2_F256", vocab_size=300, dropout=0.0,
+                                        compute_dtype=dtype, max_caption_length=12).to(dev).eval()
+    synth.randomize_state(model, 7)
+    feats = torch.randn(3, 2048, 2, 2, device=dev).to(dtype if dtype == torch.bfloat16 else torch.float32)
+    feats = feats.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)          # NHWC-physical like the backbone's output
+    step = IncrementalDecodingStep(model.textual, feats)
+    g = torch.Generator().manual_seed(5)
+    B, W = 3, 4
+    prefix = torch.full((B,), 1, dtype=torch.long)
+    tol = 2e-4 if dtype == torch.float32 else 6e-2
+    with torch.no_grad():
+        got, ref = step(prefix.to(dev)), model.decoding_step(feats, prefix.to(dev))
+        assert rel_err(got.cpu(), ref.float().cpu()) < tol
+        beams = torch.cat([prefix.view(B, 1, 1).expand(B, W, 1), torch.randint(4, 300, (B, W, 1), generator=g)], -1)
+        for t in range(2, 9):
+            flat = beams.reshape(B * W, -1)
+            got, ref = step(flat.to(dev)), model.decoding_step(feats, flat.to(dev))
+            assert got.shape == ref.shape == (B * W, 300)
+            assert rel_err(got.cpu(), ref.float().cpu()) < tol, t
+            parent = torch.randint(0, W, (B, W), generator=g)                    # beams continue arbitrary beams of their image
+            beams = torch.cat([beams.gather(1, parent.unsqueeze(-1).expand(B, W, beams.size(-1))),
+                               torch.randint(4, 300, (B, W, 1), generator=g)], -1)
+
+
+def rel_err(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()

@@ -101,6 +101,10 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
 # (0.62 GFLOP per image).  "0" = the reference's evaluation order (faithful mode for bit-level comparisons).
 SHARE_VISUAL_PROJECTION = os.environ.get("VIRTEX_AMD_SHARE_VISUAL_PROJECTION", "1") != "0"
 
+# Inference: KV-cached incremental decoding (decoding.IncrementalDecodingStep) instead of re-running the whole prefix at
+# every step like the reference's decoding_step (kept: `model.decoding_step`, and "0" here, for comparisons).
+INCREMENTAL_DECODING = os.environ.get("VIRTEX_AMD_INCREMENTAL_DECODING", "1") != "0"
+
 # the two caption directions on two streams (A/B switch; see DESIGN.md, Streams)
 HEAD_STREAMS = os.environ.get("VIRTEX_AMD_HEAD_STREAMS", "1") != "0"
 if HEAD_STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
@@ -203,7 +207,11 @@ class CaptioningModel(nn.Module):
             if self.decoder is None:
                 raise ValueError("Decoder for predicting captions is missing!")
             start_predictions = visual_features.new_full((batch_size,), self.sos_index).long()
-            decoding_step = functools.partial(self.decoding_step, visual_features)
+            if INCREMENTAL_DECODING and not self.training and hasattr(self.textual, "transformer") and hasattr(self.textual, "compute_dtype"):
+                from .decoding import IncrementalDecodingStep
+                decoding_step = IncrementalDecodingStep(self.textual, visual_features)      # one token per step, K/V cached
+            else:
+                decoding_step = functools.partial(self.decoding_step, visual_features)
             predicted_caption, _ = self.decoder.search(start_predictions, decoding_step)
             output_dict = {"predictions": predicted_caption}
         return output_dict

@@ -640,6 +640,24 @@ def tied_ce_bwd(hidden, weight, bias, targets, lse, lc, grad_out, ignore_index=0
     return d
 
 
+def beam_step(logits, last, score_in, images, per_node, beam, eos):
+    """One beam-search step on the device (vtx_beam_step).  logits fp32 [rows, V]; last int64 [rows] or None (first
+    step); score_in fp32 [rows] or None.  Returns (score [images, beam], parent [images, beam], token [images, beam])."""
+    rows, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and rows % images == 0
+    _chk(last, "last", torch.int64); _chk(score_in, "score_in", torch.float32)
+    dev = logits.device
+    cand_lp = torch.empty(rows, per_node, dtype=torch.float32, device=dev)
+    cand_tok = torch.empty(rows, per_node, dtype=torch.int64, device=dev)
+    score = torch.empty(images, beam, dtype=torch.float32, device=dev)
+    parent = torch.empty(images, beam, dtype=torch.int64, device=dev)
+    token = torch.empty(images, beam, dtype=torch.int64, device=dev)
+    call("vtx_beam_step", ptr(logits), c_long(logits.stride(0)), ptr(last), ptr(score_in), c_int(images), c_int(rows // images),
+         c_int(V), c_int(eos), c_int(per_node), c_int(beam), ptr(cand_lp), ptr(cand_tok), ptr(score), ptr(parent), ptr(token),
+         stream_ptr(logits))
+    return score, parent, token
+
+
 _colsum_ws = {}
 
 
