@@ -208,6 +208,21 @@ int vtx_image_to_nhwc_halo(int dtype, const float* src_nchw, void* dst_nhwc, int
 int vtx_image_u8_to_nhwc(int dtype, const uint8_t* src, void* dst, int N, int Hs, int Ws, int H, int W, int Cpad,
                          int halo, const int* crop_xy, const uint8_t* flip, const float* mean, const float* std,
                          void* stream);
+/* The training / validation image pipeline on the device (csrc/augment.hip): uint8 [N][Hs][Ws][3] decoder output ->
+ * per-image crop window, bilinear resize to size x size, horizontal flip, colour jitter (brightness, contrast,
+ * saturation, hue factors applied in the per-image `order`: 2 bits per position, 0 brightness 1 contrast 2 saturation
+ * 3 hue), Normalize(mean, std; host pointers, [0,1] units) -> NHWC dtype, channels zero-padded to Cpad, zero frame of
+ * `halo` pixels.  Replaces alb.RandomResizedCrop / T.HorizontalFlip / alb.ColorJitter / alb.Normalize / np.transpose of
+ * virtex/data/transforms.py:5-97 + virtex/factories.py:132-154 (validation: centre crop window, identity jitter).
+ * gray_sum: N floats of scratch.  The parameters are sampled on the host (virtex_amd/data.py). */
+typedef struct VtxAugParams {
+    int x0, y0, cw, ch;   /* crop window in source pixels (inside the image's valid area) */
+    int flip;             /* != 0: mirror horizontally */
+    float brightness, contrast, saturation, hue;   /* factors; 1, 1, 1, 0 = identity; hue = fraction of a turn */
+    int order;            /* the four colour operations' order, 2 bits each from bit 0 (0x E4 = b, c, s, h) */
+} VtxAugParams;
+int vtx_image_augment_u8(int dtype, const uint8_t* src, void* dst, const VtxAugParams* params, float* gray_sum, int N,
+                         int Hs, int Ws, int size, int Cpad, int halo, const float* mean, const float* std, void* stream);
 int vtx_weight_prep(int dtype, const float* w32 /*[KO][T][C]*/, void* w /*[KO][T][Cp] or NULL*/,
                     void* wt /*[Cp][T][KO] or NULL*/, int KO, int T, int C, int Cp, void* stream);
 /* every weight of the step in one launch: descs[i] (device memory) describes one vtx_weight_prep; tile_start[i]

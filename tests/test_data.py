@@ -53,3 +53,92 @@ def test_cycle_moves_batches_and_restarts():
     it = vdata.cycle(loader, torch.device("cpu"))
     sizes = [next(it)["image"].shape[0] for _ in range(5)]
     assert sizes == [4, 2, 4, 2, 4]
+
+
+# ---- SURVEY.md 8f f2, second part: augmentation on the device, tokenizer, caption cache -------------------------------
+import random
+
+import numpy as np
+
+from backends import BACKENDS, select
+from oracle import augment as aug_oracle
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_device_augmentation_matches_the_pipeline_restatement(backend, dtype):
+    """vtx_image_augment_u8 (crop window + bilinear resize + flip + colour jitter in the sampled order + Normalize +
+    layout) against oracle/augment.py, the numpy restatement of the reference's albumentations pipeline, on the same
+    sampled parameters: identical up to single uint8 counts on a handful of pixels (float summation order of the
+    contrast mean), for training (random windows) and validation (centre window, identity jitter) parameters."""
+    dev = select(backend)
+    rng = random.Random(7)
+    g = torch.Generator().manual_seed(7)
+    N, Hs, Ws, size = 5, 57, 75, 32
+    imgs = torch.randint(0, 256, (N, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    windows = [vdata.sample_random_resized_crop(Hs, Ws, rng) for _ in range(N - 1)] + [vdata.center_crop_window(Hs, Ws, 256, 224)]
+    flips = [rng.random() < 0.5 for _ in range(N - 1)] + [False]
+    jitters = [vdata.sample_color_jitter(rng, p=1.0) for _ in range(N - 1)] + [(1.0, 1.0, 1.0, 0.0, 0xE4)]
+    for (x0, y0, cw, ch) in windows:
+        assert 0 <= x0 and 0 <= y0 and x0 + cw <= Ws and y0 + ch <= Hs and cw > 0 and ch > 0
+    out = vdata.augment_batch(imgs.to(dev), windows, flips, jitters, size=size, dtype=dtype, packed=False)
+    assert out.shape == (N, size, size, 8) and out.dtype == dtype
+    assert out[..., 3:].abs().max().item() == 0
+    tol_count = 1.02 / (255 * 0.224)                                      # one uint8 count after Normalize
+    for n in range(N):
+        ref = aug_oracle.pipeline(imgs[n].numpy(), windows[n], flips[n], jitters[n], size)        # (3, size, size)
+        got = out[n, :, :, :3].float().cpu().permute(2, 0, 1).numpy()
+        diff = np.abs(got - ref)
+        bf = 0.02 if dtype == torch.bfloat16 else 1e-5                     # bf16 storage of values up to ~2.7
+        assert (diff > tol_count + bf).sum() == 0, n
+        assert (diff > bf).mean() < 0.01, (n, (diff > bf).mean())
+    packed = vdata.augment_batch(imgs.to(dev), windows, flips, jitters, size=size, dtype=dtype)   # the stem's packed layout
+    assert packed.shape == (N, size + 6, size + 6, 4)
+    assert torch.equal(packed[:, 3:-3, 3:-3, :3], out[..., :3]) and packed[:, :3].abs().max().item() == 0
+
+
+def test_crop_and_jitter_samplers_follow_the_reference_defaults():
+    rng = random.Random(3)
+    areas, ratios = [], []
+    for _ in range(2000):
+        x0, y0, cw, ch = vdata.sample_random_resized_crop(300, 400, rng)
+        assert 0 <= x0 <= 400 - cw and 0 <= y0 <= 300 - ch
+        areas.append(cw * ch / 120000.0); ratios.append(cw / ch)
+    assert 0.19 < min(areas) and max(areas) <= 1.0 and 0.4 < np.mean(areas) < 0.65      # scale (0.2, 1.0), large windows of extreme ratio are rejected
+    assert 0.74 < min(ratios) and max(ratios) < 1.35                                    # ratio (3/4, 4/3)
+    js = [vdata.sample_color_jitter(rng) for _ in range(2000)]
+    ident = sum(1 for j in js if j[:4] == (1.0, 1.0, 1.0, 0.0))
+    assert 300 < ident < 500                                                            # p = 0.8
+    active = [j for j in js if j[:4] != (1.0, 1.0, 1.0, 0.0)]
+    assert all(0.6 <= j[0] <= 1.4 and 0.6 <= j[1] <= 1.4 and 0.6 <= j[2] <= 1.4 and -0.1 <= j[3] <= 0.1 for j in active)
+    assert all(sorted((j[4] >> (2 * k)) & 3 for k in range(4)) == [0, 1, 2, 3] for j in js)
+    assert len({j[4] for j in active}) == 24                                            # every order of the four operations
+    assert vdata.center_crop_window(480, 640) == (110, 30, 420, 420)
+    assert vdata.flip_caption("a dog left of the right door") == "a dog right of the left door"
+
+
+def test_sentencepiece_tokenizer_and_caption_cache(tmp_path):
+    """Same interface as virtex/data/tokenizers.py on a model trained here (no network: a toy BPE model with the
+    reference's special tokens, virtex/config.py:72-82), item format through caption_instance, int16 caption cache."""
+    import sentencepiece as sp
+    corpus = tmp_path / "captions.txt"
+    words = ["a", "dog", "cat", "sits", "left", "right", "of", "the", "red", "door", "on", "grass", "two", "people", "walk"]
+    rng = random.Random(0)
+    corpus.write_text("\n".join(" ".join(rng.choice(words) for _ in range(rng.randint(4, 9))) for _ in range(400)))
+    prefix = str(tmp_path / "toy")
+    sp.SentencePieceTrainer.train(input=str(corpus), model_prefix=prefix, vocab_size=60, model_type="bpe", character_coverage=1.0,
+                                  bos_id=-1, eos_id=-1, control_symbols="[SOS],[EOS],[MASK]", minloglevel=2)
+    tok = vdata.SentencePieceBPETokenizer(prefix + ".model")
+    assert tok.get_vocab_size() == 60
+    assert (tok.token_to_id("<unk>"), tok.token_to_id("[SOS]"), tok.token_to_id("[EOS]"), tok.token_to_id("[MASK]")) == (0, 1, 2, 3)
+    ids = tok.encode("a dog sits left of the door")
+    assert all(isinstance(i, int) and 3 < i < 60 for i in ids) and tok.decode(ids) == "a dog sits left of the door"
+    assert tok.id_to_token(1) == "[SOS]"
+    import pickle
+    assert pickle.loads(pickle.dumps(tok)).encode("two people walk") == tok.encode("two people walk")     # DataLoader workers
+    caps = ["a dog sits left of the door", "two people walk on the grass"]
+    cache = vdata.CaptionTokenCache(tok, caps)
+    assert cache.tokens(0) == ids and cache.tokens(0, flipped=True) == tok.encode("a dog sits right of the door")
+    assert cache.tokens(1, flipped=True) == cache.tokens(1) and cache.plain[0].dtype == np.int16
+    item = vdata.caption_instance(7, torch.zeros(8, 8, 3, dtype=torch.uint8), cache.tokens(0))
+    assert item["caption_tokens"][0] == 1 and item["caption_tokens"][-1] == 2 and int(item["caption_lengths"]) == len(ids) + 2

@@ -392,6 +392,22 @@ def image_u8_to_nhwc(images, dtype, cpad, size=None, crop_xy=None, flip=None, me
     return out
 
 
+def image_augment_u8(images, params, size, dtype, cpad, halo=0, mean=IMAGENET_COLOR_MEAN, std=IMAGENET_COLOR_STD):
+    """uint8 (N, Hs, Ws, 3) + per-image VtxAugParams records (uint8 tensor of N*40 bytes on the device) -> augmented,
+    normalised (N, size+2*halo, size+2*halo, cpad) in `dtype` (vtx_image_augment_u8)."""
+    assert images.dtype == torch.uint8 and images.dim() == 4 and images.shape[-1] == 3 and images.is_contiguous()
+    N, Hs, Ws, _ = images.shape
+    assert params.dtype == torch.uint8 and params.numel() == N * 40 and params.is_contiguous()
+    out = torch.empty(N, size + 2 * halo, size + 2 * halo, cpad, dtype=dtype, device=images.device)
+    scratch = torch.empty(N, dtype=torch.float32, device=images.device)
+    ctypes = _lib.ctypes
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    call("vtx_image_augment_u8", c_int(dtype_code(dtype)), ptr(images), ptr(out), ptr(params), ptr(scratch), c_int(N), c_int(Hs),
+         c_int(Ws), c_int(size), c_int(cpad), c_int(halo), m, sd, stream_ptr(images))
+    return out
+
+
 # ---- compute copies of the master weights, cached on the parameter until its version changes -----------
 def _w32_view(param):
     """fp32 master weight as [KO, T, C]: conv weights are stored (KO,R,S,C) physically (channels_last)."""
