@@ -76,9 +76,15 @@ def device_batch(B, dev, seed, image_size=224, vocab_size=10000):
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r01_pmc_traffic_v9.txt.
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r02_pmc_traffic.txt.  Two
+# kernels are within a percent of each other at the top of the step (the fused-dgrad contraction and bn_bwd_apply), so both
+# are listed; `traffic` is reported for whichever the live measurement finds dominant.
 TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
 TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE)
+    # 28 launches/step: (2 x 202.6e3 + 112.4e3) KiB                 (algorithmic 513.5 MB -> 1.03x)
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 530.0e6,
+    # 53 launches/step over its three kernels: (2 x 105.4e3 + 105.8e3) KiB launch-weighted
+    "bn_bwd_apply": 324.2e6,
 }
 
 

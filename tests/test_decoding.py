@@ -37,7 +37,8 @@ def test_decoders_equal_live_reference(case):
     t, lp = dc.run(AutoRegressiveBeamSearch, AutoRegressiveNucleusSampling, case)
     assert torch.equal(t, t_ref)
     if lp_ref is not None:
-        assert torch.equal(lp, lp_ref)
+        # floating point: the summation order of log-softmax depends on the thread count earlier tests leave behind
+        torch.testing.assert_close(lp, lp_ref, rtol=1e-6, atol=1e-6)
 
 
 def test_beam_search_edge_cases():
