@@ -33,3 +33,10 @@ for i, (s, e, _, n) in enumerate(lst):
         print(f"  t={(prev_end-a)/1e6:7.3f} ms  gap {gap/1e3:7.1f} us  after [{before}] before [{short(n)[:50]}]  other queues busy {busy/1e3:7.1f} us: {names}")
     prev_end = max(prev_end, e)
 print(f"  tail: compute queue ends at t={(prev_end-a)/1e6:.3f} ms of {(b-a)/1e6:.3f}")
+# optional: rocpd_timeline.py trace.db T0_MS T1_MS -> every dispatch of the step in that window, all queues
+if len(sys.argv) >= 4:
+    t0, t1 = float(sys.argv[2]) * 1e6 + a, float(sys.argv[3]) * 1e6 + a
+    print(f"\ndispatches between t={sys.argv[2]} and t={sys.argv[3]} ms (q = queue; * = compute queue):")
+    for s, e, qq, n in step:
+        if e >= t0 and s <= t1:
+            print(f"  {(s-a)/1e6:8.3f} +{(e-s)/1e3:7.1f} us  q{qq}{'*' if qq == main else ' '} {short(n)[:110]}")

@@ -107,6 +107,8 @@ INCREMENTAL_DECODING = os.environ.get("VIRTEX_AMD_INCREMENTAL_DECODING", "1") !=
 
 # the two caption directions on two streams (A/B switch; see DESIGN.md, Streams)
 HEAD_STREAMS = os.environ.get("VIRTEX_AMD_HEAD_STREAMS", "1") != "0"
+# host order of the two heads' forward passes when they run on two streams ("0" = round-1 order, for A/B runs)
+HEAD_ORDER_BRANCH_FIRST = os.environ.get("VIRTEX_AMD_HEAD_ORDER_BRANCH_FIRST", "1") != "0"
 if HEAD_STREAMS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
     # gradients of the backward-captioning head are produced on the branch stream on purpose; autograd's
     # AccumulateGrad nodes synchronise with it correctly, the warning is only about that extra synchronisation
@@ -173,12 +175,24 @@ class CaptioningModel(nn.Module):
                     and self.backward_textual.visual_projection is self.textual.visual_projection):
                 # both heads read the same projected grid: evaluate the shared projection once
                 memory = self.textual.project_visual_features(visual_features)
+            backward_loss = None
             if self.training:
                 if self.caption_backward and HEAD_STREAMS:
                     # the two heads are independent until their losses are added: the backward-captioning head runs
-                    # on the branch stream (autograd replays each node on the stream its forward ran on)
+                    # on the branch stream (autograd replays each node on the stream its forward ran on).  It is
+                    # enqueued first, so that in backward (autograd visits the nodes created last first) the compute
+                    # stream's head is enqueued before autograd makes the compute stream wait for this head's gradient
+                    # of the shared features.  Measured neutral (tools/head_overlap.py: with HIP events and no profiler
+                    # attached both chains run 11.85 -> 14.8 ms side by side in either order; the one-after-the-other
+                    # picture in rocprofv3 kernel traces is an artefact of the tracer).
                     br = branch_stream(visual_features.device, visual_features, batch["noitpac_tokens"], caption_lengths,
-                                       *([memory] if memory is not None else [])).mark()
+                                       *([memory] if memory is not None else []))
+                    if HEAD_ORDER_BRANCH_FIRST:
+                        with br:
+                            backward_loss = self._head_loss(self.backward_textual, visual_features,
+                                                            batch["noitpac_tokens"], caption_lengths, memory)
+                    else:
+                        br.mark()
                 loss = self._head_loss(self.textual, visual_features, caption_tokens, caption_lengths, memory)
             else:
                 output_logits = self.textual(visual_features, caption_tokens, caption_lengths)
@@ -188,9 +202,10 @@ class CaptioningModel(nn.Module):
             if self.caption_backward:
                 backward_caption_tokens = batch["noitpac_tokens"]
                 if self.training and br is not None:
-                    with br:
-                        backward_loss = self._head_loss(self.backward_textual, visual_features,
-                                                        backward_caption_tokens, caption_lengths, memory)
+                    if backward_loss is None:
+                        with br:
+                            backward_loss = self._head_loss(self.backward_textual, visual_features,
+                                                            backward_caption_tokens, caption_lengths, memory)
                     br.wait(backward_loss)
                 elif self.training:
                     backward_loss = self._head_loss(self.backward_textual, visual_features,
