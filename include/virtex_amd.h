@@ -42,6 +42,10 @@ const char* vtx_last_error(void); /* thread-local */
 int vtx_set_contraction_generation(int gen);
 int vtx_set_ablation(int bits);        /* measurement only (tools/ablate_gemm.py) */
 int vtx_set_tile_override(int cand);   /* tests: force a block tile; -1 = automatic */
+/* Which contraction kernel this thread's last GEMM-shaped launch ran on: 2 = the DMA kernel (operands addressed through
+ * buffer descriptors: needs bf16, operands < 2 GB, convolution channel counts that are multiples of the 32-deep K step),
+ * 1 = the register-staged kernel (fp32, and everything the DMA kernel does not take).  Tests use it to prove coverage. */
+int vtx_last_contraction_generation(void);
 
 /* ---- LayerNorm(x + dropout(y)) --------------------------------------------------------
  * Replaces aten::dropout + aten::add + aten::layer_norm of the post-norm decoder layer

@@ -239,6 +239,29 @@ inline void hipemu_global_load_lds(const void* src, void* lds_base, int size, in
 }
 #define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) \
     hipemu_global_load_lds((const void*)(uintptr_t)(src), (void*)(uintptr_t)(dst), (size), (off))
+// buffer_load_dwordx4 ... offen lds through a raw buffer descriptor (stride 0): lane l copies `size` bytes from
+// base + voffset + soffset + imm to lds_base + l*size; every dword whose (voffset + imm) offset lies outside
+// [0, num_records) reads as zero (the range check ignores soffset, like the hardware's).  A lane that passes the range
+// check but whose full address leaves the window is a kernel bug: abort with a diagnostic.
+struct hipemu_rsrc { const char* base; uint32_t bytes; };
+typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
+inline hipemu_rsrc hipemu_make_rsrc(const void* p, int num) { return hipemu_rsrc{(const char*)p, (uint32_t)num}; }
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) hipemu_make_rsrc((p), (num))
+inline void hipemu_buffer_load_lds(hipemu_rsrc r, void* lds_base, int size, unsigned voff, unsigned soff, int imm) {
+    char* dst = (char*)lds_base + hipemu::tls.cur->lane * size;
+    for (int d = 0; d < size; d += 4) {
+        const unsigned long long o = (unsigned long long)voff + (unsigned)imm + (unsigned)d;
+        if (o + 4 > r.bytes) { memset(dst + d, 0, 4); continue; }
+        if (o + soff + 4 > r.bytes) {
+            fprintf(stderr, "hipemu: buffer load in range by voffset (%u) but voffset+soffset (%u) leaves the %u-byte window\n",
+                    voff, soff, r.bytes);
+            abort();
+        }
+        memcpy(dst + d, r.base + o + soff, 4);
+    }
+}
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, size, voff, soff, imm, aux) \
+    hipemu_buffer_load_lds((rsrc), (void*)(uintptr_t)(dst), (size), (unsigned)(voff), (unsigned)(soff), (imm))
 // ds_read_b64_tr_b16 (semantics measured on MI355X, tools/probes/tr_probe.hip): within each 16-lane
 // group, lane i receives for j = 0..3 element (i % 4) of the 8 bytes addressed by lane 4*j + i/4.
 typedef short hipemu_v4s __attribute__((ext_vector_type(4)));

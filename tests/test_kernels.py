@@ -111,7 +111,24 @@ CONV_CASES = [
     (2, 8, 8, 64, 16, 1, 1, 1, 0),
     (2, 22, 22, 8, 64, 7, 7, 2, 3),
     (1, 7, 7, 128, 128, 3, 3, 1, 1),
+    # channel counts that are multiples of the 32-deep K step: the DMA kernel with buffer-descriptor addressing
+    # (tap-uniform K steps, validity masks, the parity-decomposed stride-2 gradient, the counter-based pixel gather)
+    (2, 9, 11, 32, 64, 3, 3, 1, 1),
+    (2, 10, 12, 64, 32, 3, 3, 2, 1),
+    (3, 6, 6, 32, 32, 3, 3, 1, 0),
+    (2, 5, 7, 64, 64, 2, 3, 1, 1),
 ]
+# the cases whose bf16 forward / input gradient must run on the DMA kernel (every bf16 weight gradient does)
+def _dma_expected(case):
+    N, H, W, C, KO, R, S, stride, pad = case
+    fwd = C % 32 == 0
+    dgrad = KO % 32 == 0 and (stride == 1 or (stride == 2 and H % 2 == 0 and W % 2 == 0 and R <= 4 and S <= 4))
+    return fwd, dgrad
+
+
+def _generation():
+    from virtex_amd import _lib
+    return _lib.lib().vtx_last_contraction_generation()
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -130,15 +147,23 @@ def test_conv2d_fwd_dgrad_wgrad(backend, dtype, case):
     yr.backward(dy.float().permute(0, 3, 1, 2))
     e = 2e-5 if dtype == torch.float32 else 1e-2
 
+    bf = dtype == torch.bfloat16
+    dma_fwd, dma_dgrad = _dma_expected(case)
     y = ops.conv2d_fwd(x.to(dev), w.to(dev), stride, pad)
+    assert _generation() == (2 if bf and dma_fwd else 1)
     assert y.shape == dy.shape
     assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < e
     wt = w.permute(3, 1, 2, 0).contiguous()
     dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), x.shape, stride, pad)
+    assert _generation() == (2 if bf and dma_dgrad else 1)
     assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < e
     dw0 = torch.randn(KO, R, S, C, generator=g)
     dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), stride, pad)
+    assert _generation() == (2 if bf else 1)
     assert rel_err(dw.cpu() - dw0, wr.grad.permute(0, 2, 3, 1)) < 2 * e
+    for split in (2, 3):                     # split-K slices start their pixel counters in the middle of the batch
+        dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), stride, pad, split_k=split)
+        assert rel_err(dw.cpu() - dw0, wr.grad.permute(0, 2, 3, 1)) < 2 * e
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -383,7 +408,7 @@ def test_contraction_tile_variants_bf16(backend, cand):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("case", [(2, 9, 9, 16, 32, 3, 1, 1), (3, 8, 8, 64, 256, 1, 1, 0), (2, 10, 10, 16, 64, 3, 2, 1)])
+@pytest.mark.parametrize("case", [(2, 9, 9, 32, 32, 3, 1, 1), (3, 8, 8, 64, 256, 1, 1, 0), (2, 10, 10, 32, 64, 3, 2, 1)])
 def test_batchnorm_statistics_fused_in_conv_epilogue(backend, case):
     """bf16: the convolution epilogue emits per-strip sums of (y - shift), (y - shift)^2; BN forward fed
     with them must agree with BN forward that reduces the stored tensor itself."""
@@ -467,8 +492,8 @@ def test_contraction_profiler_counts_launches_flops_bytes(backend):
     ops.profile_start()
     ops.gemm_nt(a, b)
     ops.gemm_nt(a, b)
-    x = torch.randn(2, 9, 9, 16, generator=g).to(torch.bfloat16).to(dev)
-    w = torch.randn(32, 3, 3, 16, generator=g).to(torch.bfloat16).to(dev)
+    x = torch.randn(2, 9, 9, 32, generator=g).to(torch.bfloat16).to(dev)
+    w = torch.randn(32, 3, 3, 32, generator=g).to(torch.bfloat16).to(dev)
     ops.conv2d_fwd(x, w, 1, 1)
     rec = ops.profile_stop()
     ops.gemm_nt(a, b)                         # not profiled either
@@ -478,8 +503,8 @@ def test_contraction_profiler_counts_launches_flops_bytes(backend):
     assert "PlainKC" in gm["name"] and gm["launches"] == 2
     assert gm["flops"] == 2 * (2.0 * 300 * 128 * 64)
     assert gm["bytes"] == 2 * 2.0 * (300 * 64 + 128 * 64 + 300 * 128)
-    assert cv["flops"] == 2.0 * (2 * 9 * 9) * 32 * (9 * 16)
-    assert cv["bytes"] == 2.0 * (2 * 9 * 9 * 16 + 32 * 144 + 2 * 9 * 9 * 32)
+    assert cv["flops"] == 2.0 * (2 * 9 * 9) * 32 * (9 * 32)
+    assert cv["bytes"] == 2.0 * (2 * 9 * 9 * 32 + 32 * 288 + 2 * 9 * 9 * 32)
     assert gm["seconds"] > 0 and cv["seconds"] > 0
     ops.profile_start()
     assert ops.profile_stop() == []           # start resets the counters
@@ -609,6 +634,7 @@ def test_packed_stem_geometry(backend, dtype):
     wp[:, :, :7, :3] = w7.permute(0, 2, 3, 1)
     w = wp.to(dtype).to(dev)
     y = ops.conv2d_fwd(a0, w, 2, 0)
+    assert _generation() == (2 if dtype == torch.bfloat16 else 1)    # bf16: the DMA kernel's filter-row K steps
     e = 2e-5 if dtype == torch.float32 else 1e-2
     assert y.shape == (N, H // 2, H // 2, KO)
     assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < e

@@ -22,7 +22,7 @@ def timeit(fn, iters=10, warm=2):
 
 
 # (Cin, Cout, k, stride, Hin, count)  -- SURVEY.md B.2
-CONVS = [(8, 64, 7, 2, 224, 1), (64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256, 64, 1, 1, 56, 2),
+CONVS = [(3, 64, 7, 2, 224, 1), (64, 64, 1, 1, 56, 1), (64, 64, 3, 1, 56, 3), (64, 256, 1, 1, 56, 4), (256, 64, 1, 1, 56, 2),
          (256, 128, 1, 1, 56, 1), (128, 128, 3, 2, 56, 1), (128, 512, 1, 1, 28, 4), (256, 512, 1, 2, 56, 1),
          (512, 128, 1, 1, 28, 3), (128, 128, 3, 1, 28, 3), (512, 256, 1, 1, 28, 1), (256, 256, 3, 2, 28, 1),
          (256, 1024, 1, 1, 14, 6), (512, 1024, 1, 2, 28, 1), (1024, 256, 1, 1, 14, 5), (256, 256, 3, 1, 14, 5),
@@ -34,12 +34,18 @@ def main():
     for (C, KO, k, s, H, cnt) in CONVS:
         pad = {1: 0, 3: 1, 7: 3}[k]
         OH = (H + 2 * pad - k) // s + 1
-        x = torch.randn(B, H, H, C, device="cuda").to(dt)
-        w = (torch.randn(KO, k, k, C, device="cuda") / (k * k * C) ** 0.5).to(dt)
+        stem = k == 7
+        if stem:      # what the model runs: 4-channel pixels with a 3-pixel zero frame, 7x8 "valid" filter
+            x = torch.randn(B, H + 6, H + 6, 4, device="cuda").to(dt)
+            w = (torch.randn(KO, 7, 8, 4, device="cuda") / 147 ** 0.5).to(dt)
+            pad, C = 0, 4
+        else:
+            x = torch.randn(B, H, H, C, device="cuda").to(dt)
+            w = (torch.randn(KO, k, k, C, device="cuda") / (k * k * C) ** 0.5).to(dt)
         wt = w.permute(3, 1, 2, 0).contiguous()
         dy = torch.randn(B, OH, OH, KO, device="cuda").to(dt)
-        dw = torch.zeros(KO, k, k, C, device="cuda")
-        flops = 2.0 * B * OH * OH * KO * k * k * C
+        dw = torch.zeros(w.shape, device="cuda")
+        flops = 2.0 * B * OH * OH * KO * (147 if stem else k * k * C)
         gemm = (k == 1 and s == 1)
         if gemm:
             f = lambda: ops.gemm_nt(x.view(-1, C), w.view(KO, C))
@@ -49,7 +55,7 @@ def main():
             f = lambda: ops.conv2d_fwd(x, w, s, pad)
             d = lambda: ops.conv2d_dgrad(dy, wt, x.shape, s, pad)
             g = lambda: ops.conv2d_wgrad(x, dy, dw, s, pad)
-        tf_, td, tg = timeit(f), (timeit(d) if C != 8 else 0.0), timeit(g)
+        tf_, td, tg = timeit(f), (timeit(d) if not stem else 0.0), timeit(g)
         byts = (x.numel() + dy.numel() + w.numel()) * 2
         print(f"conv {C:4d}->{KO:4d} k{k} s{s} @{H:3d}        {cnt:3d} | {tf_*1e6:8.1f} {flops/tf_/1e12:6.0f} {byts/tf_/1e9:6.0f} | "
               f"{td*1e6:8.1f} {(flops/td/1e12 if td else 0):6.0f} | {tg*1e6:8.1f} {flops/tg/1e12:6.0f}", flush=True)

@@ -18,6 +18,8 @@
 //   MC loaders: chunk = VEC consecutive rows at one k  (k-major [K][rows] views: weight
 //               gradients; transposed into the LDS tile on store)
 #pragma once
+#include <stdlib.h>
+
 #include "vtx_common.h"
 
 namespace vtxg {
@@ -55,10 +57,28 @@ __device__ __forceinline__ int fdiv(int n, int d, float inv) {
     return q;
 }
 
+// ------------------------------------------------------------------ buffer addressing (generation-2 kernel)
+// The DMA kernel addresses every operand through a BUFFER DESCRIPTOR (buffer_load_dwordx4 ... offen lds):
+//   address = descriptor base (wave-uniform) + voffset (32-bit, per lane) + soffset (32-bit, wave-uniform SGPR).
+// A loader splits its index arithmetic accordingly: everything that depends on the lane (which row / pixel / channel
+// chunk it stages) is folded ONCE, at block start, into a byte offset `off` (B-state, one VGPR per staged chunk);
+// everything that depends on the K step (k0, and for convolutions the filter tap k0 falls into -- a K step never
+// straddles taps because C % BK == 0) is scalar arithmetic.  Lanes that must deliver zeros -- rows outside the
+// matrix, padding pixels, the K tail -- pass an out-of-range voffset: the hardware range check returns 0 and the
+// LDS-DMA writes it.  Per staged chunk the K loop therefore issues 0 (plain matrices), 3 (convolution gathers: test
+// the lane's tap-validity bit) or ~18 (pixel-major weight-gradient gather: carry-propagating (n,oh,ow) counters)
+// 32-bit VALU instructions where the pointer form needed 10 / 25 / 45 with 64-bit multiplies, two float divisions per
+// pixel and a zero-page select.  Operands must be smaller than 2 GiB (host check `buf_ok`; larger or oddly shaped
+// problems run on the register-staged generation-1 kernel through the pointer interface `init_slot` / `ptr`).
+struct BufView { const void* base; uint32_t bytes; };
+constexpr uint32_t VTX_OOB = 0x80000000u;          // voffset of a lane that must read zeros (>= every accepted size)
+constexpr double VTX_BUF_LIMIT = 2.0e9;            // bytes
+
 // ------------------------------------------------------------------ plain matrix loaders
 // rows x K view, k contiguous: element (r,k) at p[r*ld + k]
 template <class T, int SL> struct PlainKC {
     static constexpr bool MC = false;
+    static constexpr bool TAILS = true;            // K need not be a multiple of the K step
     const T* p; long ld; int rows; int K;
     struct State { const T* rp[SL]; int kc[SL]; };
     // slot i of this thread stages the chunk (global row r, k = k0 + kc)
@@ -69,10 +89,24 @@ template <class T, int SL> struct PlainKC {
     __device__ __forceinline__ const T* ptr(const State& s, int i, int k0) const {
         return (s.rp[i] && k0 + s.kc[i] < K) ? s.rp[i] + k0 : nullptr;
     }
+    // ---- buffer interface
+    struct BState { uint32_t off[SL]; int kc[SL]; };
+    bool buf_ok(int) const { return (double)rows * (double)ld * sizeof(T) < VTX_BUF_LIMIT; }
+    __device__ __forceinline__ BufView view() const { return {p, (uint32_t)(((long)(rows - 1) * ld + K) * (long)sizeof(T))}; }
+    template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int r, int kc) const {
+        s.kc[i] = kc;
+        s.off[i] = r < rows ? (uint32_t)(((long)r * ld + kc) * (long)sizeof(T)) : VTX_OOB;
+    }
+    template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(const BState& s, int i, int k0) const {
+        if constexpr (FULL) return s.off[i];
+        else return k0 + s.kc[i] < K ? s.off[i] : VTX_OOB;
+    }
+    template <int BK> __device__ __forceinline__ uint32_t soff(int k0) const { return (uint32_t)k0 * (uint32_t)sizeof(T); }
 };
 // K x rows view, rows contiguous: element (r,k) at p[k*ld + r]
 template <class T, int SL> struct PlainMC {
     static constexpr bool MC = true;
+    static constexpr bool TAILS = true;
     const T* p; long ld; int rows; int K;
     struct State { int r0[SL < 2 ? 2 : SL]; };
     // slot i stages VEC consecutive rows starting at global row r0 (r0 < 0: nothing), at global k
@@ -80,6 +114,20 @@ template <class T, int SL> struct PlainMC {
     __device__ __forceinline__ const T* ptr(const State& s, int i, int k) const {
         return (s.r0[i] >= 0 && k < K) ? p + (long)k * ld + s.r0[i] : nullptr;
     }
+    // ---- buffer interface: slot i stages rows r0..r0+7 at k = k0 + kl (kl = the slot's k inside the staged tile)
+    struct BState { uint32_t off[SL < 2 ? 2 : SL]; };
+    bool buf_ok(int) const { return (double)K * (double)ld * sizeof(T) < VTX_BUF_LIMIT; }
+    __device__ __forceinline__ BufView view() const {
+        return {p, (uint32_t)(((long)(K - 1) * ld + ((rows + 7) & ~7)) * (long)sizeof(T))};
+    }
+    template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int r0, int kl, int /*k_first*/) const {
+        s.off[i] = r0 < rows ? (uint32_t)(((long)kl * ld + r0) * (long)sizeof(T)) : VTX_OOB;
+    }
+    template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(BState& s, int i, int k0, int kl) const {
+        if constexpr (FULL) return s.off[i];
+        else return k0 + kl < K ? s.off[i] : VTX_OOB;
+    }
+    template <int BK> __device__ __forceinline__ uint32_t soff(int k0) const { return (uint32_t)((long)k0 * ld * (long)sizeof(T)); }
 };
 
 // ------------------------------------------------------------------ NHWC conv geometry
@@ -116,6 +164,54 @@ template <class T, int SL> struct ConvFwdA {
         const bool ok = s.ok[i] && k < K && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
         return ok ? x + s.base[i] + ((long)ih * g.W + iw) * g.C + ci : nullptr;
     }
+    // ---- buffer interface.  Two shapes of K step:
+    //  * tap mode (C % BK == 0): the step lies inside ONE filter tap (kh,kw): soffset = that tap's pixel offset + the
+    //    step's first channel, the lane tests bit `tap` of its validity mask (which taps of ITS output pixel are
+    //    inside the image, computed once);
+    //  * row mode (C < BK, S*C == BK, pad 0: the packed 4-channel stem): the step is one whole filter ROW, i.e. BK
+    //    contiguous elements of the input row; soffset = kh input rows, every lane is valid (the image carries its
+    //    own zero frame).
+    static constexpr bool TAILS = false;
+    struct BState { uint32_t off[SL]; uint32_t mask[SL]; };
+    long bias() const { return ((long)g.pad * g.W + g.pad) * g.C; }     // elements in front of x a padding tap may address
+    bool buf_ok(int BK) const {
+        const bool tap = g.C % BK == 0 && g.R * g.S <= 32;
+        const bool row = g.C < BK && g.S * g.C == BK && g.pad == 0;
+        return (tap || row) && K % BK == 0 && ((double)g.N * g.H * g.W * g.C + (double)bias()) * sizeof(T) < VTX_BUF_LIMIT;
+    }
+    __device__ __forceinline__ BufView view() const {
+        const long b = ((long)g.pad * g.W + g.pad) * g.C;
+        return {x - b, (uint32_t)(((long)g.N * g.H * g.W * g.C + b) * (long)sizeof(T))};
+    }
+    template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int m, int kc) const {
+        const bool ok = m < rows;
+        const int mm = ok ? m : 0;
+        const int n = mm / (g.OH * g.OW), rem = mm - n * g.OH * g.OW;
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+        const long pix = ((long)n * g.H + ih0) * g.W + iw0;             // >= -(pad*W + pad)
+        s.off[i] = (uint32_t)(((pix + (long)g.pad * g.W + g.pad) * g.C + kc) * (long)sizeof(T));
+        uint32_t mk = 0;
+        if (g.C >= BK) {
+            for (int t = 0; t < g.R * g.S; ++t) {
+                const int kh = t / g.S, kw = t - kh * g.S;
+                if (ok && (unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W) mk |= 1u << t;
+            }
+        } else mk = 1u;                                                  // row mode: rows past M re-read pixel 0 (their results are discarded)
+        s.mask[i] = mk;
+    }
+    template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(const BState& s, int i, int k0) const {
+        const int tap = g.C >= BK ? (k0 >> g.logC) : 0;                   // wave-uniform
+        return ((s.mask[i] >> tap) & 1u) ? s.off[i] : VTX_OOB;
+    }
+    template <int BK> __device__ __forceinline__ uint32_t soff(int k0) const {
+        if (g.C >= BK) {
+            const int tap = k0 >> g.logC, ci0 = k0 & (g.C - 1);
+            const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
+            return (uint32_t)(((kh * g.W + kw) * g.C + ci0) * (int)sizeof(T));
+        }
+        return (uint32_t)((k0 / BK) * g.W * g.C * (int)sizeof(T));
+    }
 };
 
 // input gradient: A(m,k): m = (n,ih,iw), k = (kh,kw,co) -> dy[n][(ih+p-kh)/s][(iw+p-kw)/s][co]
@@ -143,6 +239,42 @@ template <class T, int SL> struct ConvDgradA {
         const bool ok = s.ok[i] && k < K && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 &&
                         oh < g.OH && ow < g.OW;
         return ok ? dy + s.base[i] + ((long)oh * g.OW + ow) * g.KO + co : nullptr;
+    }
+    // ---- buffer interface (stride 1; KO % BK == 0 so that a K step lies inside one tap).  Row m = input pixel
+    // (n,ih,iw) reads dy pixel P - (kh*OW + kw) with P = (n*OH + ih+pad)*OW + iw+pad: the lane part is P, the tap part
+    // is uniform and NEGATIVE, so the descriptor starts `maxoff` elements before dy and soffset = maxoff - tap offset.
+    static constexpr bool TAILS = false;
+    struct BState { uint32_t off[SL]; uint32_t mask[SL]; };
+    long maxoff() const { return ((long)(g.R - 1) * g.OW + (g.S - 1)) * g.KO; }
+    bool buf_ok(int BK) const {
+        return g.stride == 1 && g.KO % BK == 0 && g.R * g.S <= 32 && K % BK == 0 &&
+               ((double)g.N * g.OH * g.OW * g.KO + 2.0 * (double)maxoff() + g.KO) * sizeof(T) < VTX_BUF_LIMIT;
+    }
+    __device__ __forceinline__ BufView view() const {
+        const long mo = ((long)(g.R - 1) * g.OW + (g.S - 1)) * g.KO;
+        return {dy - mo, (uint32_t)(((long)g.N * g.OH * g.OW * g.KO + 2 * mo + g.KO) * (long)sizeof(T))};
+    }
+    template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int m, int kc) const {
+        const bool ok = m < rows;
+        const int mm = ok ? m : 0;
+        const int n = mm / (g.H * g.W), rem = mm - n * g.H * g.W;
+        const int ih = rem / g.W, iw = rem - ih * g.W;
+        const long P = ((long)n * g.OH + ih + g.pad) * g.OW + iw + g.pad;
+        s.off[i] = (uint32_t)((P * g.KO + kc) * (long)sizeof(T));
+        uint32_t mk = 0;
+        for (int t = 0; t < g.R * g.S; ++t) {
+            const int kh = t / g.S, kw = t - kh * g.S;
+            if (ok && (unsigned)(ih + g.pad - kh) < (unsigned)g.OH && (unsigned)(iw + g.pad - kw) < (unsigned)g.OW) mk |= 1u << t;
+        }
+        s.mask[i] = mk;
+    }
+    template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(const BState& s, int i, int k0) const {
+        return ((s.mask[i] >> (k0 >> g.logKO)) & 1u) ? s.off[i] : VTX_OOB;
+    }
+    template <int BK> __device__ __forceinline__ uint32_t soff(int k0) const {
+        const int tap = k0 >> g.logKO, co0 = k0 & (g.KO - 1);
+        const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
+        return (uint32_t)(((((g.R - 1) - kh) * g.OW + ((g.S - 1) - kw)) * g.KO + co0) * (int)sizeof(T));
     }
 };
 
@@ -173,6 +305,42 @@ template <class T, int SL> struct ConvDgradS2A {
         const bool ok = s.ok[i] && k < K && (unsigned)oh < (unsigned)g.OH && (unsigned)ow < (unsigned)g.OW;
         return ok ? dy + s.base[i] + ((long)oh * g.OW + ow) * g.KO + co : nullptr;
     }
+    // ---- buffer interface.  ihp and the class's kh have the same parity, so (ihp - kh) >> 1 = (ihp >> 1) - (kh >> 1):
+    // lane part P = (n*OH + (ihp>>1))*OW + (iwp>>1), uniform tap part (kh>>1)*OW + (kw>>1) <= OW + 1 (filters <= 4x4).
+    static constexpr bool TAILS = false;
+    struct BState { uint32_t off[SL]; uint32_t mask[SL]; };
+    bool buf_ok(int BK) const {
+        return g.KO % BK == 0 && K % BK == 0 &&
+               ((double)g.N * g.OH * g.OW * g.KO + 2.0 * (g.OW + 1.0) * g.KO + g.KO) * sizeof(T) < VTX_BUF_LIMIT;
+    }
+    __device__ __forceinline__ BufView view() const {
+        const long mo = (long)(g.OW + 1) * g.KO;
+        return {dy - mo, (uint32_t)(((long)g.N * g.OH * g.OW * g.KO + 2 * mo + g.KO) * (long)sizeof(T))};
+    }
+    template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int m, int kc) const {
+        const bool ok = m < rows;
+        const int mm = ok ? m : 0;
+        const int h2 = g.H >> 1, w2 = g.W >> 1;
+        const int n = mm / (h2 * w2), rem = mm - n * h2 * w2;
+        const int ih2 = rem / w2, iw2 = rem - ih2 * w2;
+        const int ihp = 2 * ih2 + pa + g.pad, iwp = 2 * iw2 + pb + g.pad;
+        const long P = ((long)n * g.OH + (ihp >> 1)) * g.OW + (iwp >> 1);
+        s.off[i] = (uint32_t)((P * g.KO + kc) * (long)sizeof(T));
+        uint32_t mk = 0;
+        for (int t = 0; t < 4; ++t)
+            if (t < taps.n && ok && (unsigned)((ihp >> 1) - (taps.kh[t] >> 1)) < (unsigned)g.OH &&
+                (unsigned)((iwp >> 1) - (taps.kw[t] >> 1)) < (unsigned)g.OW) mk |= 1u << t;
+        s.mask[i] = mk;
+    }
+    template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(const BState& s, int i, int k0) const {
+        return ((s.mask[i] >> (k0 >> g.logKO)) & 1u) ? s.off[i] : VTX_OOB;
+    }
+    template <int BK> __device__ __forceinline__ uint32_t soff(int k0) const {
+        const int t = k0 >> g.logKO, co0 = k0 & (g.KO - 1);
+        const int tt = t < 4 ? t : 3;
+        const int tapoff = (taps.kh[tt] >> 1) * g.OW + (taps.kw[tt] >> 1);
+        return (uint32_t)((((g.OW + 1) - tapoff) * g.KO + co0) * (int)sizeof(T));
+    }
 };
 // B operand of the above: rows = input channels of wt[C][R][S][KO], k = (tap index, co)
 template <class T, int SL> struct TapKC {
@@ -189,6 +357,20 @@ template <class T, int SL> struct TapKC {
         const int t = k >> logKO, co = k & ((1 << logKO) - 1);
         const int tt = t < 4 ? t : 3;
         return s.rp[i] + ((long)(taps.kh[tt] * S + taps.kw[tt]) << logKO) + co;
+    }
+    // ---- buffer interface
+    static constexpr bool TAILS = false;
+    struct BState { uint32_t off[SL]; };
+    bool buf_ok(int BK) const { return (1 << logKO) % BK == 0 && K % BK == 0 && (double)rows * (double)ld * sizeof(T) < VTX_BUF_LIMIT; }
+    __device__ __forceinline__ BufView view() const { return {p, (uint32_t)((long)rows * ld * (long)sizeof(T))}; }
+    template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int r, int kc) const {
+        s.off[i] = r < rows ? (uint32_t)(((long)r * ld + kc) * (long)sizeof(T)) : VTX_OOB;
+    }
+    template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(const BState& s, int i, int) const { return s.off[i]; }
+    template <int BK> __device__ __forceinline__ uint32_t soff(int k0) const {
+        const int t = k0 >> logKO, co0 = k0 & ((1 << logKO) - 1);
+        const int tt = t < 4 ? t : 3;
+        return (uint32_t)((((taps.kh[tt] * S + taps.kw[tt]) << logKO) + co0) * (int)sizeof(T));
     }
 };
 
@@ -211,6 +393,47 @@ template <class T, int SL> struct ConvWgradB {
         const bool ok = s.ci[i] >= 0 && pix < K && (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
         return ok ? x + (((long)n * g.H + ih) * g.W + iw) * g.C + s.ci[i] : nullptr;
     }
+    // ---- buffer interface.  A slot stages 8 consecutive rows (one tap, 8 channels -- or two pixels of the packed
+    // stem) at ONE output pixel, and its pixel advances by exactly BK per K step, so the slot carries (oh, ow) and the
+    // byte offset `pos` of its input element as counters: adding BK = (dn, doh, dow) in the mixed radix (N, OH, OW)
+    // needs one conditional subtraction per digit (dow < OW, doh < OH), each carry moves `pos` by a constant.  No
+    // division, no 64-bit arithmetic in the K loop.  dhw packs the lane's tap displacement (kh - pad, kw - pad).
+    static constexpr bool TAILS = true;
+    struct BState { int oh[SL < 2 ? 2 : SL], ow[SL < 2 ? 2 : SL]; uint32_t pos[SL < 2 ? 2 : SL]; int dh[SL < 2 ? 2 : SL], dw[SL < 2 ? 2 : SL]; };
+    bool buf_ok(int) const { return (double)g.N * g.H * g.W * g.C * sizeof(T) < VTX_BUF_LIMIT; }
+    __device__ __forceinline__ BufView view() const { return {x, (uint32_t)((long)g.N * g.H * g.W * g.C * (long)sizeof(T))}; }
+    template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int r0, int kl, int k_first) const {
+        const int tap = r0 >> g.logC, ci = r0 & (g.C - 1);
+        const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
+        const int pix = k_first + kl;                                    // this slot's first output pixel
+        const int ohow = g.OH * g.OW;
+        const int n = pix / ohow, rem = pix - n * ohow;
+        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        s.oh[i] = oh; s.ow[i] = ow;
+        s.dh[i] = r0 < rows ? kh - g.pad : (1 << 28);                    // invalid row chunk: never inside the image
+        s.dw[i] = kw - g.pad;
+        const long e = (((long)n * g.H + oh * g.stride + kh - g.pad) * g.W + ow * g.stride + kw - g.pad) * g.C + ci;
+        s.pos[i] = (uint32_t)(e * (long)sizeof(T));                      // meaningful only where the lane is valid
+    }
+    template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(BState& s, int i, int k0, int kl) const {
+        const int ih = (s.oh[i] << g.logStride) + s.dh[i], iw = (s.ow[i] << g.logStride) + s.dw[i];
+        bool ok = (unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W;
+        if constexpr (!FULL) ok = ok && k0 + kl < K;
+        const uint32_t r = ok ? s.pos[i] : VTX_OOB;
+        // advance by BK output pixels (all step constants are wave-uniform)
+        const int dn = BK / (g.OH * g.OW), r1 = BK - dn * g.OH * g.OW, doh = r1 / g.OW, dow = r1 - doh * g.OW;
+        const int esz = g.C * (int)sizeof(T);
+        const int step = ((dn * g.H + doh * g.stride) * g.W + dow * g.stride) * esz;
+        const int c1 = (g.stride * g.W - g.OW * g.stride) * esz;        // ow wrapped: next output row
+        const int c2 = (g.H - g.OH * g.stride) * g.W * esz;             // oh wrapped: next image
+        int ow = s.ow[i] + dow, oh = s.oh[i] + doh;
+        uint32_t pos = s.pos[i] + (uint32_t)step;
+        if (ow >= g.OW) { ow -= g.OW; oh += 1; pos += (uint32_t)c1; }
+        if (oh >= g.OH) { oh -= g.OH; pos += (uint32_t)c2; }
+        s.ow[i] = ow; s.oh[i] = oh; s.pos[i] = pos;
+        return r;
+    }
+    template <int BK> __device__ __forceinline__ uint32_t soff(int) const { return 0u; }
 };
 
 // ------------------------------------------------------------------ epilogues
@@ -333,6 +556,9 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     // Row scatter for the parity-decomposed stride-2 input gradient: GEMM row m = (n, ih2, iw2) is output
     // pixel (n, 2*ih2+map_pa, 2*iw2+map_pb) of an H x W image.  map_on = 0: identity.
     int map_on = 0, map_H = 0, map_W = 0, map_pa = 0, map_pb = 0;
+    // Non-temporal output stores (A/B switch VIRTEX_AMD_NT_STORE_MB: outputs of at least that many MB bypass the
+    // caches on their way out -- they are larger than the 256 MB Infinity Cache, so nothing downstream could hit them).
+    int nt = 0;
     __device__ __forceinline__ long out_row(int m) const {
         if (!map_on) return m;
         const int h2 = map_H >> 1, w2 = map_W >> 1;
@@ -385,8 +611,10 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         if (act == ACT_RES_RELU) w = relu16<T>(w);
         // (non-temporal stores measured: -17 % on the write-bound 64->256 1x1 convolution alone, nothing on the
         //  step -- the BatchNorm statistics pass that follows loses its Infinity-Cache hits)
-        if (full) *reinterpret_cast<uint4*>(out + o) = w;
-        else *reinterpret_cast<uint2*>(out + o) = make_uint2(w.x, w.y);   // bf16: 4 elements
+        if (full) {
+            if (nt) st16_nt(out + o, u32x4_t{w.x, w.y, w.z, w.w});
+            else *reinterpret_cast<uint4*>(out + o) = w;
+        } else *reinterpret_cast<uint2*>(out + o) = make_uint2(w.x, w.y);   // bf16: 4 elements
     }
     // The same, accumulating the statistics of this chunk.  par = this chunk's columns inside the block's LDS parameter
     // table ([4][PBN] floats: FWD {shift}; BWD {rstd, -mean*rstd, gamma, beta}); s1/s2 = the lane's accumulators.
@@ -426,7 +654,8 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
             }
             w = pack16<T>(f);
         }
-        *reinterpret_cast<uint4*>(out + mr * ldc + n) = w;
+        if (nt) st16_nt(out + mr * ldc + n, u32x4_t{w.x, w.y, w.z, w.w});
+        else *reinterpret_cast<uint4*>(out + mr * ldc + n) = w;
     }
     __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
         if (m >= M || n >= N) return;
@@ -723,7 +952,6 @@ __global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP 
 //    on the source side; fragments = 2 x ds_read_b64_tr_b16 (the gfx950 LDS transpose read: within a
 //    16-lane group lane i receives element (i%4) of the 8 bytes addressed by lane 4j + i/4, j = 0..3),
 //    so the weight-gradient GEMMs need no transposition work at all.
-static __device__ const uint32_t vtx_zero_page[4] = {0u, 0u, 0u, 0u};
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 
 template <int ROWS> __device__ __forceinline__ int swz_mc(int chunk, int k) {
@@ -744,34 +972,45 @@ template <int ROWS, int NW, class L, int BK = 32> struct DmaStager {
     static constexpr int CH = ROWS / 8;         // 16-byte row chunks per k (MC image)
     static constexpr int KPI = 64 / CH > 0 ? 64 / CH : 1;   // k rows per wave-instruction (MC image)
     static_assert(NI >= 1, "tile too small for this many waves");
-    typename L::State st;
+    typename L::BState st;
     int kl[NI];                                 // MC: local k of each slot
+    __amdgpu_buffer_rsrc_t rsrc;                // the operand's buffer descriptor (4 SGPRs)
 
-    __device__ __forceinline__ void init(const L& l, int row0, int wave, int lane) {
+    // k_first = first k of this block's K range (split-K slices start in the middle)
+    __device__ __forceinline__ void init(const L& l, int row0, int wave, int lane, int k_first) {
+        const BufView v = l.view();
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(v.base), (short)0, (int)v.bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int q = wave + NW * i;        // which 1 KiB piece of the tile image
             if constexpr (!MC) {
                 const int row = RPI * q + lane / SLOTS;
                 const int phys = lane % SLOTS;
-                l.init_slot(st, i, row0 + row, 8 * (BK == 32 ? swz_slot(phys, row) : swz_slot64(phys, row)));
+                kl[i] = 0;
+                l.template binit<BK>(st, i, row0 + row, 8 * (BK == 32 ? swz_slot(phys, row) : swz_slot64(phys, row)));
             } else if constexpr (CH <= 64) {
                 kl[i] = q * KPI + lane / CH;
-                l.init_slot(st, i, row0 + 8 * swz_mc<ROWS>(lane % CH, kl[i]));
+                l.template binit<BK>(st, i, row0 + 8 * swz_mc<ROWS>(lane % CH, kl[i]), kl[i], k_first);
             }
         }
     }
-    __device__ __forceinline__ void issue(const L& l, int k0, bf16_t* tile, int wave) const {
+    template <bool FULL> __device__ __forceinline__ void issue_t(const L& l, int k0, bf16_t* tile, int wave) {
+        const uint32_t so = l.template soff<BK>(k0);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const bf16_t* src;
-            if constexpr (!MC) src = l.ptr(st, i, k0);
-            else src = l.ptr(st, i, k0 + kl[i]);
-            if (!src) src = reinterpret_cast<const bf16_t*>(vtx_zero_page);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + (wave + NW * i) * 512),
-                                             16, 0, 0);
+            uint32_t vo;
+            if constexpr (!MC) vo = l.template voff<FULL, BK>(st, i, k0);
+            else vo = l.template voff<FULL, BK>(st, i, k0, kl[i]);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave + NW * i) * 512),
+                                                     16, (int)vo, (int)so, 0, 0);
         }
+    }
+    // Tiles are issued in increasing k0, each exactly once (position-tracking loaders rely on it).
+    __device__ __forceinline__ void issue(const L& l, int k0, bf16_t* tile, int wave) {
+        if constexpr (L::TAILS) {
+            if (k0 + BK <= l.K) issue_t<true>(l, k0, tile, wave);        // wave-uniform branch
+            else issue_t<false>(l, k0, tile, wave);
+        } else issue_t<true>(l, k0, tile, wave);
     }
     // fragment of rows r0..r0+15 for the 32-deep MFMA step `h` of the staged tile (h = 0 when BK = 32)
     __device__ static __forceinline__ bf16x8_t frag(const bf16_t* tile, int r0, int lane, int h = 0) {
@@ -823,8 +1062,8 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
 
     SA sa;
     SB sb;
-    sa.init(al, m0, wave, lane);
-    sb.init(bl, n0, wave, lane);
+    sa.init(al, m0, wave, lane, kt0 * BK);
+    sb.init(bl, n0, wave, lane, kt0 * BK);
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -832,6 +1071,9 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+#ifndef VTX_ABLATE          // measurement builds (tools/ablate_gemm.py) compile the ablation switches in
+    abl = 0;
+#endif
     // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8]); only vmcnt waits
     constexpr int INFLIGHT = NDMA * (STAGES - 2);       // DMA instructions that may still be pending at a K step
     static_assert(INFLIGHT < 64, "vmcnt is 6 bits");
@@ -980,6 +1222,7 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
 }
 
 extern int g_vtx_contraction_generation;   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
+extern thread_local int g_vtx_last_generation;  // 1 / 2: which kernel generation this thread's last launch_auto picked
 extern thread_local int g_vtx_last_colgroups;   // column groups (tiles_n x waves per tile row) of this thread's last launch: EpiRowLse partials
 extern int g_vtx_ablate;   // measurement only: bit0 no MFMA, bit1 no fragment reads, bit2 no DMA, bit3 no barrier
 
@@ -1015,8 +1258,14 @@ template <class T, int S> inline double epi_bytes(const EpiStore<T, S>& e, doubl
            (e.bn_x ? mn * sizeof(T) : 0.0) + (e.bn_y ? mn * sizeof(T) : 0.0);
 }
 
+// outputs of at least VIRTEX_AMD_NT_STORE_MB megabytes are stored non-temporally (0 / unset: never)
+inline int vtx_nt_policy(double out_bytes) {
+    static const double thr = [] { const char* e = getenv("VIRTEX_AMD_NT_STORE_MB"); return e ? atof(e) * 1e6 : 0.0; }();
+    return thr > 0.0 && out_bytes >= thr ? 1 : 0;
+}
+
 template <int BM, int BN, int WM, int WN, int BK = 32, int STAGES = 3, class AL, class BL, class EP>
-inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
+inline int launch_v2(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K, int split_k, hipStream_t st) {
     const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
     const int nkt = vtx_cdiv(K, BK);
     if (split_k < 1) split_k = 1;
@@ -1032,6 +1281,8 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep, int M, int N, int
     }
     dim3 grid(tiles_m * tiles_n, split_k), block(64 * WM * WN);
     g_vtx_last_colgroups = tiles_n * WN;
+    EP ep = ep_in;
+    if constexpr (EP::STAGED) ep.nt = vtx_nt_policy((double)M * N * sizeof(typename EP::Out));
     bool prof = g_vtx_prof_on != 0;
     if (prof) {
         static const int cls = vtx_prof_register(__PRETTY_FUNCTION__);
@@ -1086,8 +1337,11 @@ inline int pick_tile(int M, int N, int splits, bool allow256) {
 template <class T, template <class, int> class ALT, template <class, int> class BLT, class EP, class FA, class FB>
 inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, int split_k, hipStream_t st) {
     constexpr bool BF = sizeof(T) == 2;
-    const bool v2 = BF && g_vtx_contraction_generation >= 2;
+    // the DMA kernel addresses its operands through buffer descriptors: both must qualify (size, channel multiples)
+    auto buf_ok = [&](int bk) { ALT<T, 1> a; make_a(a); BLT<T, 1> b; make_b(b); return a.buf_ok(bk) && b.buf_ok(bk); };
+    const bool v2 = BF && g_vtx_contraction_generation >= 2 && buf_ok(32);
     const int c = pick_tile(M, N, split_k, v2);
+    g_vtx_last_generation = v2 ? 2 : 1;
 #define VTX_V1(BM_, BN_, SA_, SB_)                                                          \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v1<T, BM_, BN_>(a, b, ep, M, N, K, split_k, st); }
 #define VTX_V2(BM_, BN_, WM_, WN_, SA_, SB_)                                                \
@@ -1103,7 +1357,7 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
         // 7x7 stage), -10...40 % on larger grids where two co-resident 256x128 blocks overlap instead.
         const long t256 = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, 128) * (split_k < 1 ? 1 : split_k);
         const bool small_grid = g_vtx_tile_override < 0 && t256 <= 256 && K >= 256 && N > 64 && M > 128;
-        if (v2 && (small_grid || g_vtx_tile_override >= 10)) {
+        if (v2 && (small_grid || g_vtx_tile_override >= 10) && buf_ok(64)) {
             if (g_vtx_tile_override == 11) VTX_V2X(256, 128, 4, 2, 64, 2, 4, 2)     //  96 KiB LDS: one block per CU
             else if (g_vtx_tile_override == 13) VTX_V2X(256, 256, 2, 4, 32, 4, 2, 2)     // experiments: 128 KiB, 3 stages in flight
             else if (g_vtx_tile_override == 14) VTX_V2X(256, 256, 2, 4, 64, 2, 4, 4)     //              128 KiB, whole-line rows
