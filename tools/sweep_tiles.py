@@ -31,6 +31,8 @@ def sweep(label, fn, M, N):
           " ".join(f"{names[k]}={v*1e6:.0f}" for k, v in res.items() if k != -1) + flag, flush=True)
 
 for (C, KO, k, s, H, cnt) in CONVS:
+    if k == 7:
+        continue                      # the packed stem has one sensible tile (N = 64)
     pad = {1: 0, 3: 1, 7: 3}[k]
     OH = (H + 2 * pad - k) // s + 1
     x = torch.randn(B, H, H, C, device="cuda").to(dt)

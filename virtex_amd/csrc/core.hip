@@ -1,6 +1,7 @@
 // Version / backend / error reporting of the C ABI.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -29,7 +30,7 @@ extern "C" const char* vtx_backend(void) {
 }
 
 // Runtime switch used for A/B measurements of the two contraction-kernel generations.
-namespace vtxg { int g_vtx_contraction_generation = 2; int g_vtx_ablate = 0; int g_vtx_tile_override = -1; thread_local int g_vtx_last_colgroups = 0; thread_local int g_vtx_last_generation = 0; }
+namespace vtxg { int g_vtx_contraction_generation = 2; int g_vtx_ablate = getenv("VIRTEX_AMD_KFLAGS") ? atoi(getenv("VIRTEX_AMD_KFLAGS")) : 0;   /* 16: tile-major split-K block order (A/B) */ int g_vtx_tile_override = -1; thread_local int g_vtx_last_colgroups = 0; thread_local int g_vtx_last_generation = 0; }
 extern "C" int vtx_last_contraction_generation(void) { return vtxg::g_vtx_last_generation; }
 extern "C" int vtx_set_contraction_generation(int gen) {
     VTX_CHECK(gen == 1 || gen == 2, VTX_ERR_ARG, "contraction generation must be 1 or 2");

@@ -5,6 +5,8 @@
 //   /root/reference/virtex/modules/textual_heads.py:245 (visual_projection), :270-275
 //   (nn.TransformerDecoder: in_proj, out_proj, linear1, linear2), :277 (tied output), and
 //   the 1x1 convolutions of torchvision's Bottleneck (visual_backbones.py:68-74).
+#include <stdlib.h>
+
 #include "gemm_kernel.h"
 
 using namespace vtxg;
@@ -77,8 +79,8 @@ int vtx_check_bn_bwd(const char* who, const VtxBnBwdFusion* f, int M, int N) {
 vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
 
-// Split-K policy for the weight-gradient GEMMs: enough slices to give every CU ~2 blocks, never fewer
-// than 8 K-steps per slice, bounded by the workspace ([slices][M][N] fp32 partial sums).
+// Split-K policy for the weight-gradient GEMMs: enough slices to give every CU ~2 blocks, never fewer than 8 K-steps per slice, bounded by the workspace
+// ([slices][M][N] fp32 partial sums).
 int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
     const long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
     const int nkt = vtx_cdiv(K, bk);

@@ -533,7 +533,8 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     typedef T Out;
     T* out; long ldc; const float* bias; const T* residual; long ldr; T* preact; int act;
     float alpha; Dropout drop; int M, N;
-    long split_stride = 0;   // split-K: slice blockIdx.y writes its partial result at out + blockIdx.y*split_stride
+    long split_stride = 0;   // split-K: slice s writes its partial result at out + s*split_stride ...
+    long split_off = 0;      // ... = this block's s*split_stride, set by the kernel (set_slice)
     // Fused BatchNorm statistics (generation-2 kernel only): stat_parts[strip][2][N], one strip per block row
     // (tile_m) of the grid, summed by the BatchNorm finalize kernels.  N must be a multiple of 16 bytes' worth.
     float* stat_parts = nullptr;
@@ -556,8 +557,7 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     // Row scatter for the parity-decomposed stride-2 input gradient: GEMM row m = (n, ih2, iw2) is output
     // pixel (n, 2*ih2+map_pa, 2*iw2+map_pb) of an H x W image.  map_on = 0: identity.
     int map_on = 0, map_H = 0, map_W = 0, map_pa = 0, map_pb = 0;
-    // Non-temporal output stores (A/B switch VIRTEX_AMD_NT_STORE_MB: outputs of at least that many MB bypass the
-    // caches on their way out -- they are larger than the 256 MB Infinity Cache, so nothing downstream could hit them).
+    // Non-temporal output stores (vtx_nt_policy: outputs of >= 200 MB bypass the caches on their way out).
     int nt = 0;
     __device__ __forceinline__ long out_row(int m) const {
         if (!map_on) return m;
@@ -599,7 +599,7 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         if (m >= M || n >= N) return;
         constexpr int EPV = 16 / (int)sizeof(T);
         const long mr = out_row(m);
-        const long o = mr * ldc + n + (long)blockIdx.y * split_stride;
+        const long o = mr * ldc + n + split_off;
         const bool full = n + EPV <= N;
         if (residual) {
             if (full) w = add16<T>(w, *reinterpret_cast<const uint4*>(residual + mr * ldr + n));
@@ -665,7 +665,7 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
             for (int j = 0; j < 4; ++j) v[j] += bias[n + j];
         }
         const long mr = out_row(m);
-        const long o = mr * ldc + n + (long)blockIdx.y * split_stride;
+        const long o = mr * ldc + n + split_off;
         if (preact) st4<T>(preact + o, v);
         if (act == ACT_GELU) {
 #pragma unroll
@@ -728,6 +728,10 @@ struct EpiRowLse {
     __device__ __forceinline__ void store_wide(int, int, uint4) const {}
     __device__ __forceinline__ void operator()(int, int, f32x4_t) const {}
 };
+
+// the K slice a block works on (split-K): only the storing epilogue cares
+template <class EP> __device__ __forceinline__ void set_slice(EP&, int) {}
+template <class T, int S> __device__ __forceinline__ void set_slice(EpiStore<T, S>& ep, int slice) { ep.split_off = (long)slice * ep.split_stride; }
 
 // mw / nw: first row / column of the wave tile; group: index of this column range (tile_n * waves-per-row + wn)
 template <int MT, int NT, class EP>
@@ -885,6 +889,7 @@ __global__ __launch_bounds__(NTHREADS) void contraction_kernel(AL al, BL bl, EP 
     const int nkt = (K + BK - 1) / BK;
     const int kt0 = blockIdx.y * kt_per_split;
     const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
+    set_slice(ep, (int)blockIdx.y);
 
     Stager<T, BM, AL> sa;
     Stager<T, BN, BL> sb;
@@ -1050,14 +1055,25 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch policy; a speed assumption
     // only).  Give every XCD a contiguous range of tiles so that the tiles sharing an A panel (same
     // tile_m, consecutive tile ids) hit the same private L2 instead of eight different ones.
-    int tile;
-    {
+    // Split-K launches (grid = tiles x slices, dispatched x-fastest): what the blocks of one XCD can share are the
+    // operand panels of ONE K slice (every tile of a slice reads the same rows of k), so the XCD's contiguous range is
+    // taken from the slice-major list of (slice, tile) pairs -- with the tile index alone deciding the XCD, the 8 tiles
+    // of a small weight-gradient GEMM would each re-read their panels through a different L2.
+    int tile, slice = 0;
+    if (gridDim.y == 1 || (abl & 16)) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        slice = blockIdx.y;
+    } else {
+        const int T = gridDim.x, nwg = T * gridDim.y, L = blockIdx.y * T + blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, idx = L >> 3;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        slice = w / T; tile = w - slice * T;
     }
+    set_slice(ep, slice);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nkt = (K + BK - 1) / BK;
-    const int kt0 = blockIdx.y * kt_per_split;
+    const int kt0 = slice * kt_per_split;
     const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
 
     SA sa;
@@ -1072,7 +1088,7 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #ifndef VTX_ABLATE          // measurement builds (tools/ablate_gemm.py) compile the ablation switches in
-    abl = 0;
+    abl = 0;                // (bit 4, the A/B switch of the split-K block order, has been consumed above)
 #endif
     // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8]); only vmcnt waits
     constexpr int INFLIGHT = NDMA * (STAGES - 2);       // DMA instructions that may still be pending at a K step
@@ -1258,9 +1274,11 @@ template <class T, int S> inline double epi_bytes(const EpiStore<T, S>& e, doubl
            (e.bn_x ? mn * sizeof(T) : 0.0) + (e.bn_y ? mn * sizeof(T) : 0.0);
 }
 
-// outputs of at least VIRTEX_AMD_NT_STORE_MB megabytes are stored non-temporally (0 / unset: never)
+// Outputs of at least VIRTEX_AMD_NT_STORE_MB megabytes (default 200; 0 = never) are stored non-temporally: they do not
+// fit the 256 MB Infinity Cache next to their own inputs, so caching them only evicts what the next kernel could hit.
+// A/B in one session: 31.37 -> 31.17 ms/step (profiles/r02_ab_buffer_addressing.txt).
 inline int vtx_nt_policy(double out_bytes) {
-    static const double thr = [] { const char* e = getenv("VIRTEX_AMD_NT_STORE_MB"); return e ? atof(e) * 1e6 : 0.0; }();
+    static const double thr = [] { const char* e = getenv("VIRTEX_AMD_NT_STORE_MB"); return e ? atof(e) * 1e6 : 200e6; }();
     return thr > 0.0 && out_bytes >= thr ? 1 : 0;
 }
 
