@@ -365,7 +365,7 @@ def test_small_helpers(backend, dtype):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5, 11, 12])
+@pytest.mark.parametrize("cand", [0, 1, 2, 3, 4, 5, 6, 11, 12])
 def test_contraction_tile_variants_bf16(backend, cand):
     """Every block-tile configuration of the generation-2 bf16 kernel (256x256 ... 64x64; 11, 12: the 64-deep
     K-step variants for row-major operands), on all loader kinds: row-major, k-major (transpose-read) and the
@@ -662,7 +662,7 @@ def _bn_bwd_reference(z, x, mean, rstd, gamma, beta, ymask, mode):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("mode", ["ymask", "remask", "none"])
-@pytest.mark.parametrize("cand", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cand", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_batchnorm_backward_fused_in_gemm_epilogue(backend, mode, cand):
     """bf16: the input-gradient GEMM's epilogue masks its output with the ReLU of the BatchNorm that fed the
     convolution and emits sum dz / sum dz*xhat; vtx_bn_bwd_fused turns them into dx, dgamma, dbeta.  Against a torch

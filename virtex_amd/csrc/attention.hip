@@ -192,8 +192,8 @@ constexpr int VROW = D + 8;                // LDS row pitch (elements): 144 B, k
 
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st4_bf16(bf16_t* p, f32x4_t v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
-                                              (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+    *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]),
+                                              f2bf2(v[2], v[3]));
 }
 __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* base, long ld, int row, int nrows, int col) {
     // 8 consecutive bf16 of row `row` (zeros past the end of the tile)

@@ -445,8 +445,8 @@ template <> __device__ __forceinline__ void st4<float>(float* p, const float* v)
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float* v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
-                                              (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+    *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]),
+                                              f2bf2(v[2], v[3]));
 }
 template <class T> __device__ __forceinline__ void ld4(const T* p, float* v);
 template <> __device__ __forceinline__ void ld4<float>(const float* p, float* v) {
@@ -463,13 +463,13 @@ template <> __device__ __forceinline__ void st4v<float>(float* p, f32x4_t v) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 template <> __device__ __forceinline__ void st4v<bf16_t>(bf16_t* p, f32x4_t v) {
-    *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
-                                              (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+    *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]),
+                                              f2bf2(v[2], v[3]));
 }
 __device__ __forceinline__ uint32_t bf2_add(uint32_t a, uint32_t b) {   // two packed bf16 + two packed bf16
     const float lo = __uint_as_float(a << 16) + __uint_as_float(b << 16);
     const float hi = __uint_as_float(a & 0xffff0000u) + __uint_as_float(b & 0xffff0000u);
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    return f2bf2(lo, hi);
 }
 template <class T> __device__ __forceinline__ uint4 add16(uint4 a, uint4 b);
 template <> __device__ __forceinline__ uint4 add16<bf16_t>(uint4 a, uint4 b) {
@@ -518,8 +518,8 @@ template <> __device__ __forceinline__ void unpack16<float>(uint4 w, float* f) {
 }
 template <class T> __device__ __forceinline__ uint4 pack16(const float* f);
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* f) {
-    return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
-                      (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+    return make_uint4(f2bf2(f[0], f[1]), f2bf2(f[2], f[3]),
+                      f2bf2(f[4], f[5]), f2bf2(f[6], f[7]));
 }
 template <> __device__ __forceinline__ uint4 pack16<float>(const float* f) {
     return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
@@ -1358,7 +1358,16 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
     // the DMA kernel addresses its operands through buffer descriptors: both must qualify (size, channel multiples)
     auto buf_ok = [&](int bk) { ALT<T, 1> a; make_a(a); BLT<T, 1> b; make_b(b); return a.buf_ok(bk) && b.buf_ok(bk); };
     const bool v2 = BF && g_vtx_contraction_generation >= 2 && buf_ok(32);
-    const int c = pick_tile(M, N, split_k, v2);
+    int c = pick_tile(M, N, split_k, v2);
+    if constexpr (EP::STATS) {
+        // The HBM-bound convolutions of stages 1-2 with a BatchNorm epilogue (K = 64...512: a handful of K steps, then
+        // an epilogue that reads up to three more [M][N] tensors) are chains of memory latencies, not MFMA work: on
+        // 128x128 tiles with EIGHT waves (wave tile 32x64) the epilogue chain is half as long and three blocks fit a
+        // CU.  Measured per layer at bs=256 (tools/bench_1x1.py: tensors of 0.25-2.2 GB, not cache-fed): input gradient
+        // + fused BatchNorm backward 320 -> 275 us (64->256 @56), 157 -> 146 (128->512 @28); 14x14 layers lose 10 %.
+        static const bool stats_tile = [] { const char* e = getenv("VIRTEX_AMD_STATS_TILE"); return !e || atoi(e) != 0; }();
+        if (stats_tile && v2 && c == 1 && g_vtx_tile_override < 0 && M >= 100000) c = 6;
+    }
     g_vtx_last_generation = v2 ? 2 : 1;
 #define VTX_V1(BM_, BN_, SA_, SB_)                                                          \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v1<T, BM_, BN_>(a, b, ep, M, N, K, split_k, st); }
@@ -1392,6 +1401,7 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
                 case 2: VTX_V2(128, 128, 2, 2, 2, 2) break;
                 case 3: VTX_V2(128, 64, 2, 2, 2, 1) break;
                 case 4: VTX_V2(64, 128, 2, 2, 1, 2) break;
+                case 6: VTX_V2(128, 128, 4, 2, 1, 1) break;     // 8 waves on 128x128: wave tile 32x64 (short epilogue chains)
                 default: VTX_V2(64, 64, 2, 2, 1, 1) break;
             }
             return EP::STATS ? strips : 0;

@@ -64,12 +64,26 @@ typedef short bf16x8_t __attribute__((ext_vector_type(8)));   // one 16x16x32 MF
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// fp32 -> bf16, round to nearest even.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32: two values per
+// instruction where the integer sequence below costs six each) -- every bf16-writing epilogue and the BatchNorm /
+// LayerNorm apply passes go through these two functions.  The CPU emulator build keeps the integer form (same
+// rounding; NaNs are quieted by both).
+#ifdef HIPEMU
 __device__ __forceinline__ bf16_t f2bf(float f) {
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+#else
+typedef __bf16 vtx_bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float vtx_f32x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((vtx_f32x2_hw){lo, hi}, vtx_bf16x2_hw));
+}
+#endif
 
 template <class T> struct Elem;
 template <> struct Elem<float> {
@@ -132,13 +146,13 @@ template <> struct Vec16<bf16_t> {
     __device__ __forceinline__ void store(bf16_t* p) const {
         uint32_t w[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = f2bf2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
     __device__ __forceinline__ void store_nt(bf16_t* p) const {
         u32x4_t w;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+        for (int i = 0; i < 4; ++i) w[i] = f2bf2(v[2 * i], v[2 * i + 1]);
         st16_nt(p, w);
     }
 };
