@@ -10,6 +10,8 @@
 // Replaces aten::batch_norm / relu_ / add_ (+ their backward) of torchvision's Bottleneck,
 // reached from /root/reference/virtex/modules/visual_backbones.py:68-74 (eps 1e-5,
 // momentum 0.1, unbiased running variance).
+#include <stdlib.h>
+
 #include "vtx_common.h"
 
 namespace {
@@ -175,7 +177,12 @@ __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __r
     }
 }
 
-template <class T>
+// The three apply kernels below share one thread layout: x is a flat array of 16-byte vectors, thread t of the grid
+// walks vectors t, t + S, t + 2S, ... with S = gridDim.x * 256.  The host makes S a multiple of cv = C / VEC (a power
+// of two), so a thread stays on ONE channel vector for its whole life: the per-channel coefficients are loaded into
+// registers once, and a trip is UNR payload loads, ~2 VALU per element, UNR stores -- the first version reloaded every
+// coefficient table for every vector (six to ten cached loads per 16 bytes of payload) behind a 64-bit modulo.
+template <class T, int UNR>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ residual,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ scale,
@@ -183,21 +190,34 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        long nvec, int C, int relu) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-        const int c0 = (int)(i % cv) * VEC;
-        Vec16<T> v; v.load(x + i * VEC);
+    const long t0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    const int c0 = (int)(t0 & (long)(cv - 1)) * VEC;
+    float mu[VEC], sc[VEC], be[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v.v[j] = (v.v[j] - mean[c0 + j]) * scale[c0 + j] + beta[c0 + j];  // centred first: no cancellation
-        if (residual) {
-            Vec16<T> r; r.load(residual + i * VEC);
+    for (int j = 0; j < VEC; ++j) { mu[j] = mean[c0 + j]; sc[j] = scale[c0 + j]; be[j] = beta[c0 + j]; }
+    for (long i0 = t0; i0 < nvec; i0 += UNR * stride) {
+        Vec16<T> v[UNR], r[UNR];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) v.v[j] += r.v[j];
+        for (int u = 0; u < UNR; ++u) {
+            const long i = i0 + u * stride;
+            if (i < nvec) { v[u].load(x + i * VEC); if (residual) r[u].load(residual + i * VEC); }
         }
-        if (relu) {
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) v.v[j] = fmaxf(v.v[j], 0.f);
+        for (int u = 0; u < UNR; ++u) {
+            const long i = i0 + u * stride;
+            if (i >= nvec) break;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[u].v[j] = (v[u].v[j] - mu[j]) * sc[j] + be[j];  // centred first: no cancellation
+            if (residual) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[u].v[j] += r[u].v[j];
+            }
+            if (relu) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[u].v[j] = fmaxf(v[u].v[j], 0.f);
+            }
+            v[u].store(y + i * VEC);
         }
-        v.store(y + i * VEC);
     }
 }
 
@@ -225,28 +245,30 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     long nvec, int C) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-        const int c0 = (int)(i % cv) * VEC;
+    const long t0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    const int c0 = (int)(t0 & (long)(cv - 1)) * VEC;
+    float mu[VEC], rs[VEC], k0[VEC], k1[VEC], k2[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        mu[j] = mean[c0 + j]; rs[j] = rstd[c0 + j];
+        k0[j] = coef[c0 + j]; k1[j] = coef[C + c0 + j]; k2[j] = coef[2 * C + c0 + j];
+        ga[j] = beta ? gamma[c0 + j] : 0.f; be[j] = beta ? beta[c0 + j] : 0.f;
+    }
+    for (long i = t0; i < nvec; i += stride) {
         Vec16<T> xv, g; xv.load(x + i * VEC); g.load(dy + i * VEC);
         if (ymask) {
             Vec16<T> m; m.load(ymask + i * VEC);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) g.v[j] = m.v[j] > 0.f ? g.v[j] : 0.f;
         }
-        if (beta) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float xh = (xv.v[j] - mean[c0 + j]) * rstd[c0 + j];
-                g.v[j] = xh * gamma[c0 + j] + beta[c0 + j] > 0.f ? g.v[j] : 0.f;
-            }
-        }
-        if (dz_out) g.store(dz_out + i * VEC);
         Vec16<T> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float xh = (xv.v[j] - mean[c0 + j]) * rstd[c0 + j];
-            o.v[j] = coef[c0 + j] * (g.v[j] - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
+            const float xh = (xv.v[j] - mu[j]) * rs[j];
+            if (beta) g.v[j] = xh * ga[j] + be[j] > 0.f ? g.v[j] : 0.f;
+            o.v[j] = k0[j] * (g.v[j] - k1[j] - xh * k2[j]);
         }
+        if (dz_out) g.store(dz_out + i * VEC);
         o.store(dx + i * VEC);
     }
 }
@@ -260,8 +282,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __rest
                                                                  const float* __restrict__ coef, T* __restrict__ dx, long nvec, int C) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
-    const long stride = (long)gridDim.x * 256;
-    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < nvec; i0 += UNR * stride) {
+    const long t0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    const int c0 = (int)(t0 & (long)(cv - 1)) * VEC;
+    // dx = k0*(dz - k1 - xhat*k2), xhat = (x - mu)*rs  ==  k0*dz - (x - mu)*(k0*k2*rs) - k0*k1
+    float mu[VEC], a0[VEC], a1[VEC], a2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float k0 = coef[c0 + j], k1 = coef[C + c0 + j], k2 = coef[2 * C + c0 + j];
+        mu[j] = mean[c0 + j]; a0[j] = k0; a1[j] = k0 * k2 * rstd[c0 + j]; a2[j] = k0 * k1;
+    }
+    for (long i0 = t0; i0 < nvec; i0 += UNR * stride) {
         Vec16<T> xv[UNR], g[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -272,13 +302,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __rest
         for (int u = 0; u < UNR; ++u) {
             const long i = i0 + u * stride;
             if (i >= nvec) break;
-            const int c0 = (int)(i % cv) * VEC;
             Vec16<T> o;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float xh = (xv[u].v[j] - mean[c0 + j]) * rstd[c0 + j];
-                o.v[j] = coef[c0 + j] * (g[u].v[j] - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
-            }
+            for (int j = 0; j < VEC; ++j) o.v[j] = a0[j] * g[u].v[j] - (xv[u].v[j] - mu[j]) * a1[j] - a2[j];
             o.store(dx + i * VEC);
         }
     }
@@ -382,7 +408,8 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(
     }
 }
 
-int g_bn_apply_unroll = 0;      // vectors in flight per thread of the fused backward apply kernel: 0 = by size, or 1, 2, 4
+// vectors in flight per thread of the apply kernels: 0 = by size, or 1, 2, 4 (A/B switch VIRTEX_AMD_BN_UNROLL)
+int g_bn_apply_unroll = getenv("VIRTEX_AMD_BN_UNROLL") ? atoi(getenv("VIRTEX_AMD_BN_UNROLL")) : 0;
 constexpr int VTX_BN_MAX_PARTS = 512;
 struct ReducePlan { int TX, gy, gx, rows; };
 static ReducePlan plan_reduce(int P, int C, int vec) {
@@ -399,9 +426,13 @@ static ReducePlan plan_reduce(int P, int C, int vec) {
     r.gx = vtx_cdiv(P, r.rows);
     return r;
 }
-static int apply_grid(long nvec) {
+// grid of the flat apply kernels: at most 4096 blocks, and gridDim.x * 256 a multiple of cv (see bn_apply_kernel)
+static int apply_grid(long nvec, int cv = 1) {
     long g = (nvec + 255) / 256;
-    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+    g = g > 4096 ? 4096 : (g < 1 ? 1 : g);
+    const long q = cv > 256 ? cv / 256 : 1;
+    g = (g + q - 1) / q * q;
+    return (int)g;
 }
 static bool bn_shape_ok(int C, int vec) { return C > 0 && C % vec == 0 && ((C / vec) & (C / vec - 1)) == 0; }
 
@@ -447,11 +478,16 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     else
         VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
-    if (dtype == VTX_BF16)
-        VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
-    else
-        VTX_KLAUNCH("bn_fwd_apply", 0, 4.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+    const int fwd_unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (6L << 20) ? 2 : 1);
+    if (dtype == VTX_BF16) {
+        if (fwd_unr >= 2)
+            VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t, 2>), dim3(apply_grid(vtx_cdiv(nvec, 2), C / vec)), dim3(256), 0, st, (const bf16_t*)x,
+                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
+        else
+            VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const bf16_t*)x,
+                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
+    } else
+        VTX_KLAUNCH("bn_fwd_apply", 0, 4.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<float, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const float*)x,
                            (const float*)residual, save_mean, scale, beta, (float*)y, nvec, C, relu);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
@@ -480,11 +516,11 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, rp.gx);
     if (dtype == VTX_BF16)
-        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * P * C * (3 + (ymask ? 1 : 0) + (dz_out ? 1 : 0)), (bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * P * C * (3 + (ymask ? 1 : 0) + (dz_out ? 1 : 0)), (bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, coef, gamma, relu_beta, (bf16_t*)dx,
                            (bf16_t*)dz_out, nvec, C);
     else
-        VTX_KLAUNCH("bn_bwd_apply", 0, 4.0 * P * C * (3 + (ymask ? 1 : 0) + (dz_out ? 1 : 0)), (bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+        VTX_KLAUNCH("bn_bwd_apply", 0, 4.0 * P * C * (3 + (ymask ? 1 : 0) + (dz_out ? 1 : 0)), (bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const float*)x,
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, coef, gamma, relu_beta, (float*)dx,
                            (float*)dz_out, nvec, C);
     VTX_LAUNCH_CHECK();
@@ -516,7 +552,7 @@ extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const 
     // measured (tools/bench_bn_apply.py, profiles/r02_bn_apply_unroll.txt): two vectors in flight +5 % on the >= 50 MB
     // tensors of stages 1-2, -10 % on the small ones; four are slower everywhere
     const int unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (6L << 20) ? 2 : 1);
-    const int grid = apply_grid(vtx_cdiv(nvec, unr));
+    const int grid = apply_grid(vtx_cdiv(nvec, unr), C / vec);
 #define VTX_BWD_APPLY(T, U, BYTES)                                                                                              \
     VTX_KLAUNCH("bn_bwd_apply", 0, BYTES, (bn_bwd_apply_fused_kernel<T, U>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dz, \
                 save_mean, save_rstd, coef, (T*)dx, nvec, C)
