@@ -228,6 +228,7 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
     do { hipEventRecord((e0), (stream)); hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); }); \
          hipEventRecord((e1), (stream)); } while (0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))

@@ -74,6 +74,10 @@ struct BufView { const void* base; uint32_t bytes; };
 constexpr uint32_t VTX_OOB = 0x80000000u;          // voffset of a lane that must read zeros (>= every accepted size)
 constexpr double VTX_BUF_LIMIT = 2.0e9;            // bytes
 
+// q = n / d for 0 <= n < 2^24 through the hardware reciprocal (one v_rcp_f32 + the correction step of fdiv): the block
+// prologues and the scattering epilogue decompose a few row indices each; a generic 32-bit division is ~25 instructions
+__device__ __forceinline__ int qdiv(int n, int d) { return fdiv(n, d, __builtin_amdgcn_rcpf((float)d)); }
+
 // ------------------------------------------------------------------ plain matrix loaders
 // rows x K view, k contiguous: element (r,k) at p[r*ld + k]
 template <class T, int SL> struct PlainKC {
@@ -186,17 +190,16 @@ template <class T, int SL> struct ConvFwdA {
     template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int m, int kc) const {
         const bool ok = m < rows;
         const int mm = ok ? m : 0;
-        const int n = mm / (g.OH * g.OW), rem = mm - n * g.OH * g.OW;
-        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        const int n = qdiv(mm, g.OH * g.OW), rem = mm - n * g.OH * g.OW;
+        const int oh = qdiv(rem, g.OW), ow = rem - oh * g.OW;
         const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
         const long pix = ((long)n * g.H + ih0) * g.W + iw0;             // >= -(pad*W + pad)
         s.off[i] = (uint32_t)(((pix + (long)g.pad * g.W + g.pad) * g.C + kc) * (long)sizeof(T));
         uint32_t mk = 0;
         if (g.C >= BK) {
-            for (int t = 0; t < g.R * g.S; ++t) {
-                const int kh = t / g.S, kw = t - kh * g.S;
-                if (ok && (unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W) mk |= 1u << t;
-            }
+            for (int kh = 0, t = 0; kh < g.R; ++kh)
+                for (int kw = 0; kw < g.S; ++kw, ++t)
+                    if (ok && (unsigned)(ih0 + kh) < (unsigned)g.H && (unsigned)(iw0 + kw) < (unsigned)g.W) mk |= 1u << t;
         } else mk = 1u;                                                  // row mode: rows past M re-read pixel 0 (their results are discarded)
         s.mask[i] = mk;
     }
@@ -257,15 +260,14 @@ template <class T, int SL> struct ConvDgradA {
     template <int BK> __device__ __forceinline__ void binit(BState& s, int i, int m, int kc) const {
         const bool ok = m < rows;
         const int mm = ok ? m : 0;
-        const int n = mm / (g.H * g.W), rem = mm - n * g.H * g.W;
-        const int ih = rem / g.W, iw = rem - ih * g.W;
+        const int n = qdiv(mm, g.H * g.W), rem = mm - n * g.H * g.W;
+        const int ih = qdiv(rem, g.W), iw = rem - ih * g.W;
         const long P = ((long)n * g.OH + ih + g.pad) * g.OW + iw + g.pad;
         s.off[i] = (uint32_t)((P * g.KO + kc) * (long)sizeof(T));
         uint32_t mk = 0;
-        for (int t = 0; t < g.R * g.S; ++t) {
-            const int kh = t / g.S, kw = t - kh * g.S;
-            if (ok && (unsigned)(ih + g.pad - kh) < (unsigned)g.OH && (unsigned)(iw + g.pad - kw) < (unsigned)g.OW) mk |= 1u << t;
-        }
+        for (int kh = 0, t = 0; kh < g.R; ++kh)
+            for (int kw = 0; kw < g.S; ++kw, ++t)
+                if (ok && (unsigned)(ih + g.pad - kh) < (unsigned)g.OH && (unsigned)(iw + g.pad - kw) < (unsigned)g.OW) mk |= 1u << t;
         s.mask[i] = mk;
     }
     template <bool FULL, int BK> __device__ __forceinline__ uint32_t voff(const BState& s, int i, int k0) const {
@@ -321,8 +323,8 @@ template <class T, int SL> struct ConvDgradS2A {
         const bool ok = m < rows;
         const int mm = ok ? m : 0;
         const int h2 = g.H >> 1, w2 = g.W >> 1;
-        const int n = mm / (h2 * w2), rem = mm - n * h2 * w2;
-        const int ih2 = rem / w2, iw2 = rem - ih2 * w2;
+        const int n = qdiv(mm, h2 * w2), rem = mm - n * h2 * w2;
+        const int ih2 = qdiv(rem, w2), iw2 = rem - ih2 * w2;
         const int ihp = 2 * ih2 + pa + g.pad, iwp = 2 * iw2 + pb + g.pad;
         const long P = ((long)n * g.OH + (ihp >> 1)) * g.OW + (iwp >> 1);
         s.off[i] = (uint32_t)((P * g.KO + kc) * (long)sizeof(T));
@@ -407,8 +409,8 @@ template <class T, int SL> struct ConvWgradB {
         const int kh = (tap * g.rcpS) >> 16, kw = tap - kh * g.S;
         const int pix = k_first + kl;                                    // this slot's first output pixel
         const int ohow = g.OH * g.OW;
-        const int n = pix / ohow, rem = pix - n * ohow;
-        const int oh = rem / g.OW, ow = rem - oh * g.OW;
+        const int n = qdiv(pix, ohow), rem = pix - n * ohow;
+        const int oh = qdiv(rem, g.OW), ow = rem - oh * g.OW;
         s.oh[i] = oh; s.ow[i] = ow;
         s.dh[i] = r0 < rows ? kh - g.pad : (1 << 28);                    // invalid row chunk: never inside the image
         s.dw[i] = kw - g.pad;
@@ -562,8 +564,8 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     __device__ __forceinline__ long out_row(int m) const {
         if (!map_on) return m;
         const int h2 = map_H >> 1, w2 = map_W >> 1;
-        const int n = m / (h2 * w2), rem = m - n * h2 * w2;
-        const int ih2 = rem / w2, iw2 = rem - ih2 * w2;
+        const int n = qdiv(m, h2 * w2), rem = m - n * h2 * w2;
+        const int ih2 = qdiv(rem, w2), iw2 = rem - ih2 * w2;
         return ((long)n * map_H + 2 * ih2 + map_pa) * map_W + 2 * iw2 + map_pb;
     }
     // per-lane part (4 consecutive n of one m): everything except the residual add and the store
