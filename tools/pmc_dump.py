@@ -12,6 +12,7 @@ for r in rows:
     agg[name][r[ci["counter_name"]] if "counter_name" in ci else r[ci["pmc_name"]]].append(r[ci["value"]] if "value" in ci else r[ci["counter_value"]])
 for k, d in agg.items():
     if filt in k:
-        print(k[:140])
+        cut = k.find(">(")                                              # template arguments in full, no parameter list
+        print(k[:cut + 1] if cut > 0 else k[:200])
         for c, v in sorted(d.items()):
             print(f"   {c:32s} n={len(v):3d} avg={sum(v)/len(v):.4g}")

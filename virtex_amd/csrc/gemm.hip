@@ -84,7 +84,8 @@ void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc,
 int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
     const long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
     const int nkt = vtx_cdiv(K, bk);
-    long s = (512 + tiles - 1) / tiles;
+    static const long target = [] { const char* e = getenv("VIRTEX_AMD_SPLITK_BLOCKS"); return e ? atol(e) : 512L; }();
+    long s = (target + tiles - 1) / tiles;
     if (s > nkt / 8) s = nkt / 8;
     const long cap = ws_floats / ((long)M * N);
     if (s > cap) s = cap;
