@@ -38,7 +38,7 @@ typedef enum {
 int vtx_version(void);
 const char* vtx_backend(void);    /* "hip:gfx950" (product) or "hipemu" (CPU test build) */
 const char* vtx_last_error(void); /* thread-local */
-/* 2 (default): LDS-DMA + transpose-read bf16 contraction kernel; 1: register-staged kernel (A/B tests) */
+/* 2 (default): LDS-DMA (buffer descriptors) + transpose-read bf16 contraction kernel; 1: register-staged kernel (A/B tests) */
 int vtx_set_contraction_generation(int gen);
 int vtx_set_ablation(int bits);        /* measurement only (tools/ablate_gemm.py) */
 int vtx_set_tile_override(int cand);   /* tests: force a block tile; -1 = automatic */

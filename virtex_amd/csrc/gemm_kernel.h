@@ -2,21 +2,22 @@
 //
 //   C[m][n] (+)= epilogue( sum_k A(m,k) * B(n,k) )
 //
-// Block = 256 threads = 4 waves in a 2x2 grid; block tile BM x BN (64|128), wave tile
-// (BM/2)x(BN/2) as (MT x NT) 16x16 MFMA tiles, K advanced in steps of BK = 64 bytes per row.
-// Operand tiles are staged global -> VGPR (16-byte loads, issued one K-step ahead) -> LDS
-// ([row][BK+pad], double buffered, one barrier per K-step) -> MFMA fragments.
-//   bf16: v_mfma_f32_16x16x32_bf16 (fragment = ds_read_b128 of 8 consecutive k)
-//   fp32: v_mfma_f32_16x16x4_f32   (exact fp32; parity mode)
+// Two generations share the tiling, the loaders' index spaces and the epilogues:
+//   * generation 2 (`contraction_v2_kernel`, bf16, the product path): operand tiles go HBM -> LDS by LDS-DMA through
+//     buffer descriptors (no VGPR round trip, hardware zero fill), 3 stages, one barrier per K step; fragments are
+//     ds_read_b128 (k-contiguous images) or 2 x ds_read_b64_tr_b16 (k-major images); blocks of 4 or 8 waves.
+//   * generation 1 (`contraction_kernel`, fp32 parity mode and whatever generation 2 does not take): tiles staged
+//     global -> VGPR (16-byte loads, one K step ahead) -> LDS ([row][BK+pad], double buffered), 4 waves in a 2x2 grid.
+//   bf16: v_mfma_f32_16x16x32_bf16 (fragment = 8 consecutive k)     fp32: v_mfma_f32_16x16x4_f32 (exact; parity mode)
 // The MFMA is issued as D = Btile x Atile so that each lane ends up with 4 CONSECUTIVE n of
 // one m (lane l: m = l&15, n = 4*(l>>4)..+3) -> vector epilogue loads/stores.
 //
-// Operands are described by "loaders" (how a 16-byte chunk of the tile maps to global
-// memory):
+// Operands are described by "loaders" (how a 16-byte chunk of the tile maps to global memory), each with a pointer
+// interface (init_slot / ptr: generation 1) and a buffer interface (view / binit / voff / soff: generation 2):
 //   KC loaders: chunk = VEC consecutive k of one row   (row-major [rows][K] views, im2col-free
 //               NHWC conv gathers for forward and input-gradient)
 //   MC loaders: chunk = VEC consecutive rows at one k  (k-major [K][rows] views: weight
-//               gradients; transposed into the LDS tile on store)
+//               gradients; no transposition work -- the LDS transpose read does it)
 #pragma once
 #include <stdlib.h>
 
