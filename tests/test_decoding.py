@@ -108,6 +108,7 @@ def test_inference_branch_beam_search_through_hip_head_gpu():
 
 def test_missing_decoder_raises_like_the_reference():
     import virtex_amd.factories as vf
+    select("emu")            # the forward up to the missing decoder runs kernels: do not depend on an earlier test's choice
     model = vf.build_bicaptioning_model(textual="transdec_postnorm::L1_H128_A2_F256", vocab_size=500).eval()
     model.visual.forward = lambda image: torch.zeros(image.size(0), 2048, 2, 2)
     with pytest.raises(ValueError, match="Decoder for predicting captions is missing"):
