@@ -143,3 +143,38 @@ def test_tied_vocabulary_projection_7680x10000x1024():
     d = (0.01 * torch.randn(M, N, generator=g)).to(DT)
     dw = ops.gemm_tn_acc(d.to(dev), h.to(dev), torch.zeros(N, K, device=dev))
     assert rel_err(dw.cpu(), d.float().t() @ h.float()) < 1e-3
+
+
+def _generation():
+    from virtex_amd import _lib
+    return _lib.lib().vtx_last_contraction_generation()
+
+
+def test_buffer_addressing_at_the_top_of_its_range_and_the_fallback_beyond_it():
+    """The DMA kernel addresses operands with 32-bit byte offsets (buffer descriptors): an operand just under the 2 GB
+    limit exercises offsets close to 2^31 (where the out-of-range marker 0x80000000 begins), one above the limit must be
+    taken by the register-staged kernel instead of wrapping.  Both against torch on the device, rows sampled at the
+    start, the middle and the very end of the matrix."""
+    dev = select("gpu")
+    K, N = 1024, 64
+    w = (torch.randn(N, K, generator=_g(11)) / 32).to(DT).to(dev)
+    for rows, gen in ((950_000, 2), (1_100_000, 1)):            # 1.95 GB -> DMA kernel; 2.25 GB -> fallback
+        a = torch.empty(rows, K, dtype=DT, device=dev)
+        a.normal_(generator=None)
+        y = ops.gemm_nt(a, w)
+        assert _generation() == gen
+        for lo in (0, rows // 2 - 128, rows - 256):
+            ref = a[lo:lo + 256].float() @ w.float().t()
+            assert rel_err(y[lo:lo + 256].float(), ref) < 5e-3
+        # weight gradient over the same operand (k-major view of `a`, pixel index up to `rows`)
+        dy = torch.randn(rows, N, device=dev).to(DT)
+        dw = torch.zeros(N, K, device=dev)
+        if rows * K * 2 < 2.0e9:
+            ops.gemm_tn_acc(dy, a, dw)
+            assert _generation() == 2
+            ref = torch.zeros(N, K, device=dev)
+            for lo in range(0, rows, 50_000):
+                ref += dy[lo:lo + 50_000].float().t() @ a[lo:lo + 50_000].float()
+            assert rel_err(dw, ref) < 5e-3
+        del a, y, dy, dw
+        torch.cuda.empty_cache()

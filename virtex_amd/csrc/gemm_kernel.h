@@ -1388,10 +1388,9 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
         const long t256 = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, 128) * (split_k < 1 ? 1 : split_k);
         const bool small_grid = g_vtx_tile_override < 0 && t256 <= 256 && K >= 256 && N > 64 && M > 128;
         if (v2 && (small_grid || g_vtx_tile_override >= 10) && buf_ok(64)) {
+            // (256x256 with 4 stages / 64-deep steps and 256x128 with 64-deep x 3 stages were measured and removed:
+            //  profiles/r02_tile_variants_256x256.txt)
             if (g_vtx_tile_override == 11) VTX_V2X(256, 128, 4, 2, 64, 2, 4, 2)     //  96 KiB LDS: one block per CU
-            else if (g_vtx_tile_override == 13) VTX_V2X(256, 256, 2, 4, 32, 4, 2, 2)     // experiments: 128 KiB, 3 stages in flight
-            else if (g_vtx_tile_override == 14) VTX_V2X(256, 256, 2, 4, 64, 2, 4, 4)     //              128 KiB, whole-line rows
-            else if (g_vtx_tile_override == 15) VTX_V2X(256, 128, 4, 2, 64, 3, 4, 2)     //              144 KiB
             else VTX_V2X(128, 128, 2, 2, 64, 2, 4, 4)                               //  64 KiB: two blocks per CU
             return 0;
         }
