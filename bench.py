@@ -76,15 +76,22 @@ def device_batch(B, dev, seed, image_size=224, vocab_size=10000):
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r02_pmc_traffic.txt.  Two
-# kernels are within a percent of each other at the top of the step (the fused-dgrad contraction and bn_bwd_apply), so both
-# are listed; `traffic` is reported for whichever the live measurement finds dominant.
-TRAFFIC_SOURCE = "profiles/r02_pmc_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r02_pmc_traffic_final.txt.
+# The dominant kernel is found by NAME (a family's launch sites merged), then its LARGEST launch site is timed alone: the
+# traffic listed here is that site's kernel.  Candidates for the top of the step are within a few percent of each other, so
+# the likely ones are all listed; `traffic` is reported for whichever the live measurement finds dominant.
+TRAFFIC_SOURCE = "profiles/r02_pmc_traffic_final.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
 TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE)
-    # 28 launches/step: (2 x 202.6e3 + 112.4e3) KiB                 (algorithmic 513.5 MB -> 1.03x)
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 530.0e6,
-    # 53 launches/step over its three kernels: (2 x 105.4e3 + 105.8e3) KiB launch-weighted
-    "bn_bwd_apply": 324.2e6,
+    # largest site = bn_bwd_apply_fused_kernel<bf16, 2>, 21 launches/step: (2 x 167.3e3 + 167.3e3) KiB (algorithmic 513.8 MB -> 1.00x)
+    "bn_bwd_apply": 513.9e6,
+    # largest site = bn_apply_kernel<bf16, 2>, 25 launches/step: (2 x 144.6e3 + 184.6e3) KiB
+    "bn_fwd_apply": 485.2e6,
+    # 35 launches/step (1x1 / text weight gradients): (2 x 63.6e3 + 32.8e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainMC<bf16, 2>, PlainMC<bf16, 1>, EpiStore<float, 0>, 32, 3>": 163.9e6,
+    # 11 launches/step (stage 1-2 input gradients with the fused BatchNorm backward): (2 x 351.6e3 + 207.0e3) KiB
+    "contraction_v2_kernel<128, 128, 4, 2, PlainKC<bf16, 1>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 932.0e6,
+    # 17 launches/step: (2 x 104.5e3 + 53.2e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 268.5e6,
 }
 
 
