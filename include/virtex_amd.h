@@ -46,6 +46,10 @@ int vtx_set_tile_override(int cand);   /* tests: force a block tile; -1 = automa
  * buffer descriptors: needs bf16, operands < 2 GB, convolution channel counts that are multiples of the 32-deep K step),
  * 1 = the register-staged kernel (fp32, and everything the DMA kernel does not take).  Tests use it to prove coverage. */
 int vtx_last_contraction_generation(void);
+/* Process-wide launch counts per generation since the last reset (any thread: backward runs on autograd's threads).
+ * A bf16 training step of the supported models must not touch generation 1 -- tests assert it, so that a shape that
+ * silently falls off the DMA kernel shows up as a failure, not as a slower step. */
+int vtx_contraction_generation_counts(long* gen1, long* gen2, int reset);
 
 /* ---- LayerNorm(x + dropout(y)) --------------------------------------------------------
  * Replaces aten::dropout + aten::add + aten::layer_norm of the post-norm decoder layer

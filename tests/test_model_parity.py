@@ -500,3 +500,39 @@ def test_shared_visual_projection_equals_the_per_head_evaluation(backend):
     assert rel_err(runs[True][1]["textual.visual_projection.weight"], runs[False][1]["textual.visual_projection.weight"]) < 1e-5
     worst = max(rel_err(runs[True][1][n], g) for n, g in runs[False][1].items() if "cnn" in n and g.norm() > 0)
     assert worst < 2e-2          # the backbone sees d(features) through one GEMM instead of two: fp32 summation order, amplified by the toy's conditioning
+
+
+def _generation_counts(reset=False):
+    import ctypes
+    from virtex_amd import _lib
+    g1, g2 = ctypes.c_long(0), ctypes.c_long(0)
+    _lib.call("vtx_contraction_generation_counts", ctypes.byref(g1), ctypes.byref(g2), ctypes.c_int(1 if reset else 0))
+    return g1.value, g2.value
+
+
+def _assert_step_stays_on_the_dma_kernel(case, backend):
+    """Every GEMM-shaped launch of a bf16 training step (53 convolutions x {forward, input gradient, weight gradient},
+    the text heads' linears, the tied projection) must run on the DMA kernel with buffer-descriptor addressing: a shape
+    that silently falls back to the register-staged kernel would still be correct, only slower -- so it is a test."""
+    dev = select(backend)
+    _, model, batch = _build_pair(case, dev, torch.bfloat16)
+    _generation_counts(reset=True)
+    out = _run(model, batch, dev)
+    assert torch.isfinite(out["loss"])
+    g1, g2 = _generation_counts()
+    assert g2 >= 200 and g1 == 0, (g1, g2)
+    # ... and the fp32 parity mode never touches it
+    _, model32, batch32 = _build_pair(case, dev, torch.float32)
+    _generation_counts(reset=True)
+    _run(model32, batch32, dev)
+    g1, g2 = _generation_counts()
+    assert g1 >= 200 and g2 == 0, (g1, g2)
+
+
+def test_bf16_step_stays_on_the_dma_kernel_emulator():
+    _assert_step_stays_on_the_dma_kernel("r50_l2_h128_b3_small", "emu")
+
+
+@pytest.mark.gpu
+def test_bf16_step_stays_on_the_dma_kernel_gpu():
+    _assert_step_stays_on_the_dma_kernel("r50_l1_h1024_b2_full", "gpu")

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +33,13 @@ extern "C" const char* vtx_backend(void) {
 // Runtime switch used for A/B measurements of the two contraction-kernel generations.
 namespace vtxg { int g_vtx_contraction_generation = 2; int g_vtx_ablate = getenv("VIRTEX_AMD_KFLAGS") ? atoi(getenv("VIRTEX_AMD_KFLAGS")) : 0;   /* 16: tile-major split-K block order (A/B) */ int g_vtx_tile_override = -1; thread_local int g_vtx_last_colgroups = 0; thread_local int g_vtx_last_generation = 0; }
 extern "C" int vtx_last_contraction_generation(void) { return vtxg::g_vtx_last_generation; }
+namespace vtxg { std::atomic<long> g_vtx_generation_count[3]; }
+extern "C" int vtx_contraction_generation_counts(long* gen1, long* gen2, int reset) {
+    if (gen1) *gen1 = vtxg::g_vtx_generation_count[1].load();
+    if (gen2) *gen2 = vtxg::g_vtx_generation_count[2].load();
+    if (reset) { vtxg::g_vtx_generation_count[1] = 0; vtxg::g_vtx_generation_count[2] = 0; }
+    return VTX_OK;
+}
 extern "C" int vtx_set_contraction_generation(int gen) {
     VTX_CHECK(gen == 1 || gen == 2, VTX_ERR_ARG, "contraction generation must be 1 or 2");
     vtxg::g_vtx_contraction_generation = gen;

@@ -21,6 +21,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "vtx_common.h"
 
 namespace vtxg {
@@ -1241,6 +1243,7 @@ __global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL 
 }
 
 extern int g_vtx_contraction_generation;   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
+extern std::atomic<long> g_vtx_generation_count[3];   // launches per generation (process-wide; vtx_contraction_generation_counts)
 extern thread_local int g_vtx_last_generation;  // 1 / 2: which kernel generation this thread's last launch_auto picked
 extern thread_local int g_vtx_last_colgroups;   // column groups (tiles_n x waves per tile row) of this thread's last launch: EpiRowLse partials
 extern int g_vtx_ablate;   // measurement only: bit0 no MFMA, bit1 no fragment reads, bit2 no DMA, bit3 no barrier
@@ -1372,6 +1375,7 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
         if (stats_tile && v2 && c == 1 && g_vtx_tile_override < 0 && M >= 100000) c = 6;
     }
     g_vtx_last_generation = v2 ? 2 : 1;
+    g_vtx_generation_count[v2 ? 2 : 1].fetch_add(1, std::memory_order_relaxed);
 #define VTX_V1(BM_, BN_, SA_, SB_)                                                          \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v1<T, BM_, BN_>(a, b, ep, M, N, K, split_k, st); }
 #define VTX_V2(BM_, BN_, WM_, WN_, SA_, SB_)                                                \
