@@ -1045,7 +1045,11 @@ template <int ROWS, int NW, class L, int BK = 32> struct DmaStager {
 // L2 -> LDS bandwidth, not only for LDS: a 128x128 tile needs 2*(128+128)*64 B per 2*128*128*32 flop
 // = 64 flop/B, i.e. 39 TB/s of cache bandwidth at the MFMA peak (L2 delivers ~34); 256x256 needs half.
 template <int BM, int BN, int WM, int WN, class AL, class BL, class EP, int BK = 32, int STAGES = 3>
-__global__ __launch_bounds__(64 * WM * WN) void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
+// Second launch bound = minimum waves per SIMD the register allocation must leave room for: 8-wave blocks on 128x128
+// tiles are meant to run THREE per CU (six waves per SIMD = 80 VGPRs: the HBM-bound layers live on blocks in flight),
+// 8-wave blocks on 256x128 tiles two (128 VGPRs); everything else takes what it needs.
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && BM * BN <= 128 * 128) ? 6 : (WM * WN == 8 && BM * BN <= 256 * 128) ? 4 : 1)
+void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
                                                                       int kt_per_split, int abl) {
     constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
     constexpr int TILE = (BM + BN) * BK;       // elements per stage
