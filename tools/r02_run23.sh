@@ -10,4 +10,4 @@ for v in "VIRTEX_AMD_LIB=$PREV" "X=1"; do
   env $v timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 40 --warmup 10 2> gpurun_out/ab23.err | tail -1 | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('${v##*/}', r['ms_per_step'], r['value'])" >> gpurun_out/ab23.txt
 done; done
 cat gpurun_out/ab23.txt
-python tools/bench_1x1.py -1 2>&1 | grep -v "^/opt" | tee gpurun_out/bench_1x1_d.txt
+

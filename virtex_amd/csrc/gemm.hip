@@ -26,7 +26,7 @@ int gemm_nt_t(int M, int N, int K, const void* A, long lda, const void* B, long 
     auto mk_b = [&](auto& b) { b.p = (const T*)B; b.ld = ldb; b.rows = N; b.K = K; };
     bool done = false;
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
-        if (stat_parts && N % 8 == 0 && ldc == N) {
+        if (stat_parts && !bias && N % 8 == 0 && ldc == N) {     // statistics epilogues are compiled without the bias path
             EpiStore<TO, STATS_FWD> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
             ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
             strips = launch_auto<T, PlainKC, PlainKC>(mk_a, mk_b, ep, M, N, K, 1, st);

@@ -572,12 +572,30 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         return ((long)n * map_H + 2 * ih2 + map_pa) * map_W + 2 * iw2 + map_pb;
     }
     // per-lane part (4 consecutive n of one m): everything except the residual add and the store
-    __device__ __forceinline__ f32x4_t transform(int m, int n, f32x4_t v) const {
+    // What the per-lane part needs from memory besides the accumulators is loaded ONCE per wave tile (the bias of the
+    // lane's 4 columns in each column tile) / once per 16-row step (the cross-entropy row data of the lane's row), each
+    // group in one block of loads behind one wait -- not once per 16x16 tile behind its own wait: sixteen L2 latencies
+    // in a row per wave in the epilogue of every biased GEMM.
+    struct RowData { long long t; float g, l; };
+    __device__ __forceinline__ float4 bias4(int n) const {
+        return n < N ? *reinterpret_cast<const float4*>(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ RowData row_data(int m) const {
+        RowData r{-1, 0.f, 0.f};
+        if constexpr (STATS_MODE != STATS_NONE) return r;        // the cross-entropy gradient never carries statistics
+        if (act == ACT_SOFTMAX_GRAD && m < M) {
+            r.t = ce_targets[m];
+            const bool ignored = r.t == ce_ignore || r.t < 0 || r.t >= N;
+            r.g = ignored ? 0.f : ce_gout[0] / ce_lc[1];
+            r.l = ce_lse[m];
+        }
+        return r;
+    }
+    __device__ __forceinline__ f32x4_t transform(int m, int n, f32x4_t v, float4 b, const RowData& rd) const {
         if (m >= M || n >= N) return v;
         v *= alpha;
-        if (bias) {
-            const float4 b = *reinterpret_cast<const float4*>(bias + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        if constexpr (STATS_MODE == STATS_NONE) {                // statistics epilogues belong to bias-free convolutions
+            if (bias) { v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         }
         const long o = (long)m * ldc + n;
         if (preact) st4v<T>(preact + o, v);
@@ -587,10 +605,9 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         } else if (act == ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        } else if (act == ACT_SOFTMAX_GRAD) {
-            float t4[4] = {v[0], v[1], v[2], v[3]};
-            softmax_grad(m, n, t4);
-            v = f32x4_t{t4[0], t4[1], t4[2], t4[3]};
+        } else if (STATS_MODE == STATS_NONE && act == ACT_SOFTMAX_GRAD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = rd.g * (__expf(v[j] - rd.l) - ((long long)(n + j) == rd.t ? 1.f : 0.f));
         }
         if (drop.thresh) {
 #pragma unroll
@@ -1047,8 +1064,9 @@ template <int ROWS, int NW, class L, int BK = 32> struct DmaStager {
 template <int BM, int BN, int WM, int WN, class AL, class BL, class EP, int BK = 32, int STAGES = 3>
 // Second launch bound = minimum waves per SIMD the register allocation must leave room for: 8-wave blocks on 128x128
 // tiles are meant to run THREE per CU (six waves per SIMD = 80 VGPRs: the HBM-bound layers live on blocks in flight),
-// 8-wave blocks on 256x128 tiles two (128 VGPRs); everything else takes what it needs.
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && BM * BN <= 128 * 128) ? 6 : (WM * WN == 8 && BM * BN <= 256 * 128) ? 4 : 1)
+// 8-wave blocks on 256x128 tiles two (128 VGPRs), 4-wave blocks on 128x128 tiles three (168), on 128x64 / 64x128 four (128).
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && BM * BN <= 128 * 128) ? 6 : (WM * WN == 8 && BM * BN <= 256 * 128) ? 4 :
+                                           (WM * WN == 4 && BM * BN == 128 * 128) ? 3 : (WM * WN == 4 && BM * BN == 128 * 64) ? 4 : 1)
 void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
                                                                       int kt_per_split, int abl) {
     constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
@@ -1200,12 +1218,22 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
             }
             __syncthreads();
         }
+        float4 bv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SM == STATS_NONE) {
+            if (ep.bias) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = ep.bias4(n0 + wn * WTN + j * 16 + 4 * (lane >> 4));
+            }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mrow = m0 + wm * WTM + i * 16;
+            const typename EP::RowData rd = ep.row_data(mrow + (lane & 15));
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const f32x4_t v = ep.transform(mrow + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j]);
+                const f32x4_t v = ep.transform(mrow + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j], bv[j], rd);
                 st4v<TO>(reinterpret_cast<TO*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
             }
             __builtin_amdgcn_wave_barrier();
