@@ -805,3 +805,36 @@ def test_stem_tail_maxpool_backward_inside_batchnorm_backward(backend, dtype, N,
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     assert rel_err(dx.float().cpu(), dx2.float().cpu()) < tol
     assert rel_err(dgamma.cpu(), dg2.cpu()) < tol and rel_err(dbeta.cpu(), db2.cpu()) < tol
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("M,K,N", [(4200, 64, 256), (4111, 128, 512), (8192, 64, 512)])
+def test_expand1x1_streaming_kernel(backend, M, K, N):
+    """The streaming kernel of the write-heavy 1x1 'expand' convolutions (expand1x1.hip; gemm_nt + statistics is routed
+    to it unless VIRTEX_AMD_EXPAND1X1=0): output and BatchNorm sums against the tiled kernel's contract -- y = a @ w^T in bf16,
+    per-strip sums of (y - shift) and (y - shift)^2 over the STORED values.  Ragged M (rows of the last strip masked),
+    both K, one and two 256-column blocks."""
+    import os
+    if os.environ.get("VIRTEX_AMD_EXPAND1X1", "1") == "0":
+        pytest.skip("the streaming kernel is switched off (VIRTEX_AMD_EXPAND1X1=0; read once per process)")
+    dev = select(backend)
+    g = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16); w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    shift = 0.2 * torch.randn(N, generator=g)
+    ops.profile_start()
+    y, st = ops.gemm_nt(a.to(dev), w.to(dev), bn_shift=shift.to(dev))
+    rec = ops.profile_stop()
+    assert any("expand1x1" in r["name"] and r["launches"] == 1 for r in rec), [r["name"] for r in rec]   # the streaming kernel ran
+    assert st is not None and 0 < st.strips <= min(512, M // 64)
+    ref = a.float() @ w.float().t()
+    assert rel_err(y.float().cpu(), ref) < 5e-3
+    parts = st.parts[: st.strips * 2 * N].view(st.strips, 2, N).double().cpu()
+    d = y.float().cpu().double() - shift.double()
+    assert rel_err(parts[:, 0].sum(0), d.sum(0)) < 1e-5 and rel_err(parts[:, 1].sum(0), (d * d).sum(0)) < 1e-5
+    # and the BatchNorm that consumes them
+    gamma = 0.5 + torch.rand(N, generator=g); beta = 0.1 * torch.randn(N, generator=g)
+    rm1, rv1 = shift.clone().to(dev), torch.ones(N, device=dev)
+    out1, mean1, rstd1 = ops.bn_fwd(y.view(1, 1, M, N), gamma.to(dev), beta.to(dev), rm1, rv1, None, stats=st)
+    rm2, rv2 = shift.clone().to(dev), torch.ones(N, device=dev)
+    out2, mean2, rstd2 = ops.bn_fwd(y.view(1, 1, M, N), gamma.to(dev), beta.to(dev), rm2, rv2, None)
+    assert torch.allclose(mean1.cpu(), mean2.cpu(), atol=1e-4, rtol=1e-4) and torch.allclose(rstd1.cpu(), rstd2.cpu(), rtol=1e-3)

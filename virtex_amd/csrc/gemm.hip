@@ -14,6 +14,8 @@ using namespace vtxg;
 vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
 int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats);
+int vtx_expand1x1_try(int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* Y, long ldy,
+                      const float* shift, float* parts, hipStream_t st);
 
 namespace {
 
@@ -26,6 +28,12 @@ int gemm_nt_t(int M, int N, int K, const void* A, long lda, const void* B, long 
     auto mk_b = [&](auto& b) { b.p = (const T*)B; b.ld = ldb; b.rows = N; b.K = K; };
     bool done = false;
     if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+        if (stat_parts && !bias && !residual && !preact && act == ACT_NONE && alpha == 1.f && drop.thresh == 0u) {
+            // write-heavy 1x1 "expand" convolutions: the streaming kernel (expand1x1.hip) when it takes the problem
+            const int s = vtx_expand1x1_try(M, N, K, A, lda, B, ldb, C, ldc, stat_shift, stat_parts, st);
+            if (s < 0) return s;
+            if (s > 0) { if (stat_strips) *stat_strips = s; return VTX_OK; }
+        }
         if (stat_parts && !bias && N % 8 == 0 && ldc == N) {     // statistics epilogues are compiled without the bias path
             EpiStore<TO, STATS_FWD> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
             ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
