@@ -29,7 +29,8 @@ def test_pointwise_64_to_256_at_56x56_forward_and_statistics():
     y, st = ops.gemm_nt(a.to(dev), w.to(dev), bn_shift=shift.to(dev))
     ref = a.float() @ w.float().t()
     assert rel_err(y.float().cpu(), ref) < 5e-3
-    assert st is not None and st.strips in ((M + 255) // 256, (M + 127) // 128, (M + 63) // 64)
+    # one strip per block row of the tiled kernel, or one per workgroup of the streaming kernel (expand1x1.hip: this shape is its)
+    assert st is not None and (st.strips in ((M + 255) // 256, (M + 127) // 128, (M + 63) // 64) or 0 < st.strips <= 512)
     parts = st.parts[: st.strips * 2 * N].view(st.strips, 2, N).double().cpu()
     yq = y.float().cpu().double()
     d = yq - shift.double()

@@ -9,15 +9,15 @@ python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --steps 9 --warmup 3 > $R/gpurun_out/prof_kt.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ks -- python $R/bench.py --no-cpu-baseline --no-fidelity --serial-streams --steps 9 --warmup 3 > $R/gpurun_out/prof_ks.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 > $R/gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_write -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 > $R/gpurun_out/prof_write.log 2>&1
+[ -n "$SKIP_PMC" ] || rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 > $R/gpurun_out/prof_fetch.log 2>&1
+[ -n "$SKIP_PMC" ] || rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_write -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 > $R/gpurun_out/prof_write.log 2>&1
 cd $R
 python tools/rocpd_stats.py $(find gpurun_out/prof_kt -name "*.db" | head -1) 60 > gpurun_out/kernel_stats.txt
 python tools/rocpd_stats.py $(find gpurun_out/prof_ks -name "*.db" | head -1) 60 > gpurun_out/kernel_stats_serial.txt
-python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) contraction > gpurun_out/pmc_fetch.txt 2>&1
-python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) contraction > gpurun_out/pmc_write.txt 2>&1
-python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) bn_ > gpurun_out/pmc_fetch_bn.txt 2>&1
-python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) bn_ > gpurun_out/pmc_write_bn.txt 2>&1
+[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) contraction > gpurun_out/pmc_fetch.txt 2>&1
+[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) contraction > gpurun_out/pmc_write.txt 2>&1
+[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) bn_ > gpurun_out/pmc_fetch_bn.txt 2>&1
+[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) bn_ > gpurun_out/pmc_write_bn.txt 2>&1
 find gpurun_out -name "*.db" -delete
 grep -h '^{' gpurun_out/prof_ks.log | tail -1 > gpurun_out/bench_serial.json
 cat gpurun_out/gpu_tests.txt
