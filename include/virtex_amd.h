@@ -75,7 +75,9 @@ long vtx_layernorm_workspace_floats(int H);   /* scratch for the per-block dgamm
  *   out_f32 != 0: C/residual/preact are fp32 even when dtype is bf16 (vocabulary logits).
  *   bn_parts (optional): the epilogue also emits BatchNorm statistics of the output -- per (row strip,
  *   channel) sums of (value - bn_shift[n]) and squares, [strips][2][N] fp32; *bn_strips receives the
- *   number of strips (0 if this build/dtype did not produce them: use the stand-alone reduction).
+ *   number of strips (0 if this build/dtype did not produce them: use the stand-alone reduction).  The buffer
+ *   must hold (ceil(M/64) + 4) * 2 * N floats: a strip is one block row of the tiled kernel (64...256 rows) or one
+ *   workgroup of the streaming kernel for the write-heavy 1x1 convolutions (expand1x1.hip: at most min(512, M/64)).
  * vtx_gemm_tn_acc : C[M][N] (fp32) += alpha * A[K][M]^T . B[K][N]   (weight gradients;
  *   replaces the mm inside aten::linear_backward / 1x1 convolution_backward).  split_k <= 0
  *   lets the library choose; slices write partial tiles into `workspace` ([split_k][M][N] fp32, may be
