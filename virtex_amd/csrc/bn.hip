@@ -515,6 +515,24 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
     VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, rp.gx);
+    if (!ymask && !relu_beta && !dz_out) {
+        // no ReLU behind this BatchNorm (the projection shortcuts): dy is the gradient itself, so the apply is the one
+        // of the fused path -- read x and dy, write dx, four coefficients per channel in registers, two vectors in flight
+        const int unr = g_bn_apply_unroll ? (g_bn_apply_unroll >= 2 ? 2 : 1) : (nvec >= (6L << 20) ? 2 : 1);
+        const int grid = apply_grid(vtx_cdiv(nvec, unr), C / vec);
+        if (dtype == VTX_BF16) {
+            if (unr == 2)
+                VTX_KLAUNCH("bn_bwd_apply", 0, 6.0 * P * C, (bn_bwd_apply_fused_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x,
+                            (const bf16_t*)dy, save_mean, save_rstd, coef, (bf16_t*)dx, nvec, C);
+            else
+                VTX_KLAUNCH("bn_bwd_apply", 0, 6.0 * P * C, (bn_bwd_apply_fused_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x,
+                            (const bf16_t*)dy, save_mean, save_rstd, coef, (bf16_t*)dx, nvec, C);
+        } else
+            VTX_KLAUNCH("bn_bwd_apply", 0, 12.0 * P * C, (bn_bwd_apply_fused_kernel<float, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st,
+                        (const float*)x, (const float*)dy, save_mean, save_rstd, coef, (float*)dx, nvec, C);
+        VTX_LAUNCH_CHECK();
+        return VTX_OK;
+    }
     if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * P * C * (3 + (ymask ? 1 : 0) + (dz_out ? 1 : 0)), (bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const bf16_t*)x,
                            (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, coef, gamma, relu_beta, (bf16_t*)dx,
