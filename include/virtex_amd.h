@@ -193,6 +193,14 @@ int vtx_set_bn_apply_unroll(int vectors_per_thread);   /* measurement switch: 0 
 /* The stem's backward tail fused: dx = BatchNormBackward(ReLUBackward(MaxPool3x3s2Backward(dpool))), x:[N][H][W][C] the
  * stem convolution's output, dpool:[N][OH][OW][C], argmax from vtx_maxpool3x3s2_fwd; the pre-pool gradient is gathered
  * on the fly by the reduction and the apply pass and never written (visual_backbones.py:68-74: conv1-bn1-relu-maxpool). */
+/* The stem's forward tail fused: pooled = MaxPool3x3s2(ReLU(BatchNorm(x))) with training statistics and the running-
+ * statistics update of vtx_bn_fwd; the normalised tensor is never written (its backward recomputes the ReLU mask from
+ * x: vtx_bn_bwd with relu_beta, or vtx_bn_bwd_maxpool).  Pooled values and argmax are bit-identical to vtx_bn_fwd followed
+ * by vtx_maxpool3x3s2_fwd.  workspace: vtx_bn_workspace_floats(C).  (visual_backbones.py:68-74: conv1-bn1-relu-maxpool) */
+int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, long long* num_batches_tracked, void* pooled, uint8_t* argmax,
+                       float* save_mean, float* save_rstd, float* workspace, int N, int H, int W, int C, float eps,
+                       float momentum, void* stream);
 int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, const uint8_t* argmax, const float* gamma,
                        const float* beta, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
                        float* dbeta, float* workspace, int N, int H, int W, int C, void* stream);

@@ -838,3 +838,23 @@ def test_expand1x1_streaming_kernel(backend, M, K, N):
     rm2, rv2 = shift.clone().to(dev), torch.ones(N, device=dev)
     out2, mean2, rstd2 = ops.bn_fwd(y.view(1, 1, M, N), gamma.to(dev), beta.to(dev), rm2, rv2, None)
     assert torch.allclose(mean1.cpu(), mean2.cpu(), atol=1e-4, rtol=1e-4) and torch.allclose(rstd1.cpu(), rstd2.cpu(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (3, 9, 11, 16), (1, 7, 7, 64)])
+def test_stem_tail_forward_batchnorm_relu_maxpool_in_one_pass(backend, dtype, N, H, W, C):
+    """vtx_bn_fwd_maxpool against vtx_bn_fwd followed by vtx_maxpool3x3s2_fwd: pooled values, argmax, saved statistics
+    and running statistics BIT-identical (every tap is rounded to the storage type before the comparison)."""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(N + H + W + C)
+    x = (0.8 * torch.randn(N, H, W, C, generator=g) + 0.1).to(dtype).to(dev)
+    gamma = (0.5 + torch.rand(C, generator=g)).to(dev); beta = (0.2 * torch.randn(C, generator=g)).to(dev)
+    rm1, rv1 = torch.zeros(C, device=dev), torch.ones(C, device=dev); nbt1 = torch.zeros((), dtype=torch.long, device=dev)
+    rm2, rv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev); nbt2 = torch.zeros((), dtype=torch.long, device=dev)
+    y, mean_a, rstd_a = ops.bn_fwd(x, gamma, beta, rm1, rv1, nbt1, relu=True)
+    pool_a, arg_a = ops.maxpool_fwd(y)
+    pool_b, arg_b, mean_b, rstd_b = ops.bn_fwd_maxpool(x, gamma, beta, rm2, rv2, nbt2)
+    assert torch.equal(pool_a.cpu(), pool_b.cpu()) and torch.equal(arg_a.cpu(), arg_b.cpu())
+    assert torch.equal(mean_a.cpu(), mean_b.cpu()) and torch.equal(rstd_a.cpu(), rstd_b.cpu())
+    assert torch.equal(rm1.cpu(), rm2.cpu()) and torch.equal(rv1.cpu(), rv2.cpu()) and int(nbt1) == int(nbt2) == 1

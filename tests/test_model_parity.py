@@ -536,3 +536,34 @@ def test_bf16_step_stays_on_the_dma_kernel_emulator():
 @pytest.mark.gpu
 def test_bf16_step_stays_on_the_dma_kernel_gpu():
     _assert_step_stays_on_the_dma_kernel("r50_l1_h1024_b2_full", "gpu")
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fused_stem_forward_tail_leaves_the_step_unchanged(backend):
+    """VIRTEX_AMD_FUSE_STEM_FWD (BatchNorm + ReLU + max-pool of the stem in one pass, the tensor between them never
+    written): loss, every gradient and the BatchNorm buffers bit-identical to the three-kernel path."""
+    from virtex_amd.modules import visual_backbones as vb
+    dev = select(backend)
+    _, model, batch = _build_pair("r50_l2_h128_b3_small", dev, torch.bfloat16)
+    start = {n: b.detach().clone() for n, b in model.named_buffers()}
+    saved = vb.FUSE_STEM_FWD
+    runs = {}
+    try:
+        for flag in (False, True):
+            vb.FUSE_STEM_FWD = flag
+            with torch.no_grad():
+                for n, b in model.named_buffers():
+                    b.copy_(start[n])
+            model.zero_grad(set_to_none=True)
+            out = _run(model, batch, dev)
+            runs[flag] = (out["loss"].item(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()},
+                          {n: b.detach().float().cpu().clone() for n, b in model.named_buffers()})
+    finally:
+        vb.FUSE_STEM_FWD = saved
+    assert runs[True][0] == runs[False][0]
+    for n in runs[False][1]:
+        if "embedding" in n:            # fed by fp32 atomics: not bit-reproducible run to run
+            continue
+        assert torch.equal(runs[True][1][n], runs[False][1][n]), n
+    for n in runs[False][2]:
+        assert torch.equal(runs[True][2][n], runs[False][2][n]), n

@@ -408,6 +408,69 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(
     }
 }
 
+// ---- the stem's forward tail in one pass: y = relu(BatchNorm(x)) is max-pooled (3x3, stride 2, pad 1) as it is
+// computed and never written -- the 411 MB tensor between the stem's BatchNorm and its pooling disappears (its backward
+// recomputes the ReLU mask from x).  Every tap value is rounded to the storage type before the comparison, so pooled
+// values AND argmax are bit-identical to vtx_bn_fwd followed by vtx_maxpool3x3s2_fwd (first maximum wins on ties).
+// Thread layout of the pooling kernels: tx = channel vector (coefficients in registers), ty = output pixel.
+__device__ __forceinline__ int bnpool_qdiv(int n, int d) {      // exact for 0 <= n < 2^24
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    const int r = n - q * d;
+    if (r < 0) --q; else if (r >= d) ++q;
+    return q;
+}
+template <class T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                                  const float* __restrict__ scale, const float* __restrict__ beta,
+                                                                  T* __restrict__ y, uint8_t* __restrict__ argmax, int N, int H, int W,
+                                                                  int C, int OH, int OW, int TX) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC, TY = 256 / TX;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int cvi = blockIdx.y * TX + tx;
+    if (cvi >= cv || ty >= TY) return;
+    const int c0 = cvi * VEC, P = N * OH * OW;
+    float mu[VEC], sc[VEC], be[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mu[j] = mean[c0 + j]; sc[j] = scale[c0 + j]; be[j] = beta[c0 + j]; }
+    for (int p = blockIdx.x * TY + ty; p < P; p += gridDim.x * TY) {
+        const int n = bnpool_qdiv(p, OH * OW), rem = p - n * OH * OW;
+        const int oh = bnpool_qdiv(rem, OW), ow = rem - oh * OW;
+        float best[VEC]; int idx[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; idx[j] = 0; }
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    Vec16<T> v; v.load(x + (((long)n * H + ih) * W + iw) * C + c0);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float a = fmaxf((v.v[j] - mu[j]) * sc[j] + be[j], 0.f);      // exactly bn_apply_kernel's arithmetic
+                        if constexpr (sizeof(T) == 2) a = bf2f(f2bf(a));              // ... and its storage rounding
+                        if (first || a > best[j]) { best[j] = a; idx[j] = kh * 3 + kw; }
+                    }
+                    first = false;
+                }
+            }
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
+        const long off = (long)p * C + c0;
+        o.store(y + off);
+        if constexpr (VEC == 8)
+            *reinterpret_cast<uint2*>(argmax + off) =
+                make_uint2((uint32_t)idx[0] | ((uint32_t)idx[1] << 8) | ((uint32_t)idx[2] << 16) | ((uint32_t)idx[3] << 24),
+                           (uint32_t)idx[4] | ((uint32_t)idx[5] << 8) | ((uint32_t)idx[6] << 16) | ((uint32_t)idx[7] << 24));
+        else
+            *reinterpret_cast<uint32_t*>(argmax + off) =
+                (uint32_t)idx[0] | ((uint32_t)idx[1] << 8) | ((uint32_t)idx[2] << 16) | ((uint32_t)idx[3] << 24);
+    }
+}
+
 // vectors in flight per thread of the apply kernels: 0 = by size, or 1, 2, 4 (A/B switch VIRTEX_AMD_BN_UNROLL)
 int g_bn_apply_unroll = getenv("VIRTEX_AMD_BN_UNROLL") ? atoi(getenv("VIRTEX_AMD_BN_UNROLL")) : 0;
 constexpr int VTX_BN_MAX_PARTS = 512;
@@ -627,5 +690,49 @@ extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, c
 extern "C" int vtx_set_bn_apply_unroll(int n) {
     VTX_CHECK(n == 0 || n == 1 || n == 2 || n == 4, VTX_ERR_ARG, "bn apply unroll must be 0 (automatic), 1, 2 or 4");
     g_bn_apply_unroll = n;
+    return VTX_OK;
+}
+
+// The stem's forward tail: BatchNorm (training statistics, running-statistics update) + ReLU + MaxPool2d(3,2,1) with the
+// normalised tensor never written.  Replaces aten::batch_norm + relu_ + max_pool2d_with_indices of
+// /root/reference/virtex/modules/visual_backbones.py:68-74 (torchvision ResNet: conv1 -> bn1 -> relu -> maxpool).
+// x: [N][H][W][C] the stem convolution's output; pooled: [N][OH][OW][C]; argmax: uint8, the layout of vtx_maxpool3x3s2_fwd.
+extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, long long* num_batches_tracked, void* pooled, uint8_t* argmax,
+                                  float* save_mean, float* save_rstd, float* workspace, int N, int H, int W, int C, float eps,
+                                  float momentum, void* stream) {
+    VTX_CHECK(x && gamma && beta && pooled && argmax && save_mean && save_rstd && workspace, VTX_ERR_ARG, "bn_fwd_maxpool: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_fwd_maxpool: bad dtype %d", dtype);
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(N > 0 && H > 0 && W > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_fwd_maxpool: C=%d must be vec*2^k", C);
+    VTX_CHECK((long)N * H * W < (1L << 24), VTX_ERR_SHAPE, "bn_fwd_maxpool: more than 2^24 pixels is not supported");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = N * H * W, OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    float* scale = workspace; float* sums = workspace + 4 * C;
+    ReducePlan rp = plan_reduce(P, C, vec);
+    if (dtype == VTX_BF16)
+        VTX_KLAUNCH("bn_fwd_reduce", 0, 2.0 * P * C, (bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
+                    (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+    else
+        VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
+                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+    if (dtype == VTX_BF16)
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, sums, gamma, beta,
+                    save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
+    else
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, sums, gamma, beta,
+                    save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
+    const int cv = C / vec;
+    int TX = 1; while (TX < cv && TX < 256) TX <<= 1;
+    const int gy = (cv + TX - 1) / TX, TY = 256 / TX;
+    long gx = ((long)N * OH * OW + TY - 1) / TY; gx = gx > 8192 ? 8192 : (gx < 1 ? 1 : gx);
+    const double el = dtype == VTX_BF16 ? 2.0 : 4.0;
+    if (dtype == VTX_BF16)
+        VTX_KLAUNCH("bn_fwd_apply", 0, el * P * C + (el + 1.0) * N * OH * OW * C, (bn_relu_maxpool_fwd_kernel<bf16_t>), dim3((int)gx, gy), dim3(256), 0, st,
+                    (const bf16_t*)x, save_mean, scale, beta, (bf16_t*)pooled, argmax, N, H, W, C, OH, OW, TX);
+    else
+        VTX_KLAUNCH("bn_fwd_apply", 0, el * P * C + (el + 1.0) * N * OH * OW * C, (bn_relu_maxpool_fwd_kernel<float>), dim3((int)gx, gy), dim3(256), 0, st,
+                    (const float*)x, save_mean, scale, beta, (float*)pooled, argmax, N, H, W, C, OH, OW, TX);
+    VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

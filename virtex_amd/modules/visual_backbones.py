@@ -43,6 +43,9 @@ FUSE_BN_BWD = os.environ.get("VIRTEX_AMD_FUSE_BN_BWD", "1") != "0"
 # tensor (vtx_bn_bwd_maxpool).  Measured SLOWER (1.19 vs 1.11 ms of kernel time, step 33.4 vs 33.1 ms): the 3x3/s2
 # gather is instruction-bound (0.9 TB/s) and the fusion runs it twice to save 1 GB of traffic -> off by default.
 FUSE_STEM_TAIL = os.environ.get("VIRTEX_AMD_FUSE_STEM_TAIL", "0") != "0"
+# forward counterpart: BatchNorm + ReLU + max-pool of the stem in one pass, the 411 MB tensor between them never written
+# (bit-identical results; prepared at the end of round 2 on the emulator, to be measured on the GPU before it becomes default)
+FUSE_STEM_FWD = os.environ.get("VIRTEX_AMD_FUSE_STEM_FWD", "0") != "0"
 
 
 # ----------------------------------------------------------------------------------------
@@ -388,8 +391,19 @@ class _ResNetFn(torch.autograd.Function):
             return y
 
         a0, packed = _stem_input(image, dt)
-        y = run(stem, a0, True, first=True)
-        pooled, argmax = ops.maxpool_fwd(y)
+        if FUSE_STEM_FWD and packed:
+            bn = stem.bn
+            x0 = ops.conv2d_fwd(a0, _stem_weight(stem, dt), stem.stride, 0)
+            pooled, argmax, mean0, rstd0 = ops.bn_fwd_maxpool(x0, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                                                             bn.running_var, bn.num_batches_tracked, eps=bn.eps,
+                                                             momentum=bn.momentum if bn.momentum is not None else 0.1)
+            s0 = _Saved()
+            s0.a, s0.x, s0.y, s0.mean, s0.rstd, s0.wt = a0, x0, None, mean0, rstd0, None     # y: never materialised
+            rec[stem] = s0
+            y = x0                                                          # only its shape is used below
+        else:
+            y = run(stem, a0, True, first=True)
+            pooled, argmax = ops.maxpool_fwd(y)
         cur = pooled
         for (u1, u2, u3, ud) in blocks:
             inp = cur

@@ -311,6 +311,23 @@ def bn_bwd_fused(x, dz, gamma, mean, rstd, dgamma, dbeta, stats: "BnStats"):
     return dx
 
 
+def bn_fwd_maxpool(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
+    """Stem tail forward: BatchNorm (training) + ReLU + MaxPool2d(3,2,1) in one pass; the normalised tensor is never
+    written.  Returns (pooled, argmax, mean, rstd)."""
+    N, H, W, C = x.shape
+    _chk(x, "x")
+    ws = bn_workspace(x.device, C)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(N, OH, OW, C, dtype=x.dtype, device=x.device)
+    arg = torch.empty(N, OH, OW, C, dtype=torch.uint8, device=x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    call("vtx_bn_fwd_maxpool", c_int(dtype_code(x.dtype)), ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+         ptr(nbt), ptr(y), ptr(arg), ptr(mean), ptr(rstd), ptr(ws), c_int(N), c_int(H), c_int(W), c_int(C), c_float(eps),
+         c_float(momentum), stream_ptr(x))
+    return y, arg, mean, rstd
+
+
 def bn_bwd_maxpool(x, dpool, argmax, gamma, beta, mean, rstd, dgamma, dbeta):
     """Stem tail: BatchNorm+ReLU backward with the max-pool backward gathered on the fly (no pre-pool gradient tensor)."""
     N, H, W, C = x.shape
