@@ -108,6 +108,8 @@ typedef struct VtxBnBwdFusion {
     float* parts;        /* out: [strips][2][N] fp32 partial sums {sum dz, sum dz*xhat} */
     long parts_cap;      /* capacity of `parts` in floats; (ceil(M/64) + 4) * 2 * N always suffices */
     int strips;          /* out */
+    const uint8_t* ybits; /* [M*N/8] or NULL: the same mask as ymask, one BIT per element (bit e of byte (m*N+n)/8 = output
+                                  (m, n+e) > 0), as vtx_bn_fwd writes it (relu_bits): 1/16 of the bytes; takes precedence over ymask */
 } VtxBnBwdFusion;
 /* C[M][N] = A[M][K] . B[N][K]^T + residual, with the fusion above (1x1 convolutions' input gradient). */
 int vtx_gemm_nt_bnbwd(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
@@ -178,6 +180,8 @@ int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamm
                float* running_mean, float* running_var, long long* num_batches_tracked, void* y,
                float* save_mean, float* save_rstd, float* workspace, int P, int C, float eps,
                float momentum, int relu, const float* pre_partials, int pre_nparts, const float* pre_shift,
+               uint8_t* relu_bits /* nullable; bf16 + relu only: [P*C/8] bytes, bit e of byte i = (y[8i+e] > 0) -- the ReLU mask
+                                     the input-gradient epilogues read instead of y itself (VtxBnBwdFusion.ybits) */,
                void* stream);
 int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* ymask, const float* gamma,
                const float* relu_beta /* non-NULL: ReLU mask recomputed as xhat*gamma+beta > 0, ymask must be NULL */,

@@ -21,6 +21,11 @@ def q8(v):
     return np.clip(np.rint(v), 0, 255)
 
 
+def t8(v):
+    """brightness / contrast on uint8 images: a lookup table built as clip(...).astype(uint8) -- the cast truncates."""
+    return np.floor(np.clip(v, 0, 255))
+
+
 def resize_crop(img, x0, y0, cw, ch, size):
     crop = img[y0:y0 + ch, x0:x0 + cw].astype(np.float32)
     fy = (np.arange(size, dtype=np.float32) + 0.5) * np.float32(ch) / np.float32(size) - 0.5
@@ -67,9 +72,9 @@ def jitter(img, b, c, s, h, order):
     for k in range(4):
         op = (order >> (2 * k)) & 3
         if op == 0:
-            img = q8(img * np.float32(b))
+            img = t8(img * np.float32(b))
         elif op == 1:
-            img = q8(img * np.float32(c) + np.float32(gray(img).mean(dtype=np.float64)) * np.float32(1 - c))
+            img = t8(img * np.float32(c) + np.float32(gray(img).mean(dtype=np.float64)) * np.float32(1 - c))
         elif op == 2:
             img = q8(img * np.float32(s) + gray(img)[..., None] * np.float32(1 - s))
         elif h != 0:

@@ -192,8 +192,13 @@ def test_batchnorm(backend, dtype, N, H, W, C, relu, res):
 
     rmd, rvd = rm0.clone().to(dev), rv0.clone().to(dev)
     nbt = torch.zeros((), dtype=torch.int64, device=dev)
-    y, mean, rstd = ops.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmd, rvd, nbt, relu=relu,
-                               residual=r.to(dev) if res else None)
+    if relu and dtype == torch.bfloat16:
+        y, mean, rstd, bits = ops.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmd, rvd, nbt, relu=relu,
+                                         residual=r.to(dev) if res else None, want_bits=True)
+        assert torch.equal(bits.cpu(), _pack_mask_bits(y.float().cpu()))     # the bit mask IS (y > 0)
+    else:
+        y, mean, rstd = ops.bn_fwd(x.to(dev), gamma.to(dev), beta.to(dev), rmd, rvd, nbt, relu=relu,
+                                   residual=r.to(dev) if res else None)
     e = 3e-5 if dtype == torch.float32 else 1e-2
     assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < e
     assert rel_err(rmd.cpu(), rm) < 1e-4 and rel_err(rvd.cpu(), rv) < 1e-4 and int(nbt) == 1
@@ -660,8 +665,14 @@ def _bn_bwd_reference(z, x, mean, rstd, gamma, beta, ymask, mode):
     return dz, s1, s2, dx
 
 
+def _pack_mask_bits(y):
+    """one bit per element, bit e of byte i = (y.flatten()[8 i + e] > 0): the layout vtx_bn_fwd(relu_bits) writes"""
+    m = (y.flatten() > 0).to(torch.int32).view(-1, 8)
+    return (m * (2 ** torch.arange(8, dtype=torch.int32))).sum(1).to(torch.uint8)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
-@pytest.mark.parametrize("mode", ["ymask", "remask", "none"])
+@pytest.mark.parametrize("mode", ["ymask", "ybits", "remask", "none"])
 @pytest.mark.parametrize("cand", [-1, 0, 1, 2, 3, 4, 5, 6])
 def test_batchnorm_backward_fused_in_gemm_epilogue(backend, mode, cand):
     """bf16: the input-gradient GEMM's epilogue masks its output with the ReLU of the BatchNorm that fed the
@@ -680,9 +691,13 @@ def test_batchnorm_backward_fused_in_gemm_epilogue(backend, mode, cand):
     gamma = 0.5 + torch.rand(N, generator=g); beta = 0.2 * torch.randn(N, generator=g)
     ymask = torch.relu(torch.randn(M, N, generator=g)).to(dt)
     z = a.float() @ b.float().t() + res.float()
+    bits_mode = mode == "ybits"          # the mask as one bit per element instead of the tensor: identical results
+    if bits_mode:
+        mode = "ymask"
     dz_r, s1_r, s2_r, dx_r = _bn_bwd_reference(z, x.float(), mean, rstd, gamma, beta, ymask.float(), mode)
-    bn = ops.BnBwd(x.to(dev), mean.to(dev), rstd.to(dev), ymask=ymask.to(dev) if mode == "ymask" else None,
-                   gamma=gamma.to(dev) if mode == "remask" else None, beta=beta.to(dev) if mode == "remask" else None)
+    bn = ops.BnBwd(x.to(dev), mean.to(dev), rstd.to(dev), ymask=ymask.to(dev) if (mode == "ymask" and not bits_mode) else None,
+                   gamma=gamma.to(dev) if mode == "remask" else None, beta=beta.to(dev) if mode == "remask" else None,
+                   ybits=_pack_mask_bits(ymask).to(dev) if bits_mode else None)
     try:
         _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
         dz, st = ops.gemm_nt_bnbwd(a.to(dev), b.to(dev), bn, residual=res.to(dev))

@@ -30,6 +30,14 @@ def _build_pair(case, dev, dtype):
     return oracle_model, model, batch
 
 
+def _dump_rows(name, summary, rows):
+    """Measured distances of a GPU parity run -> gpurun_out/ (copied into profiles/ as the round's evidence)."""
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name), "w") as f:
+        json.dump({"summary": summary, "rows": rows}, f, indent=1)
+
+
 def _run(model, batch, dev):
     model.train()
     out = model({k: v.to(dev) for k, v in batch.items()})
@@ -37,14 +45,32 @@ def _run(model, batch, dev):
     return out
 
 
+def backbone_rule(rows, per_tensor=2.5, median=1.5):
+    """The calibrated backbone-gradient rule of tests/test_fidelity.py, with NO absolute floor: rows = (name, ours vs
+    the fp64 oracle, the reference's own fp32 vs its fp64 evaluation).  Every tensor within `per_tensor` x the
+    reference's own distance for that tensor (a tensor whose own distance happens to lie below the median of all
+    tensors is held to the median: the per-tensor distance is itself a random variable), and the median over the
+    tensors within `median` x the reference's median."""
+    med_ref = sorted(r[2] for r in rows)[len(rows) // 2]
+    med_mine = sorted(r[1] for r in rows)[len(rows) // 2]
+    worst = max(rows, key=lambda r: r[1] / max(r[2], med_ref))
+    for n, mine, ref in rows:
+        assert mine <= per_tensor * max(ref, med_ref), (n, mine, ref, med_ref)
+    assert med_mine <= median * med_ref, (med_mine, med_ref)
+    return {"median_ref": med_ref, "median_mine": med_mine, "worst": (worst[0], worst[1], worst[2])}
+
+
 def _check(case, dev, dtype, text_tol, loss_tol, cnn_factor, cnn_floor):
     """Gradients of the text side (and the loss) are well conditioned: assert the north-star
     bound directly.  Gradients of the ResNet are NOT: at these batch sizes the reference's own
     fp32 CPU path differs from its fp64 evaluation by 0.3-3 % relative L2 (53 BatchNorm
     backward projections amplify rounding; see DESIGN.md "Parity").  We therefore measure that
-    distance here and require the median / maximum of ours over the backbone's tensors to stay
-    within `cnn_factor` x the reference's own (floored at `cnn_floor`: in the tiny emulator case
-    single ReLU sign flips, worth ~1e-2 each with 12 samples per channel, dominate)."""
+    distance here and require ours to stay within a factor of the reference's own.
+    `cnn_floor` = None (every GPU case): the per-tensor rule of tests/test_fidelity.py (`backbone_rule`), no
+    absolute floor -- a loose constant can never be the bound that passes.  `cnn_floor` > 0 (ONLY the 3-image 64x64
+    emulator toy: 12 samples per channel in the last stage, single ReLU sign flips worth ~1e-2 each dominate and the
+    reference's own distance is not a usable scale): median / maximum over the tensors within `cnn_factor` x the
+    reference's own, floored."""
     import copy
 
     oracle_model, model, batch = _build_pair(case, dev, dtype)
@@ -65,15 +91,17 @@ def _check(case, dev, dtype, text_tol, loss_tol, cnn_factor, cnn_floor):
     names = [n for n, _ in oracle_model.named_parameters()]
     assert names == [n for n, _ in model.named_parameters()]
     worst_text = ("", 0.0)
-    cnn_mine, cnn_ref = [], []
+    cnn_mine, cnn_ref, cnn_rows = [], [], []
     for (n, p), (_, q), (_, r) in zip(model.named_parameters(), oracle_model.named_parameters(),
                                       oracle64.named_parameters()):
         assert p.grad is not None and p.grad.shape == q.grad.shape, n
         if "cnn" in n:
             mine, ref = rel_err(p.grad.cpu(), r.grad), rel_err(q.grad, r.grad)
             cnn_mine.append(mine), cnn_ref.append(ref)
+            if r.grad.norm() > 0:
+                cnn_rows.append((n, mine, ref))
             g = gold["grads"][n]   # golden norms (verbatim reference, fp32) within the same band
-            assert abs(p.grad.double().norm().item() - g["norm"]) <= 3 * max(mine, ref, cnn_floor) * g["norm"] + 1e-9, n
+            assert abs(p.grad.double().norm().item() - g["norm"]) <= 3 * max(mine, ref, cnn_floor or 0.0) * g["norm"] + 1e-9, n
         else:
             e = rel_err(p.grad.cpu(), q.grad)
             g = gold["grads"][n]
@@ -82,10 +110,14 @@ def _check(case, dev, dtype, text_tol, loss_tol, cnn_factor, cnn_floor):
                 worst_text = (n, e)
     assert worst_text[1] < text_tol, f"worst text-side gradient mismatch {worst_text}"
     # backbone: aggregate over the 161 tensors (a single ReLU sign flip moves one tensor by ~1e-2)
-    cnn_mine, cnn_ref = sorted(cnn_mine), sorted(cnn_ref)
-    med_m, med_r = cnn_mine[len(cnn_mine) // 2], cnn_ref[len(cnn_ref) // 2]
-    assert med_m <= cnn_factor * max(med_r, cnn_floor), (med_m, med_r)
-    assert cnn_mine[-1] <= cnn_factor * max(cnn_ref[-1], 4 * cnn_floor), (cnn_mine[-1], cnn_ref[-1])
+    if cnn_floor is None:
+        summary = backbone_rule(cnn_rows)
+        _dump_rows(f"parity_fp32_{case}.json", summary, cnn_rows)
+    else:
+        cnn_mine, cnn_ref = sorted(cnn_mine), sorted(cnn_ref)
+        med_m, med_r = cnn_mine[len(cnn_mine) // 2], cnn_ref[len(cnn_ref) // 2]
+        assert med_m <= cnn_factor * max(med_r, cnn_floor), (med_m, med_r)
+        assert cnn_mine[-1] <= cnn_factor * max(cnn_ref[-1], 4 * cnn_floor), (cnn_mine[-1], cnn_ref[-1])
     for (n, b), (_, c) in zip(model.named_buffers(), oracle_model.named_buffers()):
         if b.dtype.is_floating_point:
             assert rel_err(b.cpu(), c) < (1e-4 if dtype == torch.float32 else 2e-2), n
@@ -203,7 +235,7 @@ def test_small_model_fp32_emulator():
 @pytest.mark.parametrize("case", ["r50_l2_h128_b3_small", "r50_l1_h1024_b2_full", "r50_l1_h1024_b2_ragged"])
 def test_model_fp32_gpu(case):
     dev = select("gpu")
-    _check(case, dev, torch.float32, text_tol=1e-3, loss_tol=1e-5, cnn_factor=4.0, cnn_floor=1.5e-2)
+    _check(case, dev, torch.float32, text_tol=1e-3, loss_tol=1e-5, cnn_factor=None, cnn_floor=None)
 
 
 @pytest.mark.gpu
@@ -291,6 +323,49 @@ def test_other_baseline_configs_fp32_gpu(visual, textual):
                 zip(model.named_parameters(), oracle_model.named_parameters()) if "cnn" not in n)
     assert worst[0] < 1e-3, worst
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("visual,textual", [("torchvision::resnet101", "transdec_postnorm::L1_H2048_A32_F8192"),
+                                            ("torchvision::wide_resnet50_2", "transdec_postnorm::L1_H1024_A16_F4096")])
+def test_other_backbones_every_gradient_fp32_gpu(visual, textual):
+    """BASELINE.json config 5 (configs/backbone_ablations/bicaptioning_R_101_L1_H1024.yaml:1-5 +
+    configs/width_ablations/bicaptioning_R_50_L1_H2048.yaml:1-5) and the wide_resnet50_2 ablation: ONE fp32 training step
+    at B = 8, 224x224, through the hand-scheduled ResNet forward/backward -- loss against the oracle, every text-side
+    gradient at the north-star bound, and EVERY backbone gradient (314 tensors for ResNet-101) per tensor against the fp64
+    oracle with the calibrated rule of tests/test_fidelity.py (`backbone_rule`: within 2.5x the reference's own
+    fp32<->fp64 distance for that tensor, median within 1.5x; no floor)."""
+    import copy
+    dev = select("gpu")
+    kw = dict(visual=visual, textual=textual, vocab_size=10000)
+    om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, **kw).train()
+    batch = synth.synthetic_batch(8, image_size=224, seed=11, ragged=True)
+    o64 = copy.deepcopy(om).double()
+    oo = om(batch); oo["loss"].backward()
+    o64({k: (v.double() if v.dtype.is_floating_point else v) for k, v in batch.items()})["loss"].backward()
+    g64 = {n: p.grad for n, p in o64.named_parameters()}
+    model = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=torch.float32, **kw)
+    missing = model.load_state_dict(om.state_dict())
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model = model.to(dev)
+    out = _run(model, batch, dev)
+    assert abs(out["loss"].item() - oo["loss"].item()) < 1e-5 * abs(oo["loss"].item())
+    rows = []
+    for (n, p), (_, q) in zip(model.named_parameters(), om.named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        if "cnn" in n:
+            if g64[n].norm() > 0:
+                rows.append((n, rel_err(p.grad.cpu(), g64[n]), rel_err(q.grad, g64[n])))
+        else:
+            assert rel_err(p.grad.cpu(), q.grad) < 1e-3, n
+    assert len(rows) >= 150
+    summary = backbone_rule(rows)
+    _dump_rows(f"parity_fp32_b8_{visual.split('::')[1]}.json", summary, rows)
+    for (n, b), (_, c) in zip(model.named_buffers(), om.named_buffers()):
+        if b.dtype.is_floating_point:
+            assert rel_err(b.cpu(), c) < 1e-4, n
+        else:
+            assert int(b) == int(c), n
 
 
 def _train_then_eval(dev, steps=2):
@@ -574,3 +649,32 @@ def test_fused_stem_forward_tail_leaves_the_step_unchanged(backend):
         for n in runs[False][2]:
             if n.startswith("visual.cnn.bn1"):
                 assert rel_err(runs[True][2][n], runs[False][2][n]) < 1e-5, n
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_relu_mask_bits_leave_the_step_unchanged(backend):
+    """VIRTEX_AMD_RELU_BITS: the fused BatchNorm backward of a Bottleneck's bn3 reads the block output's ReLU mask as one
+    bit per element (written by the BatchNorm + residual + ReLU pass) instead of the whole output tensor: loss and every
+    gradient bit-identical to the tensor-mask path."""
+    from virtex_amd.modules import visual_backbones as vb
+    dev = select(backend)
+    _, model, batch = _build_pair("r50_l2_h128_b3_small", dev, torch.bfloat16)
+    start = {n: b.detach().clone() for n, b in model.named_buffers()}
+    saved = vb.RELU_BITS
+    runs = {}
+    try:
+        for flag in (False, True):
+            vb.RELU_BITS = flag
+            with torch.no_grad():
+                for n, b in model.named_buffers():
+                    b.copy_(start[n])
+            model.zero_grad(set_to_none=True)
+            out = _run(model, batch, dev)
+            runs[flag] = (out["loss"].item(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()})
+    finally:
+        vb.RELU_BITS = saved
+    assert runs[True][0] == runs[False][0]
+    for n in runs[False][1]:
+        if "embedding" in n:            # fed by fp32 atomics: not bit-reproducible run to run
+            continue
+        assert torch.equal(runs[True][1][n], runs[False][1][n]), n

@@ -14,6 +14,9 @@ namespace {
 
 struct Rgb { float r, g, b; };
 __device__ __forceinline__ float q8(float v) { return fminf(fmaxf(rintf(v), 0.f), 255.f); }
+// brightness / contrast on uint8 images go through a lookup table built as clip(...).astype(uint8): the cast TRUNCATES
+// (albumentations' uint8 functionals); only saturation (cv2.addWeighted) and the resize round
+__device__ __forceinline__ float t8(float v) { return floorf(fminf(fmaxf(v, 0.f), 255.f)); }
 __device__ __forceinline__ float gray_of(Rgb p) { return q8(0.299f * p.r + 0.587f * p.g + 0.114f * p.b); }
 
 __device__ __forceinline__ Rgb hue_shift(Rgb p, float h) {      // HSV with H in [0,1), shift by h (fraction of a turn)
@@ -62,8 +65,8 @@ __device__ __forceinline__ Rgb sample(const uint8_t* __restrict__ src, int n, in
 __device__ __forceinline__ Rgb jitter(Rgb p, const VtxAugParams& a, int first, int last, float gray_mean) {
     for (int k = first; k < last; ++k) {
         const int op = (a.order >> (2 * k)) & 3;
-        if (op == 0) { p = {q8(p.r * a.brightness), q8(p.g * a.brightness), q8(p.b * a.brightness)}; }
-        else if (op == 1) { const float m = gray_mean * (1.f - a.contrast); p = {q8(p.r * a.contrast + m), q8(p.g * a.contrast + m), q8(p.b * a.contrast + m)}; }
+        if (op == 0) { p = {t8(p.r * a.brightness), t8(p.g * a.brightness), t8(p.b * a.brightness)}; }
+        else if (op == 1) { const float m = gray_mean * (1.f - a.contrast); p = {t8(p.r * a.contrast + m), t8(p.g * a.contrast + m), t8(p.b * a.contrast + m)}; }
         else if (op == 2) { const float g = gray_of(p) * (1.f - a.saturation); p = {q8(p.r * a.saturation + g), q8(p.g * a.saturation + g), q8(p.b * a.saturation + g)}; }
         else if (a.hue != 0.f) p = hue_shift(p, a.hue);
     }

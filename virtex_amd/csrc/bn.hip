@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ beta, T* __restrict__ y,
-                                                       long nvec, int C, int relu) {
+                                                       uint8_t* __restrict__ bits, long nvec, int C, int relu) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
     const long t0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
@@ -213,6 +213,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                 for (int j = 0; j < VEC; ++j) v[u].v[j] += r[u].v[j];
             }
             if (relu) {
+                if (bits) {                      // the ReLU mask as one bit per element: what the backward reads instead of y
+                    uint32_t mb = 0;
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) mb |= (v[u].v[j] > 0.f ? 1u : 0u) << j;
+                    bits[i] = (uint8_t)mb;
+                }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) v[u].v[j] = fmaxf(v[u].v[j], 0.f);
             }
@@ -329,8 +335,9 @@ __device__ __forceinline__ void pool_gather(const T* __restrict__ dpool, const u
             if (tw < 0 || (tw & 1) || (tw >> 1) >= OW) continue;
             const long off = (((long)n * OH + (th >> 1)) * OW + (tw >> 1)) * C + c0;
             Vec16<T> d; d.load(dpool + off);
-            const uint2 am = *reinterpret_cast<const uint2*>(argmax + off);      // VEC <= 8 argmax bytes
-            const uint32_t aw[2] = {am.x, am.y};
+            uint32_t aw[2] = {0u, 0u};                                           // VEC argmax bytes: 8 (bf16) or 4 (fp32, 4-aligned)
+            if constexpr (VEC == 8) { const uint2 am = *reinterpret_cast<const uint2*>(argmax + off); aw[0] = am.x; aw[1] = am.y; }
+            else aw[0] = *reinterpret_cast<const uint32_t*>(argmax + off);
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
                 if (((aw[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)(kh * 3 + kw)) g[j] += d.v[j];
@@ -508,8 +515,10 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
                           const float* beta, float* running_mean, float* running_var,
                           long long* num_batches_tracked, void* y, float* save_mean, float* save_rstd,
                           float* workspace, int P, int C, float eps, float momentum, int relu,
-                          const float* pre_partials, int pre_nparts, const float* pre_shift, void* stream) {
+                          const float* pre_partials, int pre_nparts, const float* pre_shift, uint8_t* relu_bits,
+                          void* stream) {
     VTX_CHECK(x && gamma && beta && y && save_mean && save_rstd && workspace, VTX_ERR_ARG, "bn_fwd: null pointer");
+    VTX_CHECK(!relu_bits || (dtype == VTX_BF16 && relu), VTX_ERR_ARG, "bn_fwd: relu_bits needs bf16 and relu");
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_fwd: bad dtype %d", dtype);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_fwd: C=%d must be vec*2^k, P=%d > 0", C, P);
@@ -545,13 +554,13 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     if (dtype == VTX_BF16) {
         if (fwd_unr >= 2)
             VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t, 2>), dim3(apply_grid(vtx_cdiv(nvec, 2), C / vec)), dim3(256), 0, st, (const bf16_t*)x,
-                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
+                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, relu_bits, nvec, C, relu);
         else
             VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const bf16_t*)x,
-                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, nvec, C, relu);
+                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, relu_bits, nvec, C, relu);
     } else
         VTX_KLAUNCH("bn_fwd_apply", 0, 4.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<float, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const float*)x,
-                           (const float*)residual, save_mean, scale, beta, (float*)y, nvec, C, relu);
+                           (const float*)residual, save_mean, scale, beta, (float*)y, (uint8_t*)nullptr, nvec, C, relu);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -161,8 +161,8 @@ int launch_expand(const void* A, long lda, const void* W, long ldw, void* Y, lon
                   int M, int N, int nt_store, hipStream_t st) {
     const size_t lds = (size_t)EX_NB * K * 2 + (size_t)EX_WAVES * 16 * EX_ROWB;       // 66 / 98 KiB
     auto kern = expand1x1_fwd_kernel<K>;
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; }
+    // per device, and cheap: set on every call (a process may drive several GPUs); failure -> the tiled kernel takes the problem
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     const int nstrips = (M + 15) / 16;
     int gx = 256 * (K == 64 ? 2 : 1);                                     // one workgroup per resident slot of the chip
     if (gx * EX_WAVES > nstrips) gx = (nstrips + EX_WAVES - 1) / EX_WAVES;

@@ -71,11 +71,12 @@ void vtx_fill_bn_bwd(vtxg::EpiStore<bf16_t, vtxg::STATS_BWD>& ep, const VtxBnBwd
     ep.stat_parts = parts;
     ep.bn_x = (const bf16_t*)f->x; ep.ldx = ld;
     ep.bn_y = (const bf16_t*)f->ymask; ep.ldy = ld;
+    ep.bn_ybits = f->ybits;
     ep.bn_mean = f->mean; ep.bn_rstd = f->rstd; ep.bn_gamma = f->gamma; ep.bn_beta = f->beta;
 }
 int vtx_check_bn_bwd(const char* who, const VtxBnBwdFusion* f, int M, int N) {
     VTX_CHECK(f->x && f->mean && f->rstd && f->parts, VTX_ERR_ARG, "%s: BatchNorm fusion needs x, mean, rstd and parts", who);
-    VTX_CHECK(!(f->ymask && f->beta), VTX_ERR_ARG, "%s: pass either ymask or gamma/beta for the ReLU mask", who);
+    VTX_CHECK(!((f->ymask || f->ybits) && f->beta), VTX_ERR_ARG, "%s: pass either ymask / ybits or gamma/beta for the ReLU mask", who);
     VTX_CHECK(!f->beta || f->gamma, VTX_ERR_ARG, "%s: a recomputed mask needs gamma and beta", who);
     VTX_CHECK(N % 8 == 0 && ((uintptr_t)f->x & 15) == 0 && (!f->ymask || ((uintptr_t)f->ymask & 15) == 0), VTX_ERR_SHAPE,
               "%s: fused BatchNorm backward needs N %% 8 == 0 and 16-byte aligned tensors", who);

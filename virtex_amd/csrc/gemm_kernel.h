@@ -546,6 +546,8 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
     const float* stat_shift = nullptr;           // STATS_FWD
     const T* bn_x = nullptr; long ldx = 0;       // STATS_BWD: the BatchNorm's input, same [M][N] coordinates as `out`
     const T* bn_y = nullptr; long ldy = 0;       //            the post-ReLU block output (mask), or nullptr
+    const uint8_t* bn_ybits = nullptr;           //            the same mask as ONE BIT per element (byte (m*ldy + n)/8, bit e = column
+                                                 //            n+e > 0; written by vtx_bn_fwd): 1/16 of the bytes of bn_y; wins over bn_y
     const float* bn_mean = nullptr; const float* bn_rstd = nullptr;
     const float* bn_gamma = nullptr; const float* bn_beta = nullptr;   // mask recomputed from bn_x when bn_y == nullptr
     // ACT_SOFTMAX_GRAD (tied projection + cross-entropy backward: the logits are recomputed, never stored)
@@ -661,20 +663,28 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         } else {
             float x[EPV];
             unpack16<T>(*reinterpret_cast<const uint4*>(bn_x + mr * ldx + n), x);
-            if (bn_y) {
+            if (bn_ybits) {
+                static_assert(STATS_MODE != STATS_BWD || EPV == 8, "mask bits: one byte per 16-byte chunk (bf16)");
+                const uint32_t mb = bn_ybits[(mr * ldy + n) >> 3];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) f[e] = (mb >> e) & 1u ? f[e] : 0.f;
+            } else if (bn_y) {
                 float y[EPV];
                 unpack16<T>(*reinterpret_cast<const uint4*>(bn_y + mr * ldy + n), y);
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) f[e] = y[e] > 0.f ? f[e] : 0.f;
             }
-            const bool remask = !bn_y && bn_beta;
+            const bool remask = !bn_y && !bn_ybits && bn_beta;
+            float xh[EPV];
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
-                const float xh = x[e] * par[e] + par[PBN + e];
-                if (remask) f[e] = xh * par[2 * PBN + e] + par[3 * PBN + e] > 0.f ? f[e] : 0.f;
-                s1[e] += f[e]; s2[e] += f[e] * xh;
+                xh[e] = x[e] * par[e] + par[PBN + e];
+                if (remask) f[e] = xh[e] * par[2 * PBN + e] + par[3 * PBN + e] > 0.f ? f[e] : 0.f;
             }
             w = pack16<T>(f);
+            unpack16<T>(w, f);                   // sums of what is stored: bn_bwd_apply_fused combines them with the ROUNDED dz
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { s1[e] += f[e]; s2[e] += f[e] * xh[e]; }
         }
         if (nt) st16_nt(out + mr * ldc + n, u32x4_t{w.x, w.y, w.z, w.w});
         else *reinterpret_cast<uint4*>(out + mr * ldc + n) = w;
@@ -1309,7 +1319,7 @@ template <class EP> inline double epi_bytes(const EP&, double mn, int) { return 
 inline double epi_bytes(const EpiRowLse& e, double, int) { return 0.0; }     // the logits are never written
 template <class T, int S> inline double epi_bytes(const EpiStore<T, S>& e, double mn, int split_k) {
     return mn * sizeof(T) * (split_k > 1 ? split_k : 1) + (e.residual ? mn * sizeof(T) : 0.0) + (e.preact ? mn * sizeof(T) : 0.0) +
-           (e.bn_x ? mn * sizeof(T) : 0.0) + (e.bn_y ? mn * sizeof(T) : 0.0);
+           (e.bn_x ? mn * sizeof(T) : 0.0) + (e.bn_ybits ? mn / 8 : e.bn_y ? mn * sizeof(T) : 0.0);
 }
 
 // Outputs of at least VIRTEX_AMD_NT_STORE_MB megabytes (default 200; 0 = never) are stored non-temporally: they do not

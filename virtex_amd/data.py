@@ -184,8 +184,10 @@ class CaptionTokenCache:
 
     def __init__(self, tokenizer, captions: Sequence[str]):
         import numpy as np
-        self.plain = [np.asarray(tokenizer.encode(c), dtype=np.int16) for c in captions]
-        self.flipped = [np.asarray(tokenizer.encode(flip_caption(c)), dtype=np.int16) for c in captions]
+        vocab = tokenizer.get_vocab_size() if hasattr(tokenizer, "get_vocab_size") else None
+        dt = np.int16 if (vocab is not None and vocab <= 32767) else np.int32       # unknown or large vocabulary: no silent wrap
+        self.plain = [np.asarray(tokenizer.encode(c), dtype=dt) for c in captions]
+        self.flipped = [np.asarray(tokenizer.encode(flip_caption(c)), dtype=dt) for c in captions]
 
     def tokens(self, index: int, flipped: bool = False) -> List[int]:
         return (self.flipped if flipped else self.plain)[index].astype("int64").tolist()

@@ -94,12 +94,15 @@ def average_across_processes(t):
         t /= world_size()
         return t
     keys = sorted(t)
-    flat = torch.stack([t[k].detach().float().reshape(()) for k in keys])
+    flat = torch.cat([t[k].detach().float().reshape(-1) for k in keys])      # values of any shape, like the reference accepts
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= world_size()
     with torch.no_grad():
-        for i, k in enumerate(keys):
-            t[k].copy_(flat[i].to(t[k].dtype).reshape(t[k].shape))
+        o = 0
+        for k in keys:
+            n = t[k].numel()
+            t[k].copy_(flat[o:o + n].to(t[k].dtype).reshape(t[k].shape))
+            o += n
     return t
 
 

@@ -46,6 +46,11 @@ FUSE_STEM_TAIL = os.environ.get("VIRTEX_AMD_FUSE_STEM_TAIL", "0") != "0"
 # forward counterpart: BatchNorm + ReLU + max-pool of the stem in one pass, the 411 MB tensor between them never written
 # (bit-identical results; prepared at the end of round 2 on the emulator, to be measured on the GPU before it becomes default)
 FUSE_STEM_FWD = os.environ.get("VIRTEX_AMD_FUSE_STEM_FWD", "0") != "0"
+# The ReLU mask of a Bottleneck's output as one BIT per element, written by the BatchNorm + residual + ReLU pass that
+# produces the output: the fused BatchNorm backward in the next block's input-gradient epilogue reads 1/16 of the bytes
+# instead of the whole output tensor (2.8 GB of reads per step at bs 256; the output itself stays: it is the next
+# block's input).
+RELU_BITS = os.environ.get("VIRTEX_AMD_RELU_BITS", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------
@@ -358,7 +363,7 @@ from ..streams import branch_stream, wgrad_stream  # noqa: E402  (shared with th
 
 
 class _Saved:
-    __slots__ = ("a", "x", "y", "mean", "rstd", "wt")
+    __slots__ = ("a", "x", "y", "mean", "rstd", "wt", "bits")
 
 
 class _ResNetFn(torch.autograd.Function):
@@ -381,12 +386,19 @@ class _ResNetFn(torch.autograd.Function):
                 w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
                 # the conv epilogue also produces the batch statistics (taken against the running mean)
                 x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean if FUSE_BN_STATS else None)
-            y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                       bn.num_batches_tracked, eps=bn.eps,
-                                       momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
-                                       residual=residual, stats=stats)
+            bits = None
+            if residual is not None and relu and need_grad and RELU_BITS and FUSE_BN_BWD and dt == torch.bfloat16:
+                y, mean, rstd, bits = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                 bn.num_batches_tracked, eps=bn.eps,
+                                                 momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
+                                                 residual=residual, stats=stats, want_bits=True)
+            else:
+                y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                           bn.num_batches_tracked, eps=bn.eps,
+                                           momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
+                                           residual=residual, stats=stats)
             s = _Saved()
-            s.a, s.x, s.y, s.mean, s.rstd, s.wt = a, x, y, mean, rstd, wt
+            s.a, s.x, s.y, s.mean, s.rstd, s.wt, s.bits = a, x, y, mean, rstd, wt, bits
             rec[u] = s
             return y
 
@@ -398,7 +410,7 @@ class _ResNetFn(torch.autograd.Function):
                                                              bn.running_var, bn.num_batches_tracked, eps=bn.eps,
                                                              momentum=bn.momentum if bn.momentum is not None else 0.1)
             s0 = _Saved()
-            s0.a, s0.x, s0.y, s0.mean, s0.rstd, s0.wt = a0, x0, None, mean0, rstd0, None     # y: never materialised
+            s0.a, s0.x, s0.y, s0.mean, s0.rstd, s0.wt, s0.bits = a0, x0, None, mean0, rstd0, None, None     # y: never materialised
             rec[stem] = s0
             y = x0                                                          # only its shape is used below
         else:
@@ -511,7 +523,7 @@ class _ResNetFn(torch.autograd.Function):
             if fuse and bi > 0:
                 p3 = rec[blocks[bi - 1][2]]
                 dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join,
-                                        bn=ops.BnBwd(p3.x, p3.mean, p3.rstd, ymask=p3.y))
+                                        bn=ops.BnBwd(p3.x, p3.mean, p3.rstd, ymask=p3.y, ybits=p3.bits))
             else:
                 dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join), None
             # this block's gradient kernels are all enqueued: let the data-parallel engine start exchanging the

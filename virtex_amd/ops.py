@@ -126,16 +126,22 @@ class _BnBwdFusion(_lib.ctypes.Structure):
     """VtxBnBwdFusion of include/virtex_amd.h."""
     _fields_ = [("x", _lib.ctypes.c_void_p), ("ymask", _lib.ctypes.c_void_p), ("mean", _lib.ctypes.c_void_p),
                 ("rstd", _lib.ctypes.c_void_p), ("gamma", _lib.ctypes.c_void_p), ("beta", _lib.ctypes.c_void_p),
-                ("parts", _lib.ctypes.c_void_p), ("parts_cap", _lib.ctypes.c_long), ("strips", _lib.ctypes.c_int)]
+                ("parts", _lib.ctypes.c_void_p), ("parts_cap", _lib.ctypes.c_long), ("strips", _lib.ctypes.c_int),
+                ("ybits", _lib.ctypes.c_void_p)]
 
 
 class BnBwd:
     """What an input-gradient kernel needs to fuse the backward of the BatchNorm(+ReLU) that produced its input's
     gradient: that BatchNorm's input `x`, saved statistics, and the ReLU mask source -- `ymask` (post-ReLU block
-    output) or `gamma`/`beta` (mask recomputed from x) or neither (no ReLU)."""
+    output), `ybits` (the same mask, one bit per element, from bn_fwd(want_bits=True): 1/16 of the bytes) or
+    `gamma`/`beta` (mask recomputed from x) or none of them (no ReLU)."""
 
-    def __init__(self, x, mean, rstd, ymask=None, gamma=None, beta=None):
+    def __init__(self, x, mean, rstd, ymask=None, gamma=None, beta=None, ybits=None):
         self.x, self.mean, self.rstd, self.ymask, self.gamma, self.beta = x, mean, rstd, ymask, gamma, beta
+        self.ybits = ybits
+        if ybits is not None:
+            assert ybits.dtype == torch.uint8 and ybits.is_contiguous() and ybits.numel() * 8 == x.numel()
+            self.ymask = None
 
     def descriptor(self, rows, N, device):
         cap = ((rows + 63) // 64 + 4) * 2 * N
@@ -143,7 +149,8 @@ class BnBwd:
         d = _BnBwdFusion(self.x.data_ptr(), self.ymask.data_ptr() if self.ymask is not None else None,
                          self.mean.data_ptr(), self.rstd.data_ptr(),
                          self.gamma.data_ptr() if self.gamma is not None else None,
-                         self.beta.data_ptr() if self.beta is not None else None, parts.data_ptr(), cap, 0)
+                         self.beta.data_ptr() if self.beta is not None else None, parts.data_ptr(), cap, 0,
+                         self.ybits.data_ptr() if self.ybits is not None else None)
         return d, parts
 
 
@@ -268,7 +275,9 @@ def bn_workspace(device, C):
 
 
 def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, relu=True,
-           residual=None, stats=None):
+           residual=None, stats=None, want_bits=False):
+    """want_bits (bf16 + relu): also returns the ReLU mask as one bit per element (uint8 [numel/8]) -- what the
+    input-gradient epilogue of the NEXT block reads instead of the whole output tensor (BnBwd(ybits=...))."""
     C = x.shape[-1]
     P = x.numel() // C
     _chk(x, "x"); _chk(residual, "residual", x.dtype)
@@ -276,12 +285,16 @@ def bn_fwd(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.
     y = torch.empty_like(x)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    bits = None
+    if want_bits:
+        assert relu and x.dtype == torch.bfloat16 and x.numel() % 8 == 0
+        bits = torch.empty(x.numel() // 8, dtype=torch.uint8, device=x.device)
     call("vtx_bn_fwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(residual), ptr(gamma), ptr(beta),
          ptr(running_mean), ptr(running_var), ptr(nbt), ptr(y), ptr(mean), ptr(rstd), ptr(ws), c_int(P),
          c_int(C), c_float(eps), c_float(momentum), c_int(1 if relu else 0),
          ptr(stats.parts if stats else None), c_int(stats.strips if stats else 0),
-         ptr(stats.shift if stats else None), stream_ptr(x))
-    return y, mean, rstd
+         ptr(stats.shift if stats else None), ptr(bits), stream_ptr(x))
+    return (y, mean, rstd, bits) if want_bits else (y, mean, rstd)
 
 
 def bn_bwd(x, dy, ymask, gamma, mean, rstd, dgamma, dbeta, want_dz=False, relu_beta=None):
