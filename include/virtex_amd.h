@@ -204,7 +204,8 @@ int vtx_set_bn_apply_unroll(int vectors_per_thread);   /* measurement switch: 0 
 int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, long long* num_batches_tracked, void* pooled, uint8_t* argmax,
                        float* save_mean, float* save_rstd, float* workspace, int N, int H, int W, int C, float eps,
-                       float momentum, void* stream);
+                       float momentum, const float* pre_partials, int pre_nparts, const float* pre_shift /* as vtx_bn_fwd */,
+                       void* stream);
 int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, const uint8_t* argmax, const float* gamma,
                        const float* beta, const float* save_mean, const float* save_rstd, void* dx, float* dgamma,
                        float* dbeta, float* workspace, int N, int H, int W, int C, void* stream);

@@ -877,3 +877,47 @@ def test_stem_tail_forward_batchnorm_relu_maxpool_in_one_pass(backend, dtype, N,
         assert rel_err(pool_b.float().cpu(), pool_a.float().cpu()) < 1e-3
     assert torch.equal(mean_a.cpu(), mean_b.cpu()) and torch.equal(rstd_a.cpu(), rstd_b.cpu())
     assert torch.equal(rm1.cpu(), rm2.cpu()) and torch.equal(rv1.cpu(), rv2.cpu()) and int(nbt1) == int(nbt2) == 1
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("N,H", [(2, 40), (3, 38), (1, 46)])
+def test_stem_streaming_kernel_with_statistics(backend, N, H):
+    """stem.hip: the packed 7x8 / stride-2 stem convolution as a streaming kernel (filter resident in LDS, A fragments
+    straight from global memory, no K tiling) with the BatchNorm statistics of the STORED output -- against torch's 7x7
+    convolution of the 3-channel image, against the tiled kernel on the same operands, and the statistics against the
+    stored tensor; ragged strip counts (M not a multiple of 16 x waves), the fused stem tail fed with them."""
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(5 * N + H)
+    KO = 64
+    img = torch.randn(N, 3, H, H, generator=g)
+    w7 = torch.randn(KO, 3, 7, 7, generator=g) / 12
+    a0 = ops.image_to_nhwc(img.to(dev), dt, 4, halo=3)
+    wp = torch.zeros(KO, 7, 8, 4)
+    wp[:, :, :7, :3] = w7.permute(0, 2, 3, 1)
+    w = wp.to(dt).to(dev)
+    shift = (0.2 * torch.randn(KO, generator=g)).to(dev)
+    y, st = ops.conv2d_fwd(a0, w, 2, 0, bn_shift=shift)
+    OH = H // 2
+    assert y.shape == (N, OH, OH, KO) and st is not None and 0 < st.strips <= 512
+    yr = F.conv2d(img.to(dt).float(), w7.to(dt).float(), stride=2, padding=3).permute(0, 2, 3, 1)
+    assert rel_err(y.float().cpu(), yr) < 1e-2
+    tiled = ops.conv2d_fwd(a0, w, 2, 0)                       # no statistics requested: the tiled contraction kernel
+    assert rel_err(y.float().cpu(), tiled.float().cpu()) < 4e-3
+    parts = st.parts[: st.strips * 2 * KO].view(st.strips, 2, KO).cpu().double()
+    d = y.float().cpu().double().view(-1, KO) - shift.cpu().double()
+    assert rel_err(parts[:, 0].sum(0), d.sum(0)) < 1e-4 and rel_err(parts[:, 1].sum(0), (d * d).sum(0)) < 1e-4
+    # BatchNorm forward fed with them == BatchNorm forward reducing the stored tensor itself; the fused tail likewise
+    gamma = (0.5 + torch.rand(KO, generator=g)).to(dev); beta = (0.1 * torch.randn(KO, generator=g)).to(dev)
+    outs = []
+    for stats in (st, None):
+        rm, rv = shift.clone(), torch.ones(KO, device=dev)
+        out, mean, rstd = ops.bn_fwd(y, gamma, beta, rm, rv, None, stats=stats)
+        rm2, rv2 = shift.clone(), torch.ones(KO, device=dev)
+        pooled, arg, mean2, rstd2 = ops.bn_fwd_maxpool(y, gamma, beta, rm2, rv2, None, stats=stats)
+        assert torch.equal(mean.cpu(), mean2.cpu()) and torch.equal(rstd.cpu(), rstd2.cpu()) and torch.equal(rm.cpu(), rm2.cpu())
+        ref_pool, ref_arg = ops.maxpool_fwd(out)
+        assert torch.equal(pooled.cpu(), ref_pool.cpu()) and torch.equal(arg.cpu(), ref_arg.cpu())
+        outs.append((mean.cpu(), rstd.cpu(), rv.cpu()))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-5) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-4)
+    assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-4)

@@ -709,7 +709,8 @@ extern "C" int vtx_set_bn_apply_unroll(int n) {
 extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, long long* num_batches_tracked, void* pooled, uint8_t* argmax,
                                   float* save_mean, float* save_rstd, float* workspace, int N, int H, int W, int C, float eps,
-                                  float momentum, void* stream) {
+                                  float momentum, const float* pre_partials, int pre_nparts, const float* pre_shift,
+                                  void* stream) {
     VTX_CHECK(x && gamma && beta && pooled && argmax && save_mean && save_rstd && workspace, VTX_ERR_ARG, "bn_fwd_maxpool: null pointer");
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_fwd_maxpool: bad dtype %d", dtype);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
@@ -719,17 +720,20 @@ extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, 
     const int P = N * H * W, OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     float* scale = workspace; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(P, C, vec);
-    if (dtype == VTX_BF16)
+    const bool fused = pre_partials != nullptr && pre_nparts > 0;   // statistics came with the convolution's epilogue
+    VTX_CHECK(!fused || (pre_shift && pre_nparts <= 512), VTX_ERR_ARG, "bn_fwd_maxpool: fused statistics need their shift vector and <= 512 strips");
+    if (fused) { sums = const_cast<float*>(pre_partials); rp.gx = pre_nparts; }
+    else if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_fwd_reduce", 0, 2.0 * P * C, (bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
                     (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     else
         VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                     save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                     save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     const int cv = C / vec;
     int TX = 1; while (TX < cv && TX < 256) TX <<= 1;

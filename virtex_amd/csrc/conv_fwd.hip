@@ -7,6 +7,9 @@
 
 using namespace vtxg;
 
+int vtx_stem_stream_try(int N, int H, int W, int C, int KO, int R, int S, int stride, int pad, const void* x, const void* w,
+                        void* y, const float* shift, float* parts, hipStream_t st);
+
 template <class T>
 static int conv_fwd_t(const ConvGeo& g, const void* x, const void* w, void* y, const float* bias, const void* residual,
                       int act, float* stat_parts, const float* stat_shift, int* stat_strips, hipStream_t st) {
@@ -40,6 +43,11 @@ extern "C" int vtx_conv2d_fwd(int dtype, int N, int H, int W, int C, int KO, int
     int rc = make_geo("conv2d_fwd", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
     if (rc) return rc;
     if (bn_strips) *bn_strips = 0;
+    if (dtype == VTX_BF16 && bn_parts && bn_strips) {      // the packed stem: streaming kernel (stem.hip)
+        const int s = vtx_stem_stream_try(N, H, W, C, KO, R, S, stride, pad, x, w, y, bn_shift, bn_parts, (hipStream_t)stream);
+        if (s < 0) return s;
+        if (s > 0) { *bn_strips = s; return VTX_OK; }
+    }
     if (dtype == VTX_BF16) return conv_fwd_t<bf16_t>(g, x, w, y, nullptr, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
     return conv_fwd_t<float>(g, x, w, y, nullptr, nullptr, ACT_NONE, bn_parts, bn_shift, bn_strips, (hipStream_t)stream);
 }

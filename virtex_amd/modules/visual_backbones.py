@@ -51,6 +51,8 @@ FUSE_STEM_FWD = os.environ.get("VIRTEX_AMD_FUSE_STEM_FWD", "0") != "0"
 # instead of the whole output tensor (2.8 GB of reads per step at bs 256; the output itself stays: it is the next
 # block's input).
 RELU_BITS = os.environ.get("VIRTEX_AMD_RELU_BITS", "1") != "0"
+# the stem convolution's epilogue emits the BatchNorm statistics (streaming kernel, stem.hip)
+STEM_STATS = os.environ.get("VIRTEX_AMD_STEM_STATS", "1") != "0"
 
 
 # ----------------------------------------------------------------------------------------
@@ -316,6 +318,15 @@ def _prep_weight(u: _Unit, dtype, need_wt: bool):
     return w, wt
 
 
+def _stem_conv(u: _Unit, a, w, dt):
+    """The packed stem convolution; bf16: the streaming kernel also emits the BatchNorm statistics of its output
+    (stem.hip) -- `stats` is None when the tiled kernel ran instead (fp32, VIRTEX_AMD_STEM_STREAM=0)."""
+    if STEM_STATS and dt == torch.bfloat16:
+        x, stats = ops.conv2d_fwd(a, w, u.stride, 0, bn_shift=u.bn.running_mean)
+        return x, (stats if (stats is not None and stats.strips <= 512) else None)
+    return ops.conv2d_fwd(a, w, u.stride, 0), None
+
+
 def _conv_fwd(u: _Unit, x, w, bn_shift=None):
     """Returns (y, stats): `stats` are the BatchNorm statistics of y emitted by the convolution's own
     epilogue (None if not requested or the kernel that ran does not produce them -> stand-alone reduction)."""
@@ -381,7 +392,7 @@ class _ResNetFn(torch.autograd.Function):
             bn = u.bn
             if first and packed:
                 w, wt = _stem_weight(u, dt), None
-                x, stats = ops.conv2d_fwd(a, w, u.stride, 0), None
+                x, stats = _stem_conv(u, a, w, dt)
             else:
                 w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
                 # the conv epilogue also produces the batch statistics (taken against the running mean)
@@ -405,10 +416,11 @@ class _ResNetFn(torch.autograd.Function):
         a0, packed = _stem_input(image, dt)
         if FUSE_STEM_FWD and packed:
             bn = stem.bn
-            x0 = ops.conv2d_fwd(a0, _stem_weight(stem, dt), stem.stride, 0)
+            x0, stats0 = _stem_conv(stem, a0, _stem_weight(stem, dt), dt)
             pooled, argmax, mean0, rstd0 = ops.bn_fwd_maxpool(x0, bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                                                              bn.running_var, bn.num_batches_tracked, eps=bn.eps,
-                                                             momentum=bn.momentum if bn.momentum is not None else 0.1)
+                                                             momentum=bn.momentum if bn.momentum is not None else 0.1,
+                                                             stats=stats0)
             s0 = _Saved()
             s0.a, s0.x, s0.y, s0.mean, s0.rstd, s0.wt, s0.bits = a0, x0, None, mean0, rstd0, None, None     # y: never materialised
             rec[stem] = s0

@@ -324,7 +324,7 @@ def bn_bwd_fused(x, dz, gamma, mean, rstd, dgamma, dbeta, stats: "BnStats"):
     return dx
 
 
-def bn_fwd_maxpool(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
+def bn_fwd_maxpool(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, stats=None):
     """Stem tail forward: BatchNorm (training) + ReLU + MaxPool2d(3,2,1) in one pass; the normalised tensor is never
     written.  Returns (pooled, argmax, mean, rstd)."""
     N, H, W, C = x.shape
@@ -337,7 +337,8 @@ def bn_fwd_maxpool(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, mom
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
     call("vtx_bn_fwd_maxpool", c_int(dtype_code(x.dtype)), ptr(x), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
          ptr(nbt), ptr(y), ptr(arg), ptr(mean), ptr(rstd), ptr(ws), c_int(N), c_int(H), c_int(W), c_int(C), c_float(eps),
-         c_float(momentum), stream_ptr(x))
+         c_float(momentum), ptr(stats.parts if stats else None), c_int(stats.strips if stats else 0),
+         ptr(stats.shift if stats else None), stream_ptr(x))
     return y, arg, mean, rstd
 
 
