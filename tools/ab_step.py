@@ -1,0 +1,80 @@
+"""Step-level A/B inside ONE process: the bench step (bench.py's `step`) timed under several settings of the Python-level
+switches of virtex_amd.modules.visual_backbones / models, interleaved round after round (the boxes of the pool differ by
++-0.3 ms and drift with temperature: only interleaved rounds in one process decide anything below 1 %).
+
+    python tools/ab_step.py [--steps 20] [--rounds 3] [--batch 256] name[:FLAG=v,FLAG=v] ...
+
+FLAG is an attribute of visual_backbones (FUSE_STEM_FWD, RELU_BITS, STEM_STATS, ...) or `models.X` / `textual.X`.
+Prints per variant: every round's ms/step, the minimum and the median."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--visual", default="torchvision::resnet50")
+    ap.add_argument("--textual", default="transdec_postnorm::L1_H1024_A16_F4096")
+    ap.add_argument("variants", nargs="+")
+    a = ap.parse_args()
+    import virtex_amd.factories as vf
+    from virtex_amd import distributed as vd, models
+    from virtex_amd.modules import textual_heads, visual_backbones as vb
+    from virtex_amd.optim import FusedPretrainOptimizer
+    from virtex_amd.synthetic import synthetic_batch
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = vf.build_bicaptioning_model(visual=a.visual, textual=a.textual, dropout=0.1, compute_dtype=torch.bfloat16).to(dev).train()
+    buckets = vd.GradientBuckets(model)
+    opt = FusedPretrainOptimizer(model, buckets, start_step=100)
+    batches = [synthetic_batch(a.batch, dev, image_size=224, max_len=30, vocab_size=10000, seed=i) for i in range(2)]
+
+    def step(i):
+        buckets.zero(); buckets.begin()
+        out = model(batches[i % 2])
+        out["loss"].backward()
+        opt.step(grad_scale=buckets.finish())
+
+    mods = {"models": models, "textual": textual_heads}
+    variants = []
+    for v in a.variants:
+        name, _, flags = v.partition(":")
+        kv = []
+        for f in filter(None, flags.split(",")):
+            k, val = f.split("=")
+            mod, attr = (mods[k.split(".")[0]], k.split(".")[1]) if "." in k else (vb, k)
+            kv.append((mod, attr, type(getattr(mod, attr))(int(val))))
+        variants.append((name, kv))
+    defaults = {(m, k): getattr(m, k) for _, kv in variants for m, k, _ in kv}
+    res = {n: [] for n, _ in variants}
+    for r in range(a.rounds):
+        for name, kv in variants:
+            for (m, k), d in defaults.items():
+                setattr(m, k, d)
+            for m, k, val in kv:
+                setattr(m, k, val)
+            for i in range(a.warmup):
+                step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(a.steps):
+                step(i)
+            torch.cuda.synchronize()
+            res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
+    for name, _ in variants:
+        v = sorted(res[name])
+        print(f"{name:28s} " + " ".join(f"{x:7.3f}" for x in res[name]) + f"   min {v[0]:7.3f}  median {v[len(v) // 2]:7.3f} ms/step", flush=True)
+
+
+if __name__ == "__main__":
+    main()
