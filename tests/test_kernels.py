@@ -921,3 +921,29 @@ def test_stem_streaming_kernel_with_statistics(backend, N, H):
         outs.append((mean.cpu(), rstd.cpu(), rv.cpu()))
     assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5, rtol=1e-5) and torch.allclose(outs[0][1], outs[1][1], rtol=1e-4)
     assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-4)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("N,H,W,C,KO", [(2, 9, 9, 64, 64), (3, 14, 14, 128, 64), (1, 7, 7, 64, 128), (2, 30, 30, 64, 64),
+                                        (2, 6, 11, 64, 64), (5, 3, 3, 128, 128)])
+def test_conv3x3_wgrad_streaming_kernel(backend, N, H, W, C, KO):
+    """conv3x3_wgrad.hip: the 3x3 / stride-1 / pad-1 weight gradient as a streaming kernel over the padded-linear pixel
+    index (every tap a constant shift of ONE ring of x rows in LDS, dy shared by the nine taps, 64 x 9 x 64 accumulators
+    per workgroup) -- against torch's convolution backward, against the implicit-GEMM kernel (explicit split_k selects
+    it), accumulation into a non-zero gradient, several (ko, c) chunk pairs, non-square images, ranges that end in the
+    middle of an image."""
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(N * H + C + W)
+    x = torch.randn(N, H, W, C, generator=g).to(dt); dy = torch.randn(N, H, W, KO, generator=g).to(dt)
+    wr = torch.zeros(KO, C, 3, 3, requires_grad=True)
+    F.conv2d(x.float().permute(0, 3, 1, 2), wr, stride=1, padding=1).backward(dy.float().permute(0, 3, 1, 2))
+    ref = wr.grad.permute(0, 2, 3, 1)
+    dw0 = torch.randn(KO, 3, 3, C, generator=g)
+    ops.profile_start()
+    dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), 1, 1)
+    recs = ops.profile_stop()
+    assert any("conv3x3_wgrad_stream" in r["name"] and r["launches"] == 1 for r in recs), [r["name"] for r in recs]
+    assert rel_err(dw.cpu() - dw0, ref) < 1e-5                  # bf16 products are exact in fp32: only the summation order differs
+    old = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), 1, 1, split_k=2)
+    assert rel_err(dw.cpu(), old.cpu()) < 1e-5

@@ -235,7 +235,9 @@ def test_small_model_fp32_emulator():
 @pytest.mark.parametrize("case", ["r50_l2_h128_b3_small", "r50_l1_h1024_b2_full", "r50_l1_h1024_b2_ragged"])
 def test_model_fp32_gpu(case):
     dev = select("gpu")
-    _check(case, dev, torch.float32, text_tol=1e-3, loss_tol=1e-5, cnn_factor=None, cnn_floor=None)
+    # the 3-image 64x64 toy is the emulator's case run on hardware: the toy's floor (see _check); the 224x224 cases: the rule
+    toy = case == "r50_l2_h128_b3_small"
+    _check(case, dev, torch.float32, text_tol=1e-3, loss_tol=1e-5, cnn_factor=4.0 if toy else None, cnn_floor=1.5e-2 if toy else None)
 
 
 @pytest.mark.gpu

@@ -64,11 +64,15 @@ def _compile_all(compiler, flags, objdir, hdr_mtime, verbose):
     return objs, bool(jobs)
 
 
-def build_hip(verbose=False) -> str:
-    objs, changed = _compile_all(HIPCC, HIP_FLAGS, os.path.join(LIB_DIR, "obj"), _deps_mtime(), verbose)
-    if changed or not os.path.exists(LIB_PATH):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
-    return LIB_PATH
+def build_hip(verbose=False, variant=None, extra_flags=()) -> str:
+    """variant / extra_flags: an A/B build next to the product library (libvirtex_amd_<variant>.so, own object
+    directory; selected at run time with VIRTEX_AMD_LIB) -- measurement sessions only."""
+    lib = LIB_PATH if not variant else os.path.join(LIB_DIR, f"libvirtex_amd_{variant}.so")
+    objdir = os.path.join(LIB_DIR, "obj" if not variant else f"obj_{variant}")
+    objs, changed = _compile_all(HIPCC, HIP_FLAGS + list(extra_flags), objdir, _deps_mtime(), verbose)
+    if changed or not os.path.exists(lib):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 def build_emu(verbose=False) -> str:
@@ -90,8 +94,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--emu", action="store_true")
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--variant", default=None, help="A/B build: libvirtex_amd_<variant>.so")
+    ap.add_argument("--define", action="append", default=[], help="extra -D for an A/B build")
     a = ap.parse_args()
-    path = build_emu(a.verbose) if a.emu else build_hip(a.verbose)
+    path = build_emu(a.verbose) if a.emu else build_hip(a.verbose, a.variant, ["-D" + d for d in a.define])
     print(path)
 
 

@@ -8,6 +8,9 @@
 
 using namespace vtxg;
 
+int vtx_conv3x3_wgrad_try(int N, int H, int W, int C, int KO, int R, int S, int stride, int pad, const void* x, const void* dy,
+                          float* dw, float* ws, long ws_floats, hipStream_t st);
+
 template <class T>
 static int conv_wgrad_t(const ConvGeo& g, const void* x, const void* dy, float* dw, int split_k, float* ws,
                         long ws_floats, hipStream_t st) {
@@ -33,6 +36,11 @@ extern "C" int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, i
     ConvGeo g;
     int rc = make_geo("conv2d_wgrad", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
     if (rc) return rc;
+    if (dtype == VTX_BF16 && split_k <= 0) {             // 3x3 / stride 1: the streaming kernel (conv3x3_wgrad.hip)
+        const int r = vtx_conv3x3_wgrad_try(N, H, W, C, KO, R, S, stride, pad, x, dy, dw, workspace, workspace_floats, (hipStream_t)stream);
+        if (r < 0) return r;
+        if (r > 0) return VTX_OK;
+    }
     if (dtype == VTX_BF16) return conv_wgrad_t<bf16_t>(g, x, dy, dw, split_k, workspace, workspace_floats, (hipStream_t)stream);
     return conv_wgrad_t<float>(g, x, dy, dw, split_k, workspace, workspace_floats, (hipStream_t)stream);
 }

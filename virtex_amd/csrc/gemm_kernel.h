@@ -1066,6 +1066,15 @@ template <int ROWS, int NW, class L, int BK = 32> struct DmaStager {
             return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
         }
     }
+    // k-major images inside the DMA pipeline: the two transposing reads of a fragment as asm statements (vtx_ds_read_tr16:
+    // the builtin makes hipcc drain every LDS-DMA in flight before the first fragment read of each K step).  The caller
+    // issues all fragments of the step, then vtx_ds_tr_wait(), then combines the halves.
+    __device__ static __forceinline__ void frag_tr(const bf16_t* tile, int r0, int lane, vtx_v4s_t (&out)[2]) {
+        static_assert(MC, "transposing reads belong to k-major images");
+        const int w = lane & 15, ka = 8 * (lane >> 4) + (w >> 2), rr = r0 + 4 * (w & 3);
+        out[0] = vtx_ds_read_tr16(tile + ka * ROWS + swz_mc<ROWS>(rr >> 3, ka) * 8 + (rr & 7));
+        out[1] = vtx_ds_read_tr16(tile + (ka + 4) * ROWS + swz_mc<ROWS>(rr >> 3, ka + 4) * 8 + (rr & 7));
+    }
 };
 
 // Block = WM x WN waves; block tile BM x BN; wave tile (BM/WM) x (BN/WN).  Large tiles matter for the
@@ -1163,7 +1172,19 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
 #pragma unroll
             for (int h = 0; h < BK / 32; ++h) {
                 bf16x8_t fa[MT], fb[NT];
-                if (!(abl & 2) || kt == kt0) {
+                static_assert(SA::MC == SB::MC, "operand pairs are both row-major or both k-major");
+                if constexpr (SA::MC) {
+                    vtx_v4s_t ra[MT][2], rb[NT][2];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) SA::frag_tr(cur, wm * WTM + i * 16, lane, ra[i]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) SB::frag_tr(cur + BM * BK, wn * WTN + j * 16, lane, rb[j]);
+                    vtx_ds_tr_wait();
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa[i] = __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb[j] = __builtin_shufflevector(rb[j][0], rb[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                } else if (!(abl & 2) || kt == kt0) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) fa[i] = SA::frag(cur, wm * WTM + i * 16, lane, h);
 #pragma unroll

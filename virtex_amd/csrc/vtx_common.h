@@ -85,6 +85,34 @@ __device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------
+// ds_read_b64_tr_b16 (the transposing LDS read that feeds MFMA fragments from k-major images) in kernels that also have
+// LDS-DMA (buffer_load ... lds) in flight.  hipcc (ROCm 7.2) treats the BUILTIN as a read of unknown LDS memory and puts
+// `s_waitcnt vmcnt(0)` in front of the first one after every DMA issue: the whole prefetch pipeline is drained once per K
+// step (found in round 3 in every k-major instantiation of the contraction kernel: the weight gradients).  An asm
+// statement is invisible to that pass; the price is that hipcc does not count it either -- the caller issues all reads
+// of a step into SEPARATE result variables, then vtx_ds_tr_wait() (s_waitcnt lgkmcnt(0) + a scheduling barrier), and only
+// then touches the results (cdna_hip_programming.md 5.7 form (iii), rule 18).  The emulator build keeps the builtin.
+// ---------------------------------------------------------------------------------------
+typedef short vtx_v4s_t __attribute__((ext_vector_type(4)));
+#if defined(HIPEMU) || defined(VTX_TR_BUILTIN)      // VTX_TR_BUILTIN: A/B builds only (the drained pipeline of rounds 1-2)
+__device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vtx_v4s_t*)p);
+}
+__device__ __forceinline__ void vtx_ds_tr_wait() {}
+#else
+__device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
+    vtx_v4s_t r;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ void vtx_ds_tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+#endif
+
 template <class T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int VEC = 4;  // elements per 16-byte access
