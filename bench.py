@@ -169,6 +169,9 @@ def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1):
     f_mfma, f_hbm = tf / peak_tf, tbs / PEAK_HBM_TBS
     bound = "mfma" if f_mfma >= f_hbm else "hbm"
     traffic = TRAFFIC_PER_LAUNCH.get(dom["name"]) if default_workload else None
+    if default_workload and traffic is None:
+        print(f"bench.py: WARNING -- no PMC traffic entry for the dominant kernel {dom['name']!r}: re-run the FETCH_SIZE / "
+              "WRITE_SIZE passes (tools/round_end.sh) and add it to TRAFFIC_PER_LAUNCH; reporting traffic = null", file=sys.stderr)
     out = {"bound": bound, "kernel": dom["name"],
            "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": peak_tf if bound == "mfma" else PEAK_HBM_TBS * 1e3,
            "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(max(f_mfma, f_hbm), 4),
@@ -189,6 +192,14 @@ def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1):
         o = fam.setdefault(f, {"ms_per_step": 0.0, "bytes": 0.0, "flops": 0.0, "seconds": 0.0})
         o["ms_per_step"] += ms; o["bytes"] += r["bytes"]; o["flops"] += r["flops"]; o["seconds"] += r["seconds"]
     out["hbm_kernels"] = dict(sorted(hbm.items(), key=lambda kv: -kv[1]["ms_per_step"]))
+    # every contraction class (one per kernel instantiation): MFMA utilisation next to the HBM fraction
+    mk = {}
+    for r in by_name.values():
+        if (r["contraction"] or r["flops"] > 0) and r["seconds"] > 0:      # incl. the streaming MFMA kernels (expand / stem / 3x3 weight gradient)
+            mk[r["name"]] = {"launches_per_step": r["launches"] // survey_steps, "ms_per_step": round(r["seconds"] / survey_steps * 1e3, 3),
+                             "TFLOP/s": round(r["flops"] / r["seconds"] / 1e12, 1), "mfma_frac": round(r["flops"] / r["seconds"] / 1e12 / peak_tf, 4),
+                             "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1), "hbm_frac": round(r["bytes"] / r["seconds"] / 1e12 / PEAK_HBM_TBS, 4)}
+    out["mfma_kernels"] = dict(sorted(mk.items(), key=lambda kv: -kv[1]["ms_per_step"]))
     out["families"] = {k: {"ms_per_step": round(v["ms_per_step"], 3), "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1) if v["seconds"] else 0.0,
                            "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 1) if v["seconds"] else 0.0}
                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
@@ -336,6 +347,15 @@ def main(argv=None, device=None, backend=None):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = loss.item()
+    # the part of the gradient exchange the backward pass did not hide (events around finish()'s wait), per rank
+    comm_exposed = buckets.comm_exposed_ms(last=a.steps)
+    if world > 1:
+        ce = torch.tensor([comm_exposed if comm_exposed is not None else -1.0], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(ce) for _ in range(world)]
+        torch.distributed.all_gather(gathered, ce)
+        comm_exposed = [round(g.item(), 3) for g in gathered]
+    elif comm_exposed is not None:
+        comm_exposed = [round(comm_exposed, 3)]
 
     # ---- roofline leg.  EVERY rank runs the same further steps (a step contains the gradient all-reduces: a rank
     # stepping alone would wait for its peers forever); only rank 0 attaches events and reports.
@@ -407,6 +427,11 @@ def main(argv=None, device=None, backend=None):
                                    f"{a.dropout}", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
         }
+        if comm_exposed is not None:
+            rec["data_parallel"] = {"comm_exposed_ms_per_rank": comm_exposed, "payload": buckets.payload,
+                                    "buckets_mb": [round((e - s0) * 4 / 2 ** 20, 1) for (s0, e, _) in buckets.buckets],
+                                    "note": "GPU time the compute stream waited in GradientBuckets.finish() for the outstanding "
+                                            "all-reduces, mean over the timed steps"}
         if gflop:
             tf = ips * gflop / 1e3
             rec["step_mfma"] = {"gflop_per_image": gflop, "achieved_tflops": round(tf, 1),

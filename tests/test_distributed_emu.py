@@ -36,7 +36,8 @@ model = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=torch.float32, **
 model.load_state_dict(oracle_model.state_dict())
 model = model.to(dev).train()
 vd.broadcast_parameters(model)
-buckets = vd.GradientBuckets(model, bucket_mb=2.0)
+buckets = vd.GradientBuckets(model, bucket_mb=2.0, payload=os.environ["VTX_PAYLOAD"])
+assert buckets.buckets[-1][1] - buckets.buckets[-1][0] <= 2.0 * (1 << 20) / 4 / 2 + 1      # the tail bucket (closes last, exposed) is small
 batch = synth.synthetic_batch(seed=40 + rank, **bk)
 buckets.zero(); buckets.begin()
 model({k: v.to(dev) for k, v in batch.items()})["loss"].backward()
@@ -55,13 +56,17 @@ def _free_port():
 
 
 @pytest.mark.emu
-def test_two_ranks_real_modules_average_matches_oracle(tmp_path):
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_two_ranks_real_modules_average_matches_oracle(tmp_path, payload):
+    """payload = bf16: every bucket is rounded to bf16 before the exchange, summed in bf16 and widened back (half the
+    xGMI bytes): per-tensor error of the averaged gradient <= 4e-3 on top of the fp32 path's."""
     port_no = _free_port()
     out_base = str(tmp_path / "rank")
     procs = []
     for r in range(2):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
-                   VTX_ROOT=ROOT, VTX_KW=json.dumps(KW), VTX_BK=json.dumps(BK), VTX_OUT=out_base, OMP_NUM_THREADS="2")
+                   VTX_ROOT=ROOT, VTX_KW=json.dumps(KW), VTX_BK=json.dumps(BK), VTX_OUT=out_base, OMP_NUM_THREADS="2",
+                   VTX_PAYLOAD=payload)
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
     outs = []
     for r, p in enumerate(procs):
@@ -91,6 +96,6 @@ def test_two_ranks_real_modules_average_matches_oracle(tmp_path):
                 cnn_err.append(ne)
             else:
                 worst_text = max(worst_text, e, ne)
-    assert worst_text < 1e-3, worst_text
+    assert worst_text < (1e-3 if payload == "fp32" else 5e-3), worst_text
     cnn_err.sort()
     assert cnn_err[len(cnn_err) // 2] < 3e-2 and cnn_err[-1] < 0.3, (cnn_err[len(cnn_err) // 2], cnn_err[-1])   # BN conditioning

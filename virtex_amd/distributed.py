@@ -57,14 +57,30 @@ def init_process_group(backend: Optional[str] = None) -> int:
         os.environ.setdefault("RANK", "0")
     if world > 1 or _forced() is not None:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "23456")
+        if "MASTER_PORT" not in os.environ:
+            # several ranks must agree on the port: the launcher's job (torchrun sets it); the reference's default
+            # (tcp://127.0.0.1:23456, virtex/utils/distributed.py:20) is the fallback.  A single forced rank has nobody
+            # to agree with: any free port, so that two such processes on one host never collide.
+            os.environ["MASTER_PORT"] = str(_free_port()) if world == 1 else "23456"
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RCCL's kernels share the CUs with three busy compute streams: VIRTEX_AMD_RCCL_MAX_CHANNELS caps the number of
+        # channels (= workgroups) a collective may occupy (NCCL_MAX_NCHANNELS, read by RCCL at communicator creation)
+        ch = os.environ.get("VIRTEX_AMD_RCCL_MAX_CHANNELS")
+        if ch:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", ch)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
     return local_rank
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def world_size() -> int:
@@ -151,17 +167,34 @@ class GradientBuckets:
     (half the xGMI bytes: 138.9 instead of 277.9 MB per step) and widens the summed result back into the fp32 buffer
     -- the sum of N bf16-rounded gradients carries a relative error of ~2^-9/sqrt(3) per element (tests/test_distributed.py)."""
 
-    def __init__(self, model: torch.nn.Module, bucket_mb: float = 64.0, payload: Optional[str] = None):
+    def __init__(self, model: torch.nn.Module, bucket_mb: float = 64.0, payload: Optional[str] = None,
+                 tail_mb: Optional[float] = None):
+        """tail_mb: the LAST bucket closes with the last gradient of the backward pass (the stem's), so its all-reduce
+        is fully exposed: it is cut off as its own small bucket of at most `tail_mb` megabytes (default 8, never more
+        than bucket_mb / 2; VIRTEX_AMD_DP_TAIL_MB) -- for ResNet-50 that is the stem + layer1 + layer2 (5.8 MB), while
+        the bulk of the ResNet's gradient goes out with the previous bucket under the early stages' backward."""
         params = [p for p in execution_order(model) if p.requires_grad]
         self.params = params
         dev = params[0].device
         total = sum(p.numel() for p in params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         cap = int(bucket_mb * (1 << 20) / 4)
+        if tail_mb is None:
+            tail_mb = float(os.environ.get("VIRTEX_AMD_DP_TAIL_MB", "8"))
+        tail_cap = int(min(tail_mb, bucket_mb / 2) * (1 << 20) / 4)
+        tail_first, acc = len(params), 0            # index of the first parameter of the tail bucket
+        for i in range(len(params) - 1, 0, -1):
+            if acc + params[i].numel() > tail_cap:
+                break
+            acc += params[i].numel()
+            tail_first = i
         self.buckets = []          # (start, end, n_params)
         self.bucket_of = {}
         off, bstart, bcount = 0, 0, 0
-        for p in params:
+        for i, p in enumerate(params):
+            if i == tail_first and bcount:          # close the bucket in front of the tail
+                self.buckets.append((bstart, off, bcount))
+                bstart, bcount = off, 0
             n = p.numel()
             if p.dim() == 4 and p.stride(1) == 1 and p.shape[1] > 1:
                 # conv master weights are stored (KO,R,S,C): give the gradient the same layout
@@ -179,6 +212,7 @@ class GradientBuckets:
         if bcount:
             self.buckets.append((bstart, off, bcount))
         self.pending = [0] * len(self.buckets)
+        self.exposed = []            # (event before, event after) the compute stream's wait for the collectives, per step
         self.early = set()           # parameters announced by gradsink.mark_ready() in the current step
         self.last_early = 0
         self.handles = []
@@ -277,7 +311,16 @@ class GradientBuckets:
                     h.wait()
                 for (_, chunk, wire) in self.widen:
                     chunk.copy_(wire)               # bf16 sum -> the fp32 buffer the optimizer reads
-            torch.cuda.current_stream().wait_stream(self.side)
+            # how long the compute stream sits in this wait = the part of the gradient exchange the backward pass did NOT
+            # hide; two events per step, read (and synchronised) only by comm_exposed_ms()
+            cur = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            cur.wait_stream(self.side)
+            e1.record(cur)
+            self.exposed.append((e0, e1))
+            if len(self.exposed) > 4096:
+                del self.exposed[:2048]
         else:
             for h in self.handles:
                 h.wait()
@@ -286,3 +329,17 @@ class GradientBuckets:
         self.last_early = len(self.early)    # how many gradients were announced from inside a backward node (diagnostic)
         self.begin()                    # armed for the next backward
         return 1.0 / self.world
+
+    def comm_exposed_ms(self, last: Optional[int] = None, reset: bool = True) -> Optional[float]:
+        """Mean time per step the compute stream waited in finish() for the outstanding all-reduces (GPU time between
+        two events around the wait) over the last `last` recorded steps (all if None); None when nothing was recorded
+        (single process, CPU).  Synchronises the device: call it outside the timed region."""
+        ev = self.exposed[-last:] if last else self.exposed
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        if reset:
+            self.exposed = []
+        return ms
+
