@@ -42,6 +42,10 @@ const char* vtx_last_error(void); /* thread-local */
 int vtx_set_contraction_generation(int gen);
 int vtx_set_ablation(int bits);        /* measurement only (tools/ablate_gemm.py) */
 int vtx_set_tile_override(int cand);   /* tests: force a block tile; -1 = automatic */
+/* Measurement switches of the specialised kernels, by name: "wgrad3x3" (0 off, 1 by image size, 2 always), "stem_stream",
+ * "expand1x1" (0 / 1), "splitk_blocks" (block target of the split-K weight gradients, default 512).  Defaults come from
+ * VIRTEX_AMD_WGRAD3X3 / _STEM_STREAM / _EXPAND1X1 / _SPLITK_BLOCKS.  No reference counterpart. */
+int vtx_set_switch(const char* name, int value);
 /* Which contraction kernel this thread's last GEMM-shaped launch ran on: 2 = the DMA kernel (operands addressed through
  * buffer descriptors: needs bf16, operands < 2 GB, convolution channel counts that are multiples of the 32-deep K step),
  * 1 = the register-staged kernel (fp32, and everything the DMA kernel does not take).  Tests use it to prove coverage. */

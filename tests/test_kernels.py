@@ -940,9 +940,15 @@ def test_conv3x3_wgrad_streaming_kernel(backend, N, H, W, C, KO):
     F.conv2d(x.float().permute(0, 3, 1, 2), wr, stride=1, padding=1).backward(dy.float().permute(0, 3, 1, 2))
     ref = wr.grad.permute(0, 2, 3, 1)
     dw0 = torch.randn(KO, 3, 3, C, generator=g)
-    ops.profile_start()
-    dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), 1, 1)
-    recs = ops.profile_stop()
+    import ctypes
+    from virtex_amd import _lib
+    _lib.call("vtx_set_switch", b"wgrad3x3", ctypes.c_int(2))           # 2 = every image size (default 1: only >= 28x28)
+    try:
+        ops.profile_start()
+        dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), 1, 1)
+        recs = ops.profile_stop()
+    finally:
+        _lib.call("vtx_set_switch", b"wgrad3x3", ctypes.c_int(1))
     assert any("conv3x3_wgrad_stream" in r["name"] and r["launches"] == 1 for r in recs), [r["name"] for r in recs]
     assert rel_err(dw.cpu() - dw0, ref) < 1e-5                  # bf16 products are exact in fp32: only the summation order differs
     old = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), 1, 1, split_k=2)

@@ -362,12 +362,16 @@ def test_other_backbones_every_gradient_fp32_gpu(visual, textual):
             assert rel_err(p.grad.cpu(), q.grad) < 1e-3, n
     assert len(rows) >= 150
     summary = backbone_rule(rows)
-    _dump_rows(f"parity_fp32_b8_{visual.split('::')[1]}.json", summary, rows)
+    worst_buf = ("", 0.0)
     for (n, b), (_, c) in zip(model.named_buffers(), om.named_buffers()):
         if b.dtype.is_floating_point:
-            assert rel_err(b.cpu(), c) < 1e-4, n
+            e = rel_err(b.cpu(), c)
+            worst_buf = max(worst_buf, (n, e), key=lambda t: t[1])
         else:
             assert int(b) == int(c), n
+    summary["worst_running_statistic"] = worst_buf
+    _dump_rows(f"parity_fp32_b8_{visual.split('::')[1]}.json", summary, rows)
+    assert worst_buf[1] < 1e-3, worst_buf          # BatchNorm running statistics after the step: the north-star bound
 
 
 def _train_then_eval(dev, steps=2):

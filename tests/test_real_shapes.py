@@ -55,15 +55,20 @@ def test_pointwise_input_gradient_with_fused_batchnorm_backward_at_56x56():
     assert rel_err(dz.float().cpu(), dz_ref) < 5e-3
     xh = (x.float() - mean) * rstd
     parts = st.parts[: st.strips * 2 * N].view(st.strips, 2, N).double().cpu()
-    assert rel_err(parts[:, 0].sum(0), dz_ref.double().sum(0)) < 2e-3
-    assert rel_err(parts[:, 1].sum(0), (dz_ref.double() * xh.double()).sum(0)) < 2e-3
+    # the sums are taken of the STORED (bf16-rounded) gradient -- what bn_bwd_fused combines them with -- so they match
+    # the stored tensor to fp32 summation accuracy and the fp32 reference to bf16 rounding of 800k terms per channel
+    dzq = dz.float().cpu().double()
+    assert rel_err(parts[:, 0].sum(0), dzq.sum(0)) < 1e-4
+    assert rel_err(parts[:, 1].sum(0), (dzq * xh.double()).sum(0)) < 1e-4
+    assert rel_err(parts[:, 0].sum(0), dz_ref.double().sum(0)) < 5e-3
+    assert rel_err(parts[:, 1].sum(0), (dz_ref.double() * xh.double()).sum(0)) < 5e-3
     gamma = 0.5 + torch.rand(N, generator=g)
     dgamma = torch.zeros(N, device=dev); dbeta = torch.zeros(N, device=dev)
     dx = ops.bn_bwd_fused(x.to(dev), dz, gamma.to(dev), mean.to(dev), rstd.to(dev), dgamma, dbeta, st)
     s1, s2 = dz_ref.sum(0), (dz_ref * xh).sum(0)
     dx_ref = gamma * rstd * (dz_ref - s1 / M - xh * s2 / M)
     assert rel_err(dx.float().cpu(), dx_ref) < 1e-2
-    assert rel_err(dgamma.cpu(), s2) < 2e-3 and rel_err(dbeta.cpu(), s1) < 2e-3
+    assert rel_err(dgamma.cpu(), s2) < 5e-3 and rel_err(dbeta.cpu(), s1) < 5e-3
 
 
 def test_conv3x3_at_28x28_forward_dgrad_wgrad():

@@ -45,20 +45,39 @@ def main():
         out["loss"].backward()
         opt.step(grad_scale=buckets.finish())
 
+    import ctypes
+    from virtex_amd import _lib
+
+    class _Switch:                      # `sw.NAME=v`: vtx_set_switch of the library loaded at that moment; `lib=PATH`: which library
+        pass
+    default_lib = os.environ.get("VIRTEX_AMD_LIB", _lib.DEFAULT_LIB)
     mods = {"models": models, "textual": textual_heads}
     variants = []
     for v in a.variants:
         name, _, flags = v.partition(":")
-        kv = []
+        kv, sw, lib = [], [], default_lib
         for f in filter(None, flags.split(",")):
             k, val = f.split("=")
-            mod, attr = (mods[k.split(".")[0]], k.split(".")[1]) if "." in k else (vb, k)
-            kv.append((mod, attr, type(getattr(mod, attr))(int(val))))
-        variants.append((name, kv))
-    defaults = {(m, k): getattr(m, k) for _, kv in variants for m, k, _ in kv}
-    res = {n: [] for n, _ in variants}
+            if k == "lib":
+                lib = val if os.path.isabs(val) else os.path.join(os.path.dirname(_lib.DEFAULT_LIB), val)
+            elif k.startswith("sw."):
+                sw.append((k[3:], int(val)))
+            else:
+                mod, attr = (mods[k.split(".")[0]], k.split(".")[1]) if "." in k else (vb, k)
+                kv.append((mod, attr, type(getattr(mod, attr))(int(val))))
+        variants.append((name, kv, sw, lib))
+    defaults = {(m, k): getattr(m, k) for _, kv, _, _ in variants for m, k, _ in kv}
+    sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512}
+    res = {n: [] for n, _, _, _ in variants}
     for r in range(a.rounds):
-        for name, kv in variants:
+        for name, kv, sw, lib in variants:
+            torch.cuda.synchronize()
+            _lib.use_library(lib)
+            for k, d in sw_defaults.items():
+                if hasattr(_lib.lib(), "vtx_set_switch"):
+                    _lib.lib().vtx_set_switch(k.encode(), ctypes.c_int(d))
+            for k, val in sw:
+                _lib.call("vtx_set_switch", k.encode(), ctypes.c_int(val))
             for (m, k), d in defaults.items():
                 setattr(m, k, d)
             for m, k, val in kv:
@@ -71,7 +90,7 @@ def main():
                 step(i)
             torch.cuda.synchronize()
             res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
-    for name, _ in variants:
+    for name, _, _, _ in variants:
         v = sorted(res[name])
         print(f"{name:28s} " + " ".join(f"{x:7.3f}" for x in res[name]) + f"   min {v[0]:7.3f}  median {v[len(v) // 2]:7.3f} ms/step", flush=True)
 

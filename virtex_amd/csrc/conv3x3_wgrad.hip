@@ -27,6 +27,7 @@
 #include "vtx_common.h"
 
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
+extern int g_vtx_sw_wgrad3x3;
 
 namespace {
 
@@ -54,6 +55,21 @@ __device__ __forceinline__ uint32_t w3_voff(const W3Geo& g, int q, int CH, int e
     const int ihp = w3_qdiv(rem, g.Wp, g.inv_wp), iwp = rem - ihp * g.Wp;
     if (ihp < 1 || ihp > g.H || iwp < 1 || iwp > g.W) return W3_OOB;
     return (uint32_t)((((n * g.H + ihp - 1) * g.W + iwp - 1) * CH + el0) * 2);
+}
+
+template <int T>
+__device__ __forceinline__ void w3_taps(vtx_v4s_t (&ra)[2][2], vtx_v4s_t (&rb)[9][2], bf16x8_t (&fa)[2], f32x4_t (&acc)[2][9]) {
+    if constexpr (T < 9) {
+        vtx_ds_tr_wait_n<(16 - 2 * T > 15 ? 15 : 16 - 2 * T)>();
+        if constexpr (T == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        const bf16x8_t fb = __builtin_shufflevector(rb[T][0], rb[T][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][T], 0, 0, 0);
+        w3_taps<T + 1>(ra, rb, fa, acc);
+    }
 }
 
 __global__ __launch_bounds__(64 * W3_WAVES, 2) void conv3x3_wgrad_stream_kernel(
@@ -150,16 +166,10 @@ __global__ __launch_bounds__(64 * W3_WAVES, 2) void conv3x3_wgrad_stream_kernel(
             rb2[tap][0] = vtx_ds_read_tr16(smem + ((offB[tap][0] + rb) & (W3_RING * 128 - 1)));
             rb2[tap][1] = vtx_ds_read_tr16(smem + ((offB[tap][1] + rb) & (W3_RING * 128 - 1)));
         }
-        vtx_ds_tr_wait();
+        // tap t multiplies as soon as ITS two reads have returned (LDS returns in order): all but the 16 - 2 t youngest
+        // (lgkmcnt holds at most 15); the later taps' reads land under the earlier taps' MFMAs
         bf16x8_t fa[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const bf16x8_t fb = __builtin_shufflevector(rb2[tap][0], rb2[tap][1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i][tap] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][tap], 0, 0, 0);
-        }
+        w3_taps<0>(ra, rb2, fa, acc);
     }
     // lane holds dw[ko = .. + (lane & 15)][tap][c = .. + 4 (lane >> 4) + 0..3]
     float* out = WS + (size_t)range * g.KO * 9 * g.C;
@@ -179,13 +189,16 @@ __global__ __launch_bounds__(64 * W3_WAVES, 2) void conv3x3_wgrad_stream_kernel(
 // (the caller then uses the implicit-GEMM kernel), < 0 on a launch error.
 int vtx_conv3x3_wgrad_try(int N, int H, int W, int C, int KO, int R, int S, int stride, int pad, const void* x, const void* dy,
                           float* dw, float* ws, long ws_floats, hipStream_t st) {
-    static const int on = [] { const char* e = getenv("VIRTEX_AMD_WGRAD3X3"); return e ? atoi(e) : 1; }();
+    const int on = g_vtx_sw_wgrad3x3;
     if (!on || R != 3 || S != 3 || stride != 1 || pad != 1 || (C & 63) || (KO & 63) || !ws) return 0;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dw & 15) || ((uintptr_t)ws & 15)) return 0;
     const int Hp = H + 2, Wp = W + 2;
     const long P = (long)N * Hp * Wp;
     const int lead = ((Wp + 1 + 31) / 32) * 32, nl = 2 * lead / 32;
     if (P >= (1L << 24) || W3_RING / 32 < nl + W3_PF + 2) return 0;
+    // by image size (switch value 1): the padding positions are multiplied as zeros -- +7 % MFMA work at 56x56, +15 % at
+    // 28x28, +31 % at 14x14, +65 % at 7x7, where the implicit-GEMM kernel (whose operands then fit the caches) wins
+    if (on == 1 && (H < 28 || W < 28)) return 0;
     if ((double)N * H * W * C * 2 >= 2.0e9 || (double)N * H * W * KO * 2 >= 2.0e9) return 0;
     const int npairs = (KO / 64) * (C / 64);
     const int total_steps = (int)((P + 31) / 32);

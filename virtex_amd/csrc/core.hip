@@ -46,6 +46,21 @@ extern "C" int vtx_set_contraction_generation(int gen) {
     return VTX_OK;
 }
 extern "C" int vtx_set_ablation(int bits) { vtxg::g_vtx_ablate = bits; return VTX_OK; }
+// Run-time switches of the specialised kernels (each starts from its VIRTEX_AMD_* environment variable): what the
+// interleaved step-level A/B of tools/ab_step.py flips between rounds inside one process.
+int g_vtx_sw_wgrad3x3 = getenv("VIRTEX_AMD_WGRAD3X3") ? atoi(getenv("VIRTEX_AMD_WGRAD3X3")) : 1;         // conv3x3_wgrad.hip: 0 off, 1 by image size, 2 always
+int g_vtx_sw_stem_stream = getenv("VIRTEX_AMD_STEM_STREAM") ? atoi(getenv("VIRTEX_AMD_STEM_STREAM")) : 1;  // stem.hip
+int g_vtx_sw_expand1x1 = getenv("VIRTEX_AMD_EXPAND1X1") ? atoi(getenv("VIRTEX_AMD_EXPAND1X1")) : 1;        // expand1x1.hip
+int g_vtx_sw_splitk_blocks = getenv("VIRTEX_AMD_SPLITK_BLOCKS") ? atoi(getenv("VIRTEX_AMD_SPLITK_BLOCKS")) : 512;   // split-K block target of the weight gradients
+extern "C" int vtx_set_switch(const char* name, int value) {
+    VTX_CHECK(name, VTX_ERR_ARG, "vtx_set_switch: null name");
+    if (!strcmp(name, "wgrad3x3")) g_vtx_sw_wgrad3x3 = value;
+    else if (!strcmp(name, "stem_stream")) g_vtx_sw_stem_stream = value;
+    else if (!strcmp(name, "expand1x1")) g_vtx_sw_expand1x1 = value;
+    else if (!strcmp(name, "splitk_blocks")) g_vtx_sw_splitk_blocks = value > 0 ? value : 512;
+    else VTX_CHECK(false, VTX_ERR_ARG, "vtx_set_switch: unknown switch '%s'", name);
+    return VTX_OK;
+}
 // tests: force tile candidate 0..5 = 256x256, 256x128, 128x128, 128x64, 64x128, 64x64 (-1: automatic)
 extern "C" int vtx_set_tile_override(int c) { vtxg::g_vtx_tile_override = c; return VTX_OK; }
 

@@ -22,6 +22,8 @@
 
 #include "vtx_common.h"
 
+extern int g_vtx_sw_expand1x1;
+
 namespace {
 
 constexpr int EX_WAVES = 8, EX_NB = 256;                 // waves per workgroup, output columns per workgroup
@@ -179,8 +181,7 @@ int launch_expand(const void* A, long lda, const void* W, long ldw, void* Y, lon
 // (the caller then uses the tiled contraction kernel), < 0 on a launch error.
 int vtx_expand1x1_try(int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* Y, long ldy,
                       const float* shift, float* parts, hipStream_t st) {
-    static const int on = [] { const char* e = getenv("VIRTEX_AMD_EXPAND1X1"); return e ? atoi(e) : 1; }();
-    if (!on || !parts || (K != 64 && K != 128) || N % EX_NB != 0 || N < 4 * K || M < 4096 || ldy != N) return 0;
+    if (!g_vtx_sw_expand1x1 || !parts || (K != 64 && K != 128) || N % EX_NB != 0 || N < 4 * K || M < 4096 || ldy != N) return 0;
     if ((lda % 8) || (ldw % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || ((uintptr_t)Y & 15)) return 0;
     const int nt = (double)M * N * 2 >= 200e6;
     const int strips = K == 64 ? launch_expand<64>(A, lda, W, ldw, Y, ldy, shift, parts, M, N, nt, st)

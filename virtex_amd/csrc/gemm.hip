@@ -90,10 +90,11 @@ void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc,
 
 // Split-K policy for the weight-gradient GEMMs: enough slices to give every CU ~2 blocks, never fewer than 8 K-steps per slice, bounded by the workspace
 // ([slices][M][N] fp32 partial sums).
+extern int g_vtx_sw_splitk_blocks;
 int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
     const long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
     const int nkt = vtx_cdiv(K, bk);
-    static const long target = [] { const char* e = getenv("VIRTEX_AMD_SPLITK_BLOCKS"); return e ? atol(e) : 512L; }();
+    const long target = g_vtx_sw_splitk_blocks;          // VIRTEX_AMD_SPLITK_BLOCKS / vtx_set_switch("splitk_blocks")
     long s = (target + tiles - 1) / tiles;
     if (s > nkt / 8) s = nkt / 8;
     const long cap = ws_floats / ((long)M * N);

@@ -1077,6 +1077,22 @@ template <int ROWS, int NW, class L, int BK = 32> struct DmaStager {
     }
 };
 
+// rows I .. MT-1 of a k-major K step (see the kernel): wait for row I's A fragment, multiply it with every B fragment
+template <int I, int MT, int NT>
+__device__ __forceinline__ void mc_rows(vtx_v4s_t (&ra)[MT][2], vtx_v4s_t (&rb)[NT][2], bf16x8_t (&fb)[NT], f32x4_t (&acc)[MT][NT]) {
+    if constexpr (I < MT) {
+        vtx_ds_tr_wait_n<2 * (MT - 1 - I)>();
+        if constexpr (I == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = __builtin_shufflevector(rb[j][0], rb[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        const bf16x8_t fa = __builtin_shufflevector(ra[I][0], ra[I][1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[I][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[I][j], 0, 0, 0);
+        mc_rows<I + 1, MT, NT>(ra, rb, fb, acc);
+    }
+}
+
 // Block = WM x WN waves; block tile BM x BN; wave tile (BM/WM) x (BN/WN).  Large tiles matter for the
 // L2 -> LDS bandwidth, not only for LDS: a 128x128 tile needs 2*(128+128)*64 B per 2*128*128*32 flop
 // = 64 flop/B, i.e. 39 TB/s of cache bandwidth at the MFMA peak (L2 delivers ~34); 256x256 needs half.
@@ -1174,16 +1190,18 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
                 bf16x8_t fa[MT], fb[NT];
                 static_assert(SA::MC == SB::MC, "operand pairs are both row-major or both k-major");
                 if constexpr (SA::MC) {
+                    // k-major operands: every transposing read of the step is issued first (B fragments, then the A
+                    // fragments in the order the MFMA rows use them); row i of the MFMAs starts as soon as ITS A fragment
+                    // has returned (LDS returns in order: all but the 2 (MT-1-i) youngest reads), the later rows' reads
+                    // land under the earlier rows' MFMAs -- the ladder hipcc builds by itself for the row-major kernels
                     vtx_v4s_t ra[MT][2], rb[NT][2];
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) SA::frag_tr(cur, wm * WTM + i * 16, lane, ra[i]);
-#pragma unroll
                     for (int j = 0; j < NT; ++j) SB::frag_tr(cur + BM * BK, wn * WTN + j * 16, lane, rb[j]);
-                    vtx_ds_tr_wait();
 #pragma unroll
-                    for (int i = 0; i < MT; ++i) fa[i] = __builtin_shufflevector(ra[i][0], ra[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) fb[j] = __builtin_shufflevector(rb[j][0], rb[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    for (int i = 0; i < MT; ++i) SA::frag_tr(cur, wm * WTM + i * 16, lane, ra[i]);
+                    static_assert(2 * (MT - 1) <= 15, "lgkmcnt ladder");
+                    mc_rows<0, MT, NT>(ra, rb, fb, acc);
+                    continue;
                 } else if (!(abl & 2) || kt == kt0) {
 #pragma unroll
                     for (int i = 0; i < MT; ++i) fa[i] = SA::frag(cur, wm * WTM + i * 16, lane, h);

@@ -22,6 +22,8 @@
 
 #include "vtx_common.h"
 
+extern int g_vtx_sw_stem_stream;
+
 namespace {
 
 constexpr int ST_WAVES = 8, ST_N = 64, ST_KH = 7;
@@ -157,8 +159,7 @@ __global__ __launch_bounds__(64 * ST_WAVES, 4) void stem_stream_fwd_kernel(
 // w: [64][7][8][4], y: [N][OH][OW][64], OH = (H - 7) / 2 + 1, OW = (W - 8) / 2 + 1.
 int vtx_stem_stream_try(int N, int H, int W, int C, int KO, int R, int S, int stride, int pad, const void* x, const void* w,
                         void* y, const float* shift, float* parts, hipStream_t st) {
-    static const int on = [] { const char* e = getenv("VIRTEX_AMD_STEM_STREAM"); return e ? atoi(e) : 1; }();
-    if (!on || !parts || C != 4 || KO != ST_N || R != ST_KH || S != 8 || stride != 2 || pad != 0 || (W & 1)) return 0;
+    if (!g_vtx_sw_stem_stream || !parts || C != 4 || KO != ST_N || R != ST_KH || S != 8 || stride != 2 || pad != 0 || (W & 1)) return 0;
     if (((uintptr_t)x & 15) || ((uintptr_t)w & 15) || ((uintptr_t)y & 15)) return 0;
     const int OH = (H - R) / 2 + 1, OW = (W - S) / 2 + 1;
     if (OH <= 0 || OW <= 0) return 0;

@@ -100,6 +100,7 @@ __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vtx_v4s_t*)p);
 }
 __device__ __forceinline__ void vtx_ds_tr_wait() {}
+template <int N> __device__ __forceinline__ void vtx_ds_tr_wait_n() {}
 #else
 __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
     vtx_v4s_t r;
@@ -109,6 +110,16 @@ __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
 }
 __device__ __forceinline__ void vtx_ds_tr_wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// all but the N most recently issued LDS operations of this wave have returned (LDS returns in order)
+template <int N> __device__ __forceinline__ void vtx_ds_tr_wait_n() {
+    static_assert(N >= 0 && N <= 15, "lgkmcnt is 4 bits");
+#ifdef VTX_TR_NOLADDER                  // A/B builds: one full wait per K step
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 #endif
