@@ -343,11 +343,12 @@ def test_other_backbones_every_gradient_fp32_gpu(visual, textual):
     om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, **kw).train()
     batch = synth.synthetic_batch(8, image_size=224, seed=11, ragged=True)
     o64 = copy.deepcopy(om).double()
+    state = copy.deepcopy(om.state_dict())           # BEFORE the oracle's step updates the BatchNorm buffers
     oo = om(batch); oo["loss"].backward()
     o64({k: (v.double() if v.dtype.is_floating_point else v) for k, v in batch.items()})["loss"].backward()
     g64 = {n: p.grad for n, p in o64.named_parameters()}
     model = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=torch.float32, **kw)
-    missing = model.load_state_dict(om.state_dict())
+    missing = model.load_state_dict(state)
     assert not missing.missing_keys and not missing.unexpected_keys
     model = model.to(dev)
     out = _run(model, batch, dev)

@@ -101,47 +101,51 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
 // Sums the per-strip partials of FIN_CH channels with FIN_GR thread groups (block = 256 threads); returns the
 // totals to the group-0 threads.  Latency-bound (the partials sit in the Infinity Cache, ~1 us away): many
 // short chains with four independent loads per trip, not a few long ones (22 us -> see DESIGN.md 6).
-constexpr int FIN_CH = 16, FIN_GR = 16;
+constexpr int FIN_CH = 16, FIN_GR_MAX = 64;
+// Thread groups per block = blockDim.x / FIN_CH (16 or 64): the finalize kernels sit on the critical path of the step (106
+// launches) and are pure latency -- a group's chain of dependent trips is nparts / (4 groups' loads) long, so launches over
+// more than 64 strips run 1024-thread blocks (64 groups): two trips instead of eight for 512 strips.
+static inline dim3 fin_block(int nparts) { return dim3(nparts > 64 ? FIN_CH * FIN_GR_MAX : 256); }
 __device__ __forceinline__ void sum_partials(const float* __restrict__ sums, int C, int nparts, int c, int grp,
                                              float& t0, float& t1) {
-    __shared__ float red[2][FIN_GR][FIN_CH];
+    __shared__ float red[2][FIN_GR_MAX][FIN_CH];
+    const int NG = blockDim.x / FIN_CH;
     float a = 0.f, b = 0.f;
     if (c < C) {
         int p = grp;
-        for (; p + 3 * FIN_GR < nparts; p += 4 * FIN_GR) {
+        for (; p + 3 * NG < nparts; p += 4 * NG) {
             const float* q = sums + (size_t)p * 2 * C + c;
-            const size_t st = (size_t)FIN_GR * 2 * C;
+            const size_t st = (size_t)NG * 2 * C;
             const float a0 = q[0], a1 = q[st], a2 = q[2 * st], a3 = q[3 * st];
             const float b0 = q[C], b1 = q[st + C], b2 = q[2 * st + C], b3 = q[3 * st + C];
             a += (a0 + a1) + (a2 + a3); b += (b0 + b1) + (b2 + b3);
         }
-        for (; p < nparts; p += FIN_GR) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
+        for (; p < nparts; p += NG) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
     }
     red[0][grp][threadIdx.x % FIN_CH] = a; red[1][grp][threadIdx.x % FIN_CH] = b;
     __syncthreads();
     t0 = t1 = 0.f;
     if (grp == 0) {
-#pragma unroll
-        for (int g = 0; g < FIN_GR; ++g) { t0 += red[0][g][threadIdx.x % FIN_CH]; t1 += red[1][g][threadIdx.x % FIN_CH]; }
+        for (int g = 0; g < NG; ++g) { t0 += red[0][g][threadIdx.x % FIN_CH]; t1 += red[1][g][threadIdx.x % FIN_CH]; }
     }
 }
 
 // Folds many statistics strips into few: block (x = 32-channel group, y = chunk of `per` strips) writes
 // one compact strip.  Used when the convolution epilogue produced thousands of strips (M = 800k rows).
+// blockDim.x / 32 thread groups (32 with the 1024-thread blocks the host launches) share a chunk's strips.
 __global__ void bn_compact_parts_kernel(const float* __restrict__ sums, float* __restrict__ out, int C, int nparts,
                                         int per) {
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5, NG = blockDim.x >> 5;
     const int p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
-    __shared__ float red[2][8][32];
+    __shared__ float red[2][32][32];
     float a = 0.f, b = 0.f;
     if (c < C)
-        for (int p = p0 + grp; p < p1; p += 8) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
+        for (int p = p0 + grp; p < p1; p += NG) { a += sums[(size_t)p * 2 * C + c]; b += sums[(size_t)p * 2 * C + C + c]; }
     red[0][grp][threadIdx.x & 31] = a; red[1][grp][threadIdx.x & 31] = b;
     __syncthreads();
     if (grp == 0 && c < C) {
         float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+        for (int g = 0; g < NG; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
         out[(size_t)blockIdx.y * 2 * C + c] = t0;
         out[(size_t)blockIdx.y * 2 * C + C + c] = t1;
     }
@@ -533,7 +537,7 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
         int np = pre_nparts;
         if (np > 512) {             // thousands of strips: fold them first (keeps the finalize short)
             const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
-            VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, C, np, per);
+            VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(1024), 0, st, parts, sums, C, np, per);
             parts = sums; np = ny;
         }
         sums = const_cast<float*>(parts); rp.gx = np;
@@ -545,10 +549,10 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
         VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     const int fwd_unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (6L << 20) ? 2 : 1);
     if (dtype == VTX_BF16) {
@@ -585,7 +589,7 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     else
         VTX_KLAUNCH("bn_bwd_reduce", 0, 4.0 * P * C * (ymask ? 3 : 2), (bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)dy, (const float*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
-    VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
+    VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, sums, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, rp.gx);
     if (!ymask && !relu_beta && !dz_out) {
         // no ReLU behind this BatchNorm (the projection shortcuts): dy is the gradient itself, so the apply is the one
@@ -633,10 +637,10 @@ extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const 
     int np = pre_nparts;
     if (np > 512) {
         const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, C, np, per);
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(1024), 0, st, parts, sums, C, np, per);
         parts = sums; np = ny;
     }
-    VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, parts, gamma, save_rstd, coef,
+    VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(np), 0, st, parts, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, np);
     const long nvec = (long)P * C / vec;
     // measured (tools/bench_bn_apply.py, profiles/r02_bn_apply_unroll.txt): two vectors in flight +5 % on the >= 50 MB
@@ -682,7 +686,7 @@ extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, c
     else
         VTX_KLAUNCH("bn_bwd_reduce", 0, el * P * C + pool_bytes, (pool_bn_bwd_reduce_kernel<float>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                     (const float*)dpool, argmax, save_mean, save_rstd, gamma, beta, sums, N, H, W, C, OH, OW, rp.TX, rp.rows);
-    VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, sums, gamma, save_rstd, coef,
+    VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, sums, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, rp.gx);
     const long nvec = (long)P * C / vec;
     if (dtype == VTX_BF16)
@@ -730,10 +734,10 @@ extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, 
         VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
     if (dtype == VTX_BF16)
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                     save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), dim3(256), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                     save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     const int cv = C / vec;
     int TX = 1; while (TX < cv && TX < 256) TX <<= 1;

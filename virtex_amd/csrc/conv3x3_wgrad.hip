@@ -15,12 +15,13 @@
 //     the rings are k-major exactly as in HBM, no transposition work), the A fragments (dyp) are shared by the taps:
 //     22 transposing reads for 18 MFMAs per wave and step, two address VALU per read (the swizzle of a ring row
 //     depends on bits 1 and 3 of its index, which a step of 32 rows does not change: per-tap lane constants);
-//   * loads run W3_PF = 8 steps (64 KiB per CU) ahead of the MFMAs behind a counted s_waitcnt and ONE barrier per step;
+//   * loads run W3_PF = 8 steps (64 KiB per CU) ahead of the MFMAs behind a counted s_waitcnt and ONE barrier per TWO steps;
+//     a loading lane tracks its padded-linear position with carries (no division in the loop);
 //   * the pixel ranges' partial blocks go to the split-K workspace as [range][KO][9][C] and the existing reduce adds
 //     them into dw.
 // MFMA work grows by (H+2)(W+2)/(HW) (7 % at 56x56, 15 % at 28x28, 31 % at 14x14, 65 % at 7x7: the padding positions
 // are multiplied as zeros).
-// Entry: vtx_conv2d_wgrad routes here (bf16, 3x3 / s1 / p1, C and KO multiples of 64, W + 3 <= 96) unless
+// Entry: vtx_conv2d_wgrad routes here (bf16, 3x3 / s1 / p1, C and KO multiples of 64, 7 <= W <= 61, by default H, W >= 28) unless
 // VIRTEX_AMD_WGRAD3X3=0.
 #include <stdlib.h>
 
@@ -76,6 +77,9 @@ __global__ __launch_bounds__(64 * W3_WAVES, 2) void conv3x3_wgrad_stream_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ DY, float* __restrict__ WS, W3Geo g, int lead, int nl,
     int steps_per_range, int total_steps, int npairs) {
     HIP_DYNAMIC_SHARED(char, smem)
+#ifndef HIPEMU
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();   // the rings' offsets ARE their LDS addresses
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware order: the (ko, c) chunk pairs of one pixel range share their operands -> contiguous on one XCD
@@ -92,20 +96,44 @@ __global__ __launch_bounds__(64 * W3_WAVES, 2) void conv3x3_wgrad_stream_kernel(
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(X), (short)0, (int)((long)g.N * g.H * g.W * g.C * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(DY), (short)0, (int)((long)g.N * g.H * g.W * g.KO * 2), 0x00020000);
 
-    // ---- loader role: waves 0-3 stage xp (8 positions each per step), waves 4-7 dyp
+    // ---- loader role: waves 0-3 stage xp (8 positions each per step), waves 4-7 dyp.  A lane stays on ONE position of
+    // the 32-position step and one 16-byte chunk; its padded-linear position advances by 32 per step, tracked as
+    // (image, padded row, padded column) with carries -- no division in the loop.
     const bool xrole = wave < 4;
     const int sub = wave & 3;
     const int lpos = 8 * sub + (lane >> 3);                                 // position within the 32-position step
     const int src_chunk = w3_swz(lane & 7, lpos);                           // bits 1, 3 of the ring row = those of lpos
-    auto issue = [&](int s) {                                               // x-step s (xrole) / dy-step s
-        if (xrole) {
-            const uint32_t vo = w3_voff(g, p0 - lead + 32 * s + lpos, g.C, c0 + 8 * src_chunk);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem + (((32 * s + 8 * sub) & (W3_RING - 1)) << 7)),
-                                                     16, (int)vo, 0, 0, 0);
+    const int CH = xrole ? g.C : g.KO, el0 = (xrole ? c0 : ko0) + 8 * src_chunk;
+    int q = (xrole ? p0 - lead : p0) + lpos;                                // position of this lane's next piece
+    int qn, qh, qw;                                                         // its (image, padded row, padded column); q < 0: unused
+    {
+        const int qq = q < 0 ? 0 : q;
+        qn = w3_qdiv(qq, g.Hp * g.Wp, g.inv_img);
+        const int rem = qq - qn * g.Hp * g.Wp;
+        qh = w3_qdiv(rem, g.Wp, g.inv_wp); qw = rem - qh * g.Wp;
+    }
+    const uint32_t dst0 = xrole ? (uint32_t)(8 * sub) << 7 : (uint32_t)(W3_RING * 128 + (sub << 10));
+    int sissue = 0;                                                         // steps issued so far
+    auto issue = [&]() {
+        const bool ok = q >= 0 && q < g.P && qh >= 1 && qh <= g.H && qw >= 1 && qw <= g.W;
+        const uint32_t vo = ok ? (uint32_t)((((qn * g.H + qh - 1) * g.W + qw - 1) * CH + el0) * 2) : W3_OOB;
+        const uint32_t dst = xrole ? dst0 + ((uint32_t)((32 * sissue) & (W3_RING - 1)) << 7) : dst0 + ((uint32_t)(sissue & (W3_DS - 1)) << 12);
+        if (xrole) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)vo, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)vo, 0, 0, 0);
+        ++sissue;
+        const bool was_neg = q < 0;
+        q += 32;
+        if (was_neg) {                                                      // the lead-in of the first range: re-derive once q >= 0
+            if (q >= 0) {
+                qn = w3_qdiv(q, g.Hp * g.Wp, g.inv_img);
+                const int rem = q - qn * g.Hp * g.Wp;
+                qh = w3_qdiv(rem, g.Wp, g.inv_wp); qw = rem - qh * g.Wp;
+            }
         } else {
-            const uint32_t vo = w3_voff(g, p0 + 32 * s + lpos, g.KO, ko0 + 8 * src_chunk);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)(smem + W3_RING * 128 + ((s & (W3_DS - 1)) << 12) + (sub << 10)),
-                                                     16, (int)vo, 0, 0, 0);
+            qw += 32;                                                       // Wp >= 9: at most four row carries per step
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const bool cy = qw >= g.Wp; qw -= cy ? g.Wp : 0; qh += cy ? 1 : 0; }
+            const bool ci = qh >= g.Hp; qh -= ci ? g.Hp : 0; qn += ci ? 1 : 0;
         }
     };
 
@@ -147,29 +175,37 @@ __global__ __launch_bounds__(64 * W3_WAVES, 2) void conv3x3_wgrad_stream_kernel(
 
     constexpr int WAIT_PF = (W3_PF & 0xF) | ((W3_PF >> 4) << 14) | (0x7 << 4) | (0xF << 8);
     const int xahead = nl + W3_PF;
-    for (int s = 0; s < (xrole ? xahead : W3_PF); ++s) issue(s);
-    for (int t = 0; t < nsteps; ++t) {
-        issue(t + (xrole ? xahead : W3_PF));        // beyond the range's needs: out-of-range lanes or never-read slots
-        __builtin_amdgcn_s_waitcnt(WAIT_PF);        // this wave's pieces of x-step t + nl / dy-step t have landed ...
-        __builtin_amdgcn_s_barrier();               // ... and everybody's; all waves are done with step t - 1
-        const uint32_t slot = (uint32_t)(t & (W3_DS - 1)) << 12;
-        const uint32_t rb = (uint32_t)((32 * t) & (W3_RING - 1)) << 7;
-        // all 22 transposing reads of the step first (asm: see vtx_ds_read_tr16), ONE wait, then the 18 MFMAs
-        vtx_v4s_t ra[2][2], rb2[9][2];
+    for (int s = 0; s < (xrole ? xahead : W3_PF); ++s) issue();
+    // TWO steps per barrier (the ring margins are sized for it: host check): per pair two loads per wave are issued, the
+    // wait leaves the W3_PF youngest in flight (x-steps <= t + 1 + nl and dy-steps <= t + 1 have landed), one barrier,
+    // then 2 x (22 transposing reads + 18 MFMAs)
+    for (int t = 0; t < nsteps; t += 2) {
+        issue(); issue();                           // beyond the range's needs: out-of-range lanes or never-read slots
+        __builtin_amdgcn_s_waitcnt(WAIT_PF);
+        __builtin_amdgcn_s_barrier();               // everybody's pieces have landed; all waves are done with the previous pair
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            ra[i][0] = vtx_ds_read_tr16(smem + offA[i][0] + slot);
-            ra[i][1] = vtx_ds_read_tr16(smem + offA[i][1] + slot);
-        }
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && t + 1 >= nsteps) break;   // odd tail: the positions of step t + 1 belong to the next range
+            const uint32_t slot = (uint32_t)((t + u) & (W3_DS - 1)) << 12;
+            const uint32_t rb = (uint32_t)((32 * (t + u)) & (W3_RING - 1)) << 7;
+            // all 22 transposing reads of the step first (asm: see vtx_ds_read_tr16), then tap by tap: tap T multiplies as
+            // soon as ITS two reads have returned (LDS returns in order: all but the 16 - 2 T youngest; lgkmcnt holds at
+            // most 15) -- the later taps' reads land under the earlier taps' MFMAs.  The xp ring is 64 KiB at LDS address
+            // 0: a 16-bit add wraps by itself.
+            vtx_v4s_t ra[2][2], rb2[9][2];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            rb2[tap][0] = vtx_ds_read_tr16(smem + ((offB[tap][0] + rb) & (W3_RING * 128 - 1)));
-            rb2[tap][1] = vtx_ds_read_tr16(smem + ((offB[tap][1] + rb) & (W3_RING * 128 - 1)));
+            for (int i = 0; i < 2; ++i) {
+                ra[i][0] = vtx_ds_read_tr16_at(smem, offA[i][0] + slot);
+                ra[i][1] = vtx_ds_read_tr16_at(smem, offA[i][1] + slot);
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                rb2[tap][0] = vtx_ds_read_tr16_at(smem, (uint32_t)(uint16_t)((uint16_t)offB[tap][0] + (uint16_t)rb));
+                rb2[tap][1] = vtx_ds_read_tr16_at(smem, (uint32_t)(uint16_t)((uint16_t)offB[tap][1] + (uint16_t)rb));
+            }
+            bf16x8_t fa[2];
+            w3_taps<0>(ra, rb2, fa, acc);
         }
-        // tap t multiplies as soon as ITS two reads have returned (LDS returns in order): all but the 16 - 2 t youngest
-        // (lgkmcnt holds at most 15); the later taps' reads land under the earlier taps' MFMAs
-        bf16x8_t fa[2];
-        w3_taps<0>(ra, rb2, fa, acc);
     }
     // lane holds dw[ko = .. + (lane & 15)][tap][c = .. + 4 (lane >> 4) + 0..3]
     float* out = WS + (size_t)range * g.KO * 9 * g.C;
@@ -195,7 +231,7 @@ int vtx_conv3x3_wgrad_try(int N, int H, int W, int C, int KO, int R, int S, int 
     const int Hp = H + 2, Wp = W + 2;
     const long P = (long)N * Hp * Wp;
     const int lead = ((Wp + 1 + 31) / 32) * 32, nl = 2 * lead / 32;
-    if (P >= (1L << 24) || W3_RING / 32 < nl + W3_PF + 2) return 0;
+    if (P >= (1L << 24) || W3_RING / 32 < nl + W3_PF + 4 || Wp < 9) return 0;   // ring margins for two steps per barrier (W <= 61)
     // by image size (switch value 1): the padding positions are multiplied as zeros -- +7 % MFMA work at 56x56, +15 % at
     // 28x28, +31 % at 14x14, +65 % at 7x7, where the implicit-GEMM kernel (whose operands then fit the caches) wins
     if (on == 1 && (H < 28 || W < 28)) return 0;

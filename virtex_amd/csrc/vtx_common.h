@@ -99,6 +99,9 @@ typedef short vtx_v4s_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) vtx_v4s_t*)p);
 }
+// the same from a byte offset inside the kernel's dynamic LDS (which starts at LDS address 0 when the kernel has no static
+// __shared__ object: the offset IS the address -- no per-read "+ base" instruction)
+__device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16_at(const char* dyn_lds, uint32_t off) { return vtx_ds_read_tr16(dyn_lds + off); }
 __device__ __forceinline__ void vtx_ds_tr_wait() {}
 template <int N> __device__ __forceinline__ void vtx_ds_tr_wait_n() {}
 #else
@@ -106,6 +109,11 @@ __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
     vtx_v4s_t r;
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a) : "memory");
+    return r;
+}
+__device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16_at(const char*, uint32_t off) {
+    vtx_v4s_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(off) : "memory");
     return r;
 }
 __device__ __forceinline__ void vtx_ds_tr_wait() {

@@ -44,8 +44,9 @@ FUSE_BN_BWD = os.environ.get("VIRTEX_AMD_FUSE_BN_BWD", "1") != "0"
 # gather is instruction-bound (0.9 TB/s) and the fusion runs it twice to save 1 GB of traffic -> off by default.
 FUSE_STEM_TAIL = os.environ.get("VIRTEX_AMD_FUSE_STEM_TAIL", "0") != "0"
 # forward counterpart: BatchNorm + ReLU + max-pool of the stem in one pass, the 411 MB tensor between them never written
-# (bit-identical results; prepared at the end of round 2 on the emulator, to be measured on the GPU before it becomes default)
-FUSE_STEM_FWD = os.environ.get("VIRTEX_AMD_FUSE_STEM_FWD", "0") != "0"
+# (pooled values and argmax bit-identical to the three-kernel path).  Round 3, interleaved A/B in one process:
+# 27.72 -> 27.56 ms/step (profiles/r03_ab_session1.txt) -> on by default.
+FUSE_STEM_FWD = os.environ.get("VIRTEX_AMD_FUSE_STEM_FWD", "1") != "0"
 # The ReLU mask of a Bottleneck's output as one BIT per element, written by the BatchNorm + residual + ReLU pass that
 # produces the output: the fused BatchNorm backward in the next block's input-gradient epilogue reads 1/16 of the bytes
 # instead of the whole output tensor (2.8 GB of reads per step at bs 256; the output itself stays: it is the next
