@@ -80,18 +80,21 @@ PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355
 # The dominant kernel is found by NAME (a family's launch sites merged), then its LARGEST launch site is timed alone: the
 # traffic listed here is that site's kernel.  Candidates for the top of the step are within a few percent of each other, so
 # the likely ones are all listed; `traffic` is reported for whichever the live measurement finds dominant.
-TRAFFIC_SOURCE = "profiles/r02_pmc_traffic_final.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE)
-    # largest site = bn_bwd_apply_fused_kernel<bf16, 2>, 21 launches/step: (2 x 167.3e3 + 167.3e3) KiB (algorithmic 513.8 MB -> 1.00x)
-    "bn_bwd_apply": 513.9e6,
-    # largest site = bn_apply_kernel<bf16, 2>, 25 launches/step: (2 x 144.6e3 + 184.6e3) KiB
-    "bn_fwd_apply": 485.2e6,
+TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, round-3 build)"
+TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE), averaged over the site's launches
+    # largest site = bn_bwd_apply_fused_kernel<bf16, 2>, 24 launches/step: (2 x 175.7e3 + 175.6e3) KiB (reads x and dz, writes dx: 2 : 1)
+    "bn_bwd_apply": 539.6e6,
+    # largest site = bn_apply_kernel<bf16, 2>, 24 launches/step: (2 x 142.2e3 + 182.9e3) KiB
+    "bn_fwd_apply": 478.5e6,
     # 35 launches/step (1x1 / text weight gradients): (2 x 63.6e3 + 32.8e3) KiB
     "contraction_v2_kernel<256, 128, 4, 2, PlainMC<bf16, 2>, PlainMC<bf16, 1>, EpiStore<float, 0>, 32, 3>": 163.9e6,
-    # 11 launches/step (stage 1-2 input gradients with the fused BatchNorm backward): (2 x 351.6e3 + 207.0e3) KiB
-    "contraction_v2_kernel<128, 128, 4, 2, PlainKC<bf16, 1>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 932.0e6,
-    # 17 launches/step: (2 x 104.5e3 + 53.2e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 268.5e6,
+    # 11 launches/step (stage 1-2 input gradients with the fused BatchNorm backward; the bn3 launches read the ReLU mask as
+    # bits since round 3: 932.0 -> 754.9 MB): (2 x 265.1e3 + 207.0e3) KiB
+    "contraction_v2_kernel<128, 128, 4, 2, PlainKC<bf16, 1>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 754.9e6,
+    # 17 launches/step: (2 x 85.2e3 + 53.2e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 229.0e6,
+    # 14 launches/step (text GEMMs, late 1x1 convolutions): (2 x 113.9e3 + 71.1e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 0>, 32, 3>": 306.1e6,
 }
 
 

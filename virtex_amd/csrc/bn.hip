@@ -14,6 +14,8 @@
 
 #include "vtx_common.h"
 
+extern int g_vtx_sw_bn_fin_wide;     // vtx_set_switch("bn_fin_wide"): 1024-thread finalize / compaction blocks (default off)
+
 namespace {
 
 // x viewed as [P][cv] 16-byte vectors.  Block: TX threads across channel vectors, TY = 256/TX
@@ -102,10 +104,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
 // totals to the group-0 threads.  Latency-bound (the partials sit in the Infinity Cache, ~1 us away): many
 // short chains with four independent loads per trip, not a few long ones (22 us -> see DESIGN.md 6).
 constexpr int FIN_CH = 16, FIN_GR_MAX = 64;
-// Thread groups per block = blockDim.x / FIN_CH (16 or 64): the finalize kernels sit on the critical path of the step (106
-// launches) and are pure latency -- a group's chain of dependent trips is nparts / (4 groups' loads) long, so launches over
-// more than 64 strips run 1024-thread blocks (64 groups): two trips instead of eight for 512 strips.
-static inline dim3 fin_block(int nparts) { return dim3(nparts > 64 ? FIN_CH * FIN_GR_MAX : 256); }
+// Thread groups per block = blockDim.x / FIN_CH: 16, or 64 with the measurement switch "bn_fin_wide".  Measured in round 3
+// (profiles/r03_kernel_stats_*): the 106 finalize launches per step take 4.8-5.0 us each with either block size -- they
+// are launch / first-load latency, not the chain of trips -- so the default stays at 256 threads (and at the summation
+// order the calibrated fp32 gradient bounds of tests/test_fidelity.py were measured with).
+static inline dim3 fin_block(int nparts) { return dim3((nparts > 64 && g_vtx_sw_bn_fin_wide) ? FIN_CH * FIN_GR_MAX : 256); }
 __device__ __forceinline__ void sum_partials(const float* __restrict__ sums, int C, int nparts, int c, int grp,
                                              float& t0, float& t1) {
     __shared__ float red[2][FIN_GR_MAX][FIN_CH];
@@ -537,7 +540,7 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
         int np = pre_nparts;
         if (np > 512) {             // thousands of strips: fold them first (keeps the finalize short)
             const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
-            VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(1024), 0, st, parts, sums, C, np, per);
+            VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(g_vtx_sw_bn_fin_wide ? 1024 : 256), 0, st, parts, sums, C, np, per);
             parts = sums; np = ny;
         }
         sums = const_cast<float*>(parts); rp.gx = np;
@@ -637,7 +640,7 @@ extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const 
     int np = pre_nparts;
     if (np > 512) {
         const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(1024), 0, st, parts, sums, C, np, per);
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(g_vtx_sw_bn_fin_wide ? 1024 : 256), 0, st, parts, sums, C, np, per);
         parts = sums; np = ny;
     }
     VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(np), 0, st, parts, gamma, save_rstd, coef,
