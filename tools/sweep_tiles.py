@@ -10,9 +10,12 @@ B, dt = 256, torch.bfloat16
 lib = _lib.lib()
 names = {-1: "auto", 0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x128", 5: "64x64", 11: "256x128k64s2", 12: "128x128k64s2"}
 CANDS = [int(c) for c in sys.argv[1].split(",")] if len(sys.argv) > 1 else [-1, 0, 1, 2, 3, 4, 5]
-ONLY_KC = len(sys.argv) > 2
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""          # "kc": skip the weight gradients; "wgrad": only them
+ONLY_KC = ONLY not in ("", "wgrad")
 def sweep(label, fn, M, N):
     if ONLY_KC and "wgrad" in label:
+        return
+    if ONLY == "wgrad" and "wgrad" not in label:
         return
     res = {}
     for c in CANDS:

@@ -105,6 +105,10 @@ SHARE_VISUAL_PROJECTION = os.environ.get("VIRTEX_AMD_SHARE_VISUAL_PROJECTION", "
 # every step like the reference's decoding_step (kept: `model.decoding_step`, and "0" here, for comparisons).
 INCREMENTAL_DECODING = os.environ.get("VIRTEX_AMD_INCREMENTAL_DECODING", "1") != "0"
 
+# compute copies of the text heads' weights prepared on the branch stream under the backbone's first kernels instead of
+# in front of the whole forward pass (the one preparation launch is 0.18 ms at the head of every step)
+SPLIT_WEIGHT_PREP = os.environ.get("VIRTEX_AMD_SPLIT_WEIGHT_PREP", "1") != "0"
+
 # the two caption directions on two streams (A/B switch; see DESIGN.md, Streams)
 HEAD_STREAMS = os.environ.get("VIRTEX_AMD_HEAD_STREAMS", "1") != "0"
 # host order of the two heads' forward passes when they run on two streams ("0" = round-1 order, for A/B runs)
@@ -142,28 +146,43 @@ class CaptioningModel(nn.Module):
     def _refresh_compute_weights(self):
         """One launch for all the bf16/fp32 compute copies (and their transposes) the step will use; weights whose
         copies are current (no optimizer step / in-place edit since) cost nothing."""
-        seen, items = set(), []
+        seen, vis_items, text_items = set(), [], []
         heads = [self.textual] + ([self.backward_textual] if self.caption_backward else [])
-        plan = (self.visual.weight_plan() if hasattr(self.visual, "weight_plan") else [])
-        for h in heads:
-            if hasattr(h, "weight_plan"):
-                plan = plan + h.weight_plan()
-        for it in plan:
+        for it in (self.visual.weight_plan() if hasattr(self.visual, "weight_plan") else []):
             if id(it[0]) not in seen:
                 seen.add(id(it[0]))
-                items.append(it)
+                vis_items.append(it)
+        for h in heads:
+            for it in (h.weight_plan() if hasattr(h, "weight_plan") else []):
+                if id(it[0]) not in seen:
+                    seen.add(id(it[0]))
+                    text_items.append(it)
         dt = getattr(self.textual, "compute_dtype", None)
-        if items and dt is not None:
-            ops.prep_many(items, dt)
+        if dt is None:
+            return None
+        dev = next(self.parameters()).device
+        if SPLIT_WEIGHT_PREP and self.training and vis_items and text_items and dev.type == "cuda" and branch_stream.enabled:
+            # the text heads' copies (2/3 of the bytes) are not needed before the backbone is through: prepared on the
+            # branch stream under the stem / first stage; the caller makes the compute stream wait before the heads start
+            br = branch_stream(dev)
+            with br:
+                ops.prep_many(text_items, dt)
+            ops.prep_many(vis_items, dt)
+            return br
+        if vis_items or text_items:
+            ops.prep_many(vis_items + text_items, dt)
+        return None
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, Any]:
-        self._refresh_compute_weights()
+        text_prep = self._refresh_compute_weights()
         emb = getattr(self.textual, "embedding", None)
         if emb is not None and hasattr(emb, "defer_join"):
             # the backbone's backward runs after both heads' and joins the weight-gradient side stream itself
             emb.defer_join = bool(self.training and torch.is_grad_enabled()
                                   and any(p.requires_grad for p in self.visual.parameters()))
         visual_features = self.visual(batch["image"])
+        if text_prep is not None:
+            text_prep.wait()               # the text heads' compute copies are ready (they were prepared beside the backbone)
         batch_size = visual_features.size(0)
         if "caption_tokens" in batch:
             caption_tokens = batch["caption_tokens"]
