@@ -1410,7 +1410,8 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
 // efficiency); candidates with BN > what N needs are skipped.
 struct TileCand { int bm, bn, resident; float eff; };
 extern int g_vtx_tile_override;   // tests: force a candidate (-1 = automatic)
-inline int pick_tile(int M, int N, int splits, bool allow256) {
+extern int g_vtx_sw_mc_eff128;    // percent: relative efficiency of 128x128 tiles for k-major operands (vtx_set_switch("mc_eff128"))
+inline int pick_tile(int M, int N, int splits, bool allow256, bool mc = false) {
     if (g_vtx_tile_override >= 0 && (allow256 || g_vtx_tile_override >= 2)) return g_vtx_tile_override;
     // eff = measured relative throughput on a large NT GEMM (tools/ablate_gemm.py: 256x128 806 TF/s,
     // 128x128 680, 256x256 567 -- one resident block per CU cannot hide its own epilogue)
@@ -1431,7 +1432,10 @@ inline int pick_tile(int M, int N, int splits, bool allow256) {
         const long blocks = tm * tn * (splits < 1 ? 1 : splits);
         const long rounds = (blocks + 255) / 256;
         const float overlap = (rounds < 2 && t.resident > 1) ? 0.9f : 1.0f;
-        const float cost = (float)rounds * (float)(t.bm * t.bn) / (t.eff * overlap);
+        // k-major operands (weight gradients): since their LDS-DMA pipeline works (round 3) the 4-wave 128x128 tile,
+        // three blocks per CU, is the faster one per flop (tools/sweep_tiles.py on the repaired kernels)
+        const float eff = (mc && c == 2) ? 0.01f * (float)g_vtx_sw_mc_eff128 : t.eff;
+        const float cost = (float)rounds * (float)(t.bm * t.bn) / (eff * overlap);
         if (cost < best_cost) { best_cost = cost; best = c; }
     }
     return best;
@@ -1445,7 +1449,7 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
     // the DMA kernel addresses its operands through buffer descriptors: both must qualify (size, channel multiples)
     auto buf_ok = [&](int bk) { ALT<T, 1> a; make_a(a); BLT<T, 1> b; make_b(b); return a.buf_ok(bk) && b.buf_ok(bk); };
     const bool v2 = BF && g_vtx_contraction_generation >= 2 && buf_ok(32);
-    int c = pick_tile(M, N, split_k, v2);
+    int c = pick_tile(M, N, split_k, v2, ALT<T, 1>::MC);
     if constexpr (EP::STATS) {
         // The HBM-bound convolutions of stages 1-2 with a BatchNorm epilogue (K = 64...512: a handful of K steps, then
         // an epilogue that reads up to three more [M][N] tensors) are chains of memory latencies, not MFMA work: on

@@ -107,7 +107,7 @@ INCREMENTAL_DECODING = os.environ.get("VIRTEX_AMD_INCREMENTAL_DECODING", "1") !=
 
 # compute copies of the text heads' weights prepared on the branch stream under the backbone's first kernels instead of
 # in front of the whole forward pass (the one preparation launch is 0.18 ms at the head of every step)
-SPLIT_WEIGHT_PREP = os.environ.get("VIRTEX_AMD_SPLIT_WEIGHT_PREP", "1") != "0"
+SPLIT_WEIGHT_PREP = os.environ.get("VIRTEX_AMD_SPLIT_WEIGHT_PREP", "0") != "0"   # measured neutral (profiles/r03_ab_session5.txt): off
 
 # the two caption directions on two streams (A/B switch; see DESIGN.md, Streams)
 HEAD_STREAMS = os.environ.get("VIRTEX_AMD_HEAD_STREAMS", "1") != "0"
