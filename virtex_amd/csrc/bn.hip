@@ -11,8 +11,10 @@
 // reached from /root/reference/virtex/modules/visual_backbones.py:68-74 (eps 1e-5,
 // momentum 0.1, unbiased running variance).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "vtx_common.h"
+#include "pool_windows.h"
 
 extern int g_vtx_sw_bn_fin_wide;     // vtx_set_switch("bn_fin_wide"): 1024-thread finalize / compaction blocks (default off)
 
@@ -326,58 +328,49 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __rest
 // ---- the stem's tail: MaxPool2d(3,2,1) backward gathered on the fly inside the BatchNorm backward -------------
 // gradient wrt the pre-pool tensor at pixel (n, ih, iw): the dy of the (<= 2x2) pooling windows whose argmax is this
 // pixel (same gather as maxpool_bwd_kernel in pool.hip; first-maximum tie rule lives in the forward's argmax)
-template <class T>
-__device__ __forceinline__ void pool_gather(const T* __restrict__ dpool, const uint8_t* __restrict__ argmax, int n, int ih,
-                                            int iw, int c0, int C, int OH, int OW, float* g) {
-    constexpr int VEC = Elem<T>::VEC;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) g[j] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int th = ih + 1 - kh;
-        if (th < 0 || (th & 1) || (th >> 1) >= OH) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int tw = iw + 1 - kw;
-            if (tw < 0 || (tw & 1) || (tw >> 1) >= OW) continue;
-            const long off = (((long)n * OH + (th >> 1)) * OW + (tw >> 1)) * C + c0;
-            Vec16<T> d; d.load(dpool + off);
-            uint32_t aw[2] = {0u, 0u};                                           // VEC argmax bytes: 8 (bf16) or 4 (fp32, 4-aligned)
-            if constexpr (VEC == 8) { const uint2 am = *reinterpret_cast<const uint2*>(argmax + off); aw[0] = am.x; aw[1] = am.y; }
-            else aw[0] = *reinterpret_cast<const uint32_t*>(argmax + off);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                if (((aw[j >> 2] >> (8 * (j & 3))) & 0xffu) == (uint32_t)(kh * 3 + kw)) g[j] += d.v[j];
-        }
-    }
+__device__ __forceinline__ int bnpool_qdiv(int n, int d) {      // exact for 0 <= n < 2^24
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    const int r = n - q * d;
+    if (r < 0) --q; else if (r >= d) ++q;
+    return q;
 }
-
+// (PoolQuad, pool_windows.h: a thread owns a 2 x 2 quad of input pixels = exactly four pooling windows; everything it needs is
+// requested before anything is used)
 // reduce: s1 = sum dz, s2 = sum dz*xhat with dz = pool-gathered gradient masked by relu(xhat*gamma+beta) > 0
 template <class T>
 __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(
     const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ argmax, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ sums,
-    int N, int H, int W, int C, int OH, int OW, int TX, int rows_per_block) {
+    int N, int H, int W, int C, int OH, int OW, int TX, int quads_per_block) {
     constexpr int VEC = Elem<T>::VEC;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX, TY = 256 / TX;
     const int c0 = (blockIdx.y * TX + tx) * VEC;
-    const int P = N * H * W;
-    const int p0 = blockIdx.x * rows_per_block;
-    const int p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
+    const int QH = (H + 1) >> 1, QW = (W + 1) >> 1, NQ = N * QH * QW;
+    const int q0 = blockIdx.x * quads_per_block;
+    const int q1 = q0 + quads_per_block < NQ ? q0 + quads_per_block : NQ;
     float a[VEC], b[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { a[j] = b[j] = 0.f; mu[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; }
-    for (int p = p0 + ty; p < p1; p += TY) {
-        const int iw = p % W, t = p / W, ih = t % H, n = t / H;
-        Vec16<T> xv; xv.load(x + (size_t)p * C + c0);
-        float g[VEC];
-        pool_gather<T>(dpool, argmax, n, ih, iw, c0, C, OH, OW, g);
+    for (int q = q0 + ty; q < q1; q += TY) {
+        const int n = bnpool_qdiv(q, QH * QW), rem = q - n * QH * QW;
+        const int qa = bnpool_qdiv(rem, QW), qb = rem - qa * QW;
+        PoolQuad<T> quad;
+        quad.request(x, dpool, argmax, n, qa, qb, c0, H, W, C, OH, OW);
+        auto pixel = [&](auto K) {
+            constexpr int k = decltype(K)::value;
+            float g[VEC], xv[VEC];
+            quad.template gather<k>(g);
+            vtx_unpack_raw16<T>(quad.x[k], xv);
+            const bool in = (quad.pvalid >> k) & 1u;
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const float xh = (xv.v[j] - mu[j]) * rs[j];
-            const float d = xh * ga[j] + be[j] > 0.f ? g[j] : 0.f;
-            a[j] += d; b[j] += d * xh;
-        }
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (xv[j] - mu[j]) * rs[j];
+                const float d = (in && xh * ga[j] + be[j] > 0.f) ? g[j] : 0.f;
+                a[j] += d; b[j] += d * xh;
+            }
+        };
+        pixel(std::integral_constant<int, 0>{}); pixel(std::integral_constant<int, 1>{});
+        pixel(std::integral_constant<int, 2>{}); pixel(std::integral_constant<int, 3>{});
     }
     __shared__ float red[2][256 * VEC];
 #pragma unroll
@@ -401,24 +394,38 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(
     T* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
-    const long total = (long)N * H * W * cv;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c0 = (int)(i % cv) * VEC;
-        long p = i / cv;
-        const int iw = (int)(p % W); p /= W;
-        const int ih = (int)(p % H);
-        const int n = (int)(p / H);
-        Vec16<T> xv; xv.load(x + i * VEC);
-        float g[VEC];
-        pool_gather<T>(dpool, argmax, n, ih, iw, c0, C, OH, OW, g);
-        Vec16<T> o;
+    const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+    const long total = (long)N * QH * QW * cv;
+    // gridDim.x * 256 is a multiple of cv (apply_grid): a thread keeps its channel vector, coefficients live in registers
+    const int c0 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cv) * VEC;
+    float mu[VEC], rs[VEC], ga[VEC], be[VEC], k0[VEC], k1[VEC], k2[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const float xh = (xv.v[j] - mean[c0 + j]) * rstd[c0 + j];
-            const float d = xh * gamma[c0 + j] + beta[c0 + j] > 0.f ? g[j] : 0.f;
-            o.v[j] = coef[c0 + j] * (d - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
-        }
-        o.store(dx + i * VEC);
+    for (int j = 0; j < VEC; ++j) {
+        mu[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
+        k0[j] = coef[c0 + j]; k1[j] = coef[C + c0 + j]; k2[j] = coef[2 * C + c0 + j];
+    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i / cv);
+        const int n = bnpool_qdiv(q, QH * QW), rem = q - n * QH * QW;
+        const int qa = bnpool_qdiv(rem, QW), qb = rem - qa * QW;
+        PoolQuad<T> quad;
+        quad.request(x, dpool, argmax, n, qa, qb, c0, H, W, C, OH, OW);
+        auto pixel = [&](auto K) {
+            constexpr int k = decltype(K)::value;
+            float g[VEC], xv[VEC];
+            quad.template gather<k>(g);
+            vtx_unpack_raw16<T>(quad.x[k], xv);
+            Vec16<T> o;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (xv[j] - mu[j]) * rs[j];
+                const float d = xh * ga[j] + be[j] > 0.f ? g[j] : 0.f;
+                o.v[j] = k0[j] * (d - k1[j] - xh * k2[j]);
+            }
+            if ((quad.pvalid >> k) & 1u) o.store(dx + quad.xoff[k]);
+        };
+        pixel(std::integral_constant<int, 0>{}); pixel(std::integral_constant<int, 1>{});
+        pixel(std::integral_constant<int, 2>{}); pixel(std::integral_constant<int, 3>{});
     }
 }
 
@@ -427,12 +434,6 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(
 // recomputes the ReLU mask from x).  Every tap value is rounded to the storage type before the comparison, so pooled
 // values AND argmax are bit-identical to vtx_bn_fwd followed by vtx_maxpool3x3s2_fwd (first maximum wins on ties).
 // Thread layout of the pooling kernels: tx = channel vector (coefficients in registers), ty = output pixel.
-__device__ __forceinline__ int bnpool_qdiv(int n, int d) {      // exact for 0 <= n < 2^24
-    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
-    const int r = n - q * d;
-    if (r < 0) --q; else if (r >= d) ++q;
-    return q;
-}
 template <class T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                                   const float* __restrict__ scale, const float* __restrict__ beta,
@@ -453,23 +454,22 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
         float best[VEC]; int idx[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; idx[j] = 0; }
+        PoolTaps<T> taps;
+        taps.request(x, n, oh, ow, c0, H, W, C);             // all nine taps in flight, then consumed in (kh, kw) order
         bool first = true;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int k = 0; k < 9; ++k) {
+            const bool ok = (taps.valid >> k) & 1u;
+            float v[VEC];
+            vtx_unpack_raw16<T>(taps.v[k], v);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-                    Vec16<T> v; v.load(x + (((long)n * H + ih) * W + iw) * C + c0);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        float a = fmaxf((v.v[j] - mu[j]) * sc[j] + be[j], 0.f);      // exactly bn_apply_kernel's arithmetic
-                        if constexpr (sizeof(T) == 2) a = bf2f(f2bf(a));              // ... and its storage rounding
-                        if (first || a > best[j]) { best[j] = a; idx[j] = kh * 3 + kw; }
-                    }
-                    first = false;
-                }
+            for (int j = 0; j < VEC; ++j) {
+                float a = fmaxf((v[j] - mu[j]) * sc[j] + be[j], 0.f);      // exactly bn_apply_kernel's arithmetic
+                if constexpr (sizeof(T) == 2) a = bf2f(f2bf(a));              // ... and its storage rounding
+                if (ok && (first || a > best[j])) { best[j] = a; idx[j] = k; }
             }
+            first = first && !ok;
+        }
         Vec16<T> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
@@ -678,9 +678,12 @@ extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, c
     const long Pl = (long)N * H * W;
     VTX_CHECK(Pl < (1L << 31), VTX_ERR_SHAPE, "bn_bwd_maxpool: too many pixels");
     const int P = (int)Pl;
+    const long NQl = (long)N * ((H + 1) / 2) * ((W + 1) / 2);            // 2 x 2 quads of input pixels: one per thread and trip
+    VTX_CHECK(NQl < (1L << 24), VTX_ERR_SHAPE, "bn_bwd_maxpool: more than 2^24 pixel quads is not supported");
+    const int NQ = (int)NQl;
     hipStream_t st = (hipStream_t)stream;
     float* coef = workspace + C; float* sums = workspace + 4 * C;
-    ReducePlan rp = plan_reduce(P, C, vec);
+    ReducePlan rp = plan_reduce(NQ, C, vec);
     const double el = dtype == VTX_BF16 ? 2.0 : 4.0;
     const double pool_bytes = (double)N * OH * OW * C * (el + 1.0);
     if (dtype == VTX_BF16)
@@ -691,12 +694,12 @@ extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, c
                     (const float*)dpool, argmax, save_mean, save_rstd, gamma, beta, sums, N, H, W, C, OH, OW, rp.TX, rp.rows);
     VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, sums, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, rp.gx);
-    const long nvec = (long)P * C / vec;
+    const long nvec = (long)NQ * C / vec;
     if (dtype == VTX_BF16)
-        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x,
+        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const bf16_t*)x,
                     (const bf16_t*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (bf16_t*)dx, N, H, W, C, OH, OW);
     else
-        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec)), dim3(256), 0, st, (const float*)x,
+        VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const float*)x,
                     (const float*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (float*)dx, N, H, W, C, OH, OW);
     VTX_LAUNCH_CHECK();
     return VTX_OK;

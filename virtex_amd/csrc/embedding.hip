@@ -15,6 +15,9 @@ template <int NV> struct RowF32 {  // H fp32 values of one row, 4 per lane per c
     float v[NV][4];
 };
 
+__device__ __forceinline__ void emb_st4(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void emb_st4(bf16_t* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3])); }
+
 template <class T, int NV>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(
     const long long* __restrict__ tokens, const float* __restrict__ words, const float* __restrict__ pos,
@@ -29,14 +32,22 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     const int t = row % Tlen;
     const float* wrow = words + (size_t)tok * H;
     const float* prow = pos + (size_t)t * H;
+    // every vector of the two table rows is requested before any is used (vtx_loads_issued, vtx_common.h)
+    float4 wa[NV], pa[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * 4, cc = col < H ? col : 0;
+        wa[i] = *reinterpret_cast<const float4*>(wrow + cc);
+        pa[i] = *reinterpret_cast<const float4*>(prow + cc);
+    }
+    vtx_loads_issued();
     RowF32<NV> e;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = (i * 64 + lane) * 4;
         if (col < H) {
-            const float4 a = *reinterpret_cast<const float4*>(wrow + col);
-            const float4 b = *reinterpret_cast<const float4*>(prow + col);
+            const float4 a = wa[i], b = pa[i];
             e.v[i][0] = a.x + b.x; e.v[i][1] = a.y + b.y; e.v[i][2] = a.z + b.z; e.v[i][3] = a.w + b.w;
             s += e.v[i][0] + e.v[i][1] + e.v[i][2] + e.v[i][3];
         } else {
@@ -60,11 +71,15 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     for (int i = 0; i < NV; ++i) {
         const int col = (i * 64 + lane) * 4;
         if (col < H) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + col), b4 = *reinterpret_cast<const float4*>(beta + col);
+            const float ga[4] = {g4.x, g4.y, g4.z, g4.w}, be[4] = {b4.x, b4.y, b4.z, b4.w};
+            float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float y = (e.v[i][j] - mean) * rstd * gamma[col + j] + beta[col + j];
-                Elem<T>::st(out + base + col + j, keep * drop.apply(y, base + col + j));
+                const float y = (e.v[i][j] - mean) * rstd * ga[j] + be[j];
+                o[j] = keep * drop.apply(y, base + col + j);
             }
+            emb_st4(out + base + col, o);
         }
     }
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }

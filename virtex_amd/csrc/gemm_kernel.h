@@ -617,9 +617,40 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         }
         return v;
     }
+    // The global operands of ONE 16-byte output chunk (row m, columns n .. n+EPV-1).  They do not depend on the
+    // accumulators, so the kernel issues them for every chunk of a 16-row step BEFORE the step's transform and its trip
+    // through the LDS strip, and consumes them (finish / finish_stats) afterwards: the loads of a step are all in flight
+    // together and land under the strip traffic.  (Loading inside the per-chunk store -- rounds 1-2 -- made every chunk
+    // a chain of residual load -> wait -> x / mask load -> wait -> sixteen single LDS parameter reads with a wait each ->
+    // store: one 16-byte load in flight per wave in kernels that are HBM-bound.)
+    // Only the fused BatchNorm-backward epilogue (three operand tensors, HBM-bound kernels) hoists; the other modes load
+    // their residual inside finish (hoisting there costs registers in every instantiation for an operand most launches
+    // do not have).
+    struct Ops { uint4 res, x; uint32_t mb; };
+    __device__ __forceinline__ Ops load_ops(int m, int n) const {
+        Ops o;
+        o.res = o.x = make_uint4(0u, 0u, 0u, 0u);
+        o.mb = 0u;
+        if constexpr (STATS_MODE != STATS_BWD) return o;
+        if (m >= M || n >= N) return o;
+        constexpr int EPV = 16 / (int)sizeof(T);
+        const long mr = out_row(m);
+        if (residual) o.res = *reinterpret_cast<const uint4*>(residual + mr * ldr + n);
+        if constexpr (STATS_MODE == STATS_BWD) {
+            static_assert(STATS_MODE != STATS_BWD || EPV == 8 || EPV == 4, "chunk = 16 bytes");
+            o.x = *reinterpret_cast<const uint4*>(bn_x + mr * ldx + n);
+            // the mask byte of the chunk (bf16: one byte per 16-byte chunk); without a bit mask the load is aimed at one
+            // fixed valid byte (a broadcast, no traffic) instead of being skipped: a skipped load leaves a default to be
+            // written on the other path, and hipcc guards that write with s_waitcnt vmcnt(0) -- in front of the step
+            const uint8_t* bp = reinterpret_cast<const uint8_t*>(bn_rstd);
+            if constexpr (EPV == 8) bp = bn_ybits ? bn_ybits + ((mr * ldy + n) >> 3) : bp;
+            o.mb = *bp;
+        }
+        return o;
+    }
     // 16 bytes (8 bf16 / 4 fp32) of row m starting at column n: + residual, store.  N is a multiple of 4,
     // so a chunk is either entirely inside the row, or (bf16 only) its first half is.
-    __device__ __forceinline__ void store_wide(int m, int n, uint4 w) const {
+    __device__ __forceinline__ void finish(int m, int n, uint4 w, const Ops&) const {
         if (m >= M || n >= N) return;
         constexpr int EPV = 16 / (int)sizeof(T);
         const long mr = out_row(m);
@@ -641,9 +672,17 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         } else *reinterpret_cast<uint2*>(out + o) = make_uint2(w.x, w.y);   // bf16: 4 elements
     }
     // The same, accumulating the statistics of this chunk.  par = this chunk's columns inside the block's LDS parameter
-    // table ([4][PBN] floats: FWD {shift}; BWD {rstd, -mean*rstd, gamma, beta}); s1/s2 = the lane's accumulators.
-    __device__ __forceinline__ void store_wide_stats(int m, int n, uint4 w, const float* par, int PBN, float* s1,
-                                                     float* s2) const {
+    // table ([4][PBN] floats: FWD {shift}; BWD {rstd, -mean*rstd, gamma, beta}), read as 16-byte vectors; s1/s2 = the
+    // lane's accumulators.
+    template <int EPV> __device__ static __forceinline__ void ld_par(const float* p, float* v) {
+#pragma unroll
+        for (int q = 0; q < EPV / 4; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+        }
+    }
+    __device__ __forceinline__ void finish_stats(int m, int n, uint4 w, const Ops& ops, const float* par, int PBN, float* s1,
+                                                 float* s2) const {
         if (m >= M || n >= N) return;
         constexpr int EPV = 16 / (int)sizeof(T);
         const long mr = out_row(m);
@@ -651,40 +690,63 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         unpack16<T>(w, f);
         if (residual) {
             float r[EPV];
-            unpack16<T>(*reinterpret_cast<const uint4*>(residual + mr * ldr + n), r);
+            if constexpr (STATS_MODE == STATS_BWD) unpack16<T>(ops.res, r);
+            else unpack16<T>(*reinterpret_cast<const uint4*>(residual + mr * ldr + n), r);
 #pragma unroll
             for (int e = 0; e < EPV; ++e) f[e] += r[e];
         }
         if constexpr (STATS_MODE == STATS_FWD) {
+            float sh[EPV];
+            ld_par<EPV>(par, sh);
             w = pack16<T>(f);
             unpack16<T>(w, f);                   // statistics of what is stored (what the BatchNorm will read)
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) { const float d = f[e] - par[e]; s1[e] += d; s2[e] += d * d; }
+            for (int e = 0; e < EPV; ++e) { const float d = f[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
         } else {
-            float x[EPV];
-            unpack16<T>(*reinterpret_cast<const uint4*>(bn_x + mr * ldx + n), x);
-            if (bn_ybits) {
-                static_assert(STATS_MODE != STATS_BWD || EPV == 8, "mask bits: one byte per 16-byte chunk (bf16)");
-                const uint32_t mb = bn_ybits[(mr * ldy + n) >> 3];
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) f[e] = (mb >> e) & 1u ? f[e] : 0.f;
-            } else if (bn_y) {
+            // four elements (two stored words) at a time: the 16 parameter values of a half are all the registers the
+            // table costs (the kernel class lives on six waves per SIMD = 80 VGPRs)
+            static_assert(STATS_MODE != STATS_BWD || sizeof(T) == 2, "the fused BatchNorm backward epilogue is bf16");
+            const bool remask = !bn_y && !bn_ybits && bn_beta;      // mask recomputed from x (interior BatchNorms)
+            uint32_t mb = bn_ybits ? ops.mb : 0xffu;
+            if (!bn_ybits && bn_y) {                 // the mask as the whole post-ReLU tensor (VIRTEX_AMD_RELU_BITS=0)
                 float y[EPV];
                 unpack16<T>(*reinterpret_cast<const uint4*>(bn_y + mr * ldy + n), y);
+                mb = 0u;
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) f[e] = y[e] > 0.f ? f[e] : 0.f;
+                for (int e = 0; e < EPV; ++e) mb |= y[e] > 0.f ? 1u << e : 0u;
             }
-            const bool remask = !bn_y && !bn_ybits && bn_beta;
-            float xh[EPV];
+            const uint32_t xi[4] = {ops.x.x, ops.x.y, ops.x.z, ops.x.w};
+            uint32_t wo[4];
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                xh[e] = x[e] * par[e] + par[PBN + e];
-                if (remask) f[e] = xh[e] * par[2 * PBN + e] + par[3 * PBN + e] > 0.f ? f[e] : 0.f;
+            for (int h = 0; h < 2; ++h) {
+                float rs[4], sh[4], ga[4], be[4], x[4], xh[4];
+                ld_par<4>(par + 4 * h, rs);
+                ld_par<4>(par + PBN + 4 * h, sh);
+                ld_par<4>(par + 2 * PBN + 4 * h, ga);
+                ld_par<4>(par + 3 * PBN + 4 * h, be);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    x[2 * k] = __uint_as_float(xi[2 * h + k] << 16);
+                    x[2 * k + 1] = __uint_as_float(xi[2 * h + k] & 0xffff0000u);
+                }
+                float* g = f + 4 * h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    g[e] = (mb >> (4 * h + e)) & 1u ? g[e] : 0.f;
+                    xh[e] = x[e] * rs[e] + sh[e];
+                    const bool pos = xh[e] * ga[e] + be[e] > 0.f;
+                    g[e] = (!remask || pos) ? g[e] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {    // sums of what is stored: bn_bwd_apply_fused combines them with the ROUNDED dz
+                    const uint32_t u = f2bf2(g[2 * k], g[2 * k + 1]);
+                    wo[2 * h + k] = u;
+                    g[2 * k] = __uint_as_float(u << 16); g[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[4 * h + e] += g[e]; s2[4 * h + e] += g[e] * xh[e]; }
             }
-            w = pack16<T>(f);
-            unpack16<T>(w, f);                   // sums of what is stored: bn_bwd_apply_fused combines them with the ROUNDED dz
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) { s1[e] += f[e]; s2[e] += f[e] * xh[e]; }
+            w = make_uint4(wo[0], wo[1], wo[2], wo[3]);
         }
         if (nt) st16_nt(out + mr * ldc + n, u32x4_t{w.x, w.y, w.z, w.w});
         else *reinterpret_cast<uint4*>(out + mr * ldc + n) = w;
@@ -724,6 +786,7 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
 };
 // out(fp32) += alpha * acc     (split-K partial sums and "+=" gradient accumulation)
 struct EpiAtomic {
+    struct Ops {};
     static constexpr bool STAGED = false;
     static constexpr bool STATS = false;
     static constexpr int SMODE = STATS_NONE;
@@ -733,7 +796,6 @@ struct EpiAtomic {
     float* stat_parts = nullptr;
     const float* stat_shift = nullptr;
     __device__ __forceinline__ f32x4_t transform(int, int, f32x4_t v) const { return v; }
-    __device__ __forceinline__ void store_wide(int, int, uint4) const {}
     __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
         if (m >= M || n >= N) return;
         float* o = out + (long)m * ldc + n;
@@ -747,6 +809,7 @@ struct EpiAtomic {
 // and the sum of exp(v - max) over its own columns into pmax/psum[column group][M]; a tiny kernel folds the groups
 // into lse[m].  The lane that holds column target[m] also records that logit.  Nothing else is stored.
 struct EpiRowLse {
+    struct Ops {};
     static constexpr bool STAGED = false;
     static constexpr bool STATS = false;
     static constexpr int SMODE = STATS_NONE;
@@ -757,7 +820,6 @@ struct EpiRowLse {
     float* stat_parts = nullptr; const float* stat_shift = nullptr;
     const void* residual = nullptr; const void* preact = nullptr; const void* bn_x = nullptr; const void* bn_y = nullptr;
     __device__ __forceinline__ f32x4_t transform(int, int, f32x4_t v) const { return v; }
-    __device__ __forceinline__ void store_wide(int, int, uint4) const {}
     __device__ __forceinline__ void operator()(int, int, f32x4_t) const {}
 };
 
@@ -1093,6 +1155,15 @@ __device__ __forceinline__ void mc_rows(vtx_v4s_t (&ra)[MT][2], vtx_v4s_t (&rb)[
     }
 }
 
+#ifndef VTX_EPI_BWD_OCC
+#define VTX_EPI_BWD_OCC 4      // waves per SIMD the 8-wave 128x128 kernels with the fused BatchNorm-backward epilogue are built for
+#endif
+#ifndef VTX_EPI_OPS_PRE
+#define VTX_EPI_OPS_PRE 0      // 1 (with OPS_ALL): ... and already in front of the K loop, together with the first operand tiles
+#endif
+#ifndef VTX_EPI_OPS_ALL
+#define VTX_EPI_OPS_ALL 1      // 1: the epilogue operands of ALL 16-row steps of a wave tile are fetched up front (<= 4 chunks)
+#endif
 // Block = WM x WN waves; block tile BM x BN; wave tile (BM/WM) x (BN/WN).  Large tiles matter for the
 // L2 -> LDS bandwidth, not only for LDS: a 128x128 tile needs 2*(128+128)*64 B per 2*128*128*32 flop
 // = 64 flop/B, i.e. 39 TB/s of cache bandwidth at the MFMA peak (L2 delivers ~34); 256x256 needs half.
@@ -1100,7 +1171,7 @@ template <int BM, int BN, int WM, int WN, class AL, class BL, class EP, int BK =
 // Second launch bound = minimum waves per SIMD the register allocation must leave room for: 8-wave blocks on 128x128
 // tiles are meant to run THREE per CU (six waves per SIMD = 80 VGPRs: the HBM-bound layers live on blocks in flight),
 // 8-wave blocks on 256x128 tiles two (128 VGPRs), 4-wave blocks on 128x128 tiles three (168), on 128x64 / 64x128 four (128).
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && BM * BN <= 128 * 128) ? 6 : (WM * WN == 8 && BM * BN <= 256 * 128) ? 4 :
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 && BM * BN <= 128 * 128) ? (EP::SMODE == STATS_BWD ? VTX_EPI_BWD_OCC : 6) : (WM * WN == 8 && BM * BN <= 256 * 128) ? 4 :
                                            (WM * WN == 4 && BM * BN == 128 * 128) ? 3 : (WM * WN == 4 && BM * BN == 128 * 64) ? 4 : 1)
 void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
                                                                       int kt_per_split, int abl) {
@@ -1148,6 +1219,46 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // Statistics epilogues: the per-channel parameters of this block's columns are fetched NOW, into registers, and
+    // written to their LDS table after the K loop -- fetched there (rounds 1-2) they were three to four dependent L2
+    // round trips in front of the epilogue of blocks whose whole K loop is one or two steps.
+    constexpr int PPT = EP::SMODE == STATS_NONE ? 1 : (BN + 64 * NW - 1) / (64 * NW);    // table columns per thread
+    float pre[PPT][4];
+    if constexpr (EP::SMODE != STATS_NONE) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int c = tid + q * 64 * NW, n = n0 + c;
+            pre[q][0] = pre[q][1] = pre[q][2] = pre[q][3] = 0.f;
+            if (c < BN && n < ep.N) {
+                if constexpr (EP::SMODE == STATS_FWD) {
+                    if (ep.stat_shift) pre[q][0] = ep.stat_shift[n];
+                } else {
+                    pre[q][0] = ep.bn_rstd[n]; pre[q][1] = ep.bn_mean[n];
+                    if (ep.bn_gamma) pre[q][2] = ep.bn_gamma[n];
+                    if (ep.bn_beta) pre[q][3] = ep.bn_beta[n];
+                }
+            }
+        }
+    }
+
+    // Wave tiles of at most four output chunks per lane (8 waves on 128x128): ALL operand chunks of the fused BatchNorm-
+    // backward epilogue are requested here, in front of the K loop -- the short-K layers this epilogue serves are then ONE
+    // memory latency deep per block (operand tiles and epilogue operands in flight together), not two in a row.
+    constexpr int E_CPR = WTN * (int)sizeof(typename EP::Out) / 16, E_EPV = 16 / (int)sizeof(typename EP::Out);
+    constexpr int E_NCH = (16 * E_CPR + 63) / 64;
+    constexpr bool OPS_ALL = VTX_EPI_OPS_ALL && EP::STAGED && EP::SMODE == STATS_BWD && MT * E_NCH <= 4;
+    constexpr bool OPS_PRE = OPS_ALL && VTX_EPI_OPS_PRE;
+    typename EP::Ops ops[OPS_ALL ? MT : 1][E_NCH];
+    if constexpr (OPS_PRE) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < E_NCH; ++q) {
+                const int c = lane + 64 * q;
+                ops[i][q] = ep.load_ops(c < 16 * E_CPR ? m0 + wm * WTM + i * 16 + c / E_CPR : ep.M, n0 + wn * WTN + (c % E_CPR) * E_EPV);
+            }
+    }
 
 #ifndef VTX_ABLATE          // measurement builds (tools/ablate_gemm.py) compile the ablation switches in
     abl = 0;                // (bit 4, the A/B switch of the split-K block order, has been consumed above)
@@ -1254,15 +1365,15 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
         if constexpr (SM != STATS_NONE) {
 #pragma unroll
             for (int e = 0; e < EPV; ++e) s1[e] = s2[e] = 0.f;
-            for (int c = tid; c < BN; c += 64 * NW) {             // per-channel parameters of this block's columns
-                const int n = n0 + c;
-                const bool ok = n < ep.N;
-                if constexpr (SM == STATS_FWD) par[c] = (ok && ep.stat_shift) ? ep.stat_shift[n] : 0.f;
-                else {
-                    const float rs = ok ? ep.bn_rstd[n] : 0.f, mu = ok ? ep.bn_mean[n] : 0.f;
-                    par[c] = rs; par[BN + c] = -mu * rs;
-                    par[2 * BN + c] = (ok && ep.bn_gamma) ? ep.bn_gamma[n] : 0.f;
-                    par[3 * BN + c] = (ok && ep.bn_beta) ? ep.bn_beta[n] : 0.f;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {                       // per-channel parameters of this block's columns
+                const int c = tid + q * 64 * NW;
+                if (c < BN) {
+                    if constexpr (SM == STATS_FWD) par[c] = pre[q][0];
+                    else {
+                        par[c] = pre[q][0]; par[BN + c] = -pre[q][1] * pre[q][0];
+                        par[2 * BN + c] = pre[q][2]; par[3 * BN + c] = pre[q][3];
+                    }
                 }
             }
             __syncthreads();
@@ -1276,9 +1387,28 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
                 for (int j = 0; j < NT; ++j) bv[j] = ep.bias4(n0 + wn * WTN + j * 16 + 4 * (lane >> 4));
             }
         }
+        constexpr int NCH = (16 * CPR + 63) / 64;                 // chunks a lane drains per 16-row step
+        static_assert(NCH == E_NCH && CPR == E_CPR && EPV == E_EPV, "operand prefetch in front of the K loop");
+        if constexpr (OPS_ALL && !OPS_PRE) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int c = lane + 64 * q;
+                    ops[i][q] = ep.load_ops(c < 16 * CPR ? m0 + wm * WTM + i * 16 + c / CPR : ep.M, n0 + wn * WTN + (c % CPR) * EPV);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mrow = m0 + wm * WTM + i * 16;
+            // the step's global operands (residual, BatchNorm input, mask) first: independent of the accumulators
+            if constexpr (!OPS_ALL) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int c = lane + 64 * q;
+                    ops[0][q] = ep.load_ops(c < 16 * CPR ? mrow + c / CPR : ep.M, n0 + wn * WTN + (c % CPR) * EPV);
+                }
+            }
             const typename EP::RowData rd = ep.row_data(mrow + (lane & 15));
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -1287,11 +1417,14 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c = lane; c < 16 * CPR; c += 64) {
-                const int r = c / CPR, ch = c % CPR;
-                const uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
-                if constexpr (SM == STATS_NONE) ep.store_wide(mrow + r, n0 + wn * WTN + ch * EPV, w);
-                else ep.store_wide_stats(mrow + r, n0 + wn * WTN + ch * EPV, w, par + wn * WTN + ch * EPV, BN, s1, s2);
+            for (int q = 0; q < NCH; ++q) {
+                const int c = lane + 64 * q;
+                if (c < 16 * CPR) {
+                    const int r = c / CPR, ch = c % CPR;
+                    const uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
+                    if constexpr (SM == STATS_NONE) ep.finish(mrow + r, n0 + wn * WTN + ch * EPV, w, ops[OPS_ALL ? i : 0][q]);
+                    else ep.finish_stats(mrow + r, n0 + wn * WTN + ch * EPV, w, ops[OPS_ALL ? i : 0][q], par + wn * WTN + ch * EPV, BN, s1, s2);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -1410,6 +1543,7 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
 // efficiency); candidates with BN > what N needs are skipped.
 struct TileCand { int bm, bn, resident; float eff; };
 extern int g_vtx_tile_override;   // tests: force a candidate (-1 = automatic)
+extern int g_vtx_sw_stats_tile;   // vtx_set_switch("stats_tile"): which statistics epilogues take 8-wave 128x128 tiles on large M
 extern int g_vtx_sw_mc_eff128;    // percent: relative efficiency of 128x128 tiles for k-major operands (vtx_set_switch("mc_eff128"))
 inline int pick_tile(int M, int N, int splits, bool allow256, bool mc = false) {
     if (g_vtx_tile_override >= 0 && (allow256 || g_vtx_tile_override >= 2)) return g_vtx_tile_override;
@@ -1456,7 +1590,8 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
         // 128x128 tiles with EIGHT waves (wave tile 32x64) the epilogue chain is half as long and three blocks fit a
         // CU.  Measured per layer at bs=256 (tools/bench_1x1.py: tensors of 0.25-2.2 GB, not cache-fed): input gradient
         // + fused BatchNorm backward 320 -> 275 us (64->256 @56), 157 -> 146 (128->512 @28); 14x14 layers lose 10 %.
-        static const bool stats_tile = [] { const char* e = getenv("VIRTEX_AMD_STATS_TILE"); return !e || atoi(e) != 0; }();
+        const int rule = g_vtx_sw_stats_tile;
+        const bool stats_tile = rule == 1 || (rule == 2 && EP::SMODE == STATS_FWD) || (rule == 3 && EP::SMODE == STATS_BWD);
         if (stats_tile && v2 && c == 1 && g_vtx_tile_override < 0 && M >= 100000) c = 6;
     }
     g_vtx_last_generation = v2 ? 2 : 1;

@@ -22,17 +22,28 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;  // whole wave exits together (row is wave-uniform)
     const size_t base = (size_t)row * H;
+    // every vector of the row (and of the residual branch) is requested before any is used (vtx_loads_issued, vtx_common.h)
+    uint4 xr[NV], yr[NV];
+    const T* yp = y ? y : x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC, cc = col < H ? col : 0;
+        xr[i] = *reinterpret_cast<const uint4*>(x + base + cc);
+        yr[i] = *reinterpret_cast<const uint4*>(yp + base + cc);
+    }
+    vtx_loads_issued();
     Vec16<T> z[NV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int col = (i * 64 + lane) * VEC;
         if (col < H) {
-            z[i].load(x + base + col);
+            vtx_unpack_raw16<T>(xr[i], z[i].v);
             if (y) {
-                Vec16<T> t; t.load(y + base + col);
+                float t[VEC];
+                vtx_unpack_raw16<T>(yr[i], t);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) z[i].v[j] += drop.apply(t.v[j], base + col + j);
+                for (int j = 0; j < VEC; ++j) z[i].v[j] += drop.apply(t[j], base + col + j);
             }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) s += z[i].v[j];
@@ -56,10 +67,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     for (int i = 0; i < NV; ++i) {
         const int col = (i * 64 + lane) * VEC;
         if (col < H) {
+            float ga[VEC], be[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; j += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(gamma + col + j), b4 = *reinterpret_cast<const float4*>(beta + col + j);
+                ga[j] = g4.x; ga[j + 1] = g4.y; ga[j + 2] = g4.z; ga[j + 3] = g4.w;
+                be[j] = b4.x; be[j + 1] = b4.y; be[j + 2] = b4.z; be[j + 3] = b4.w;
+            }
             Vec16<T> o;
 #pragma unroll
             for (int j = 0; j < VEC; ++j)
-                o.v[j] = (z[i].v[j] - mean) * rstd * gamma[col + j] + beta[col + j];
+                o.v[j] = (z[i].v[j] - mean) * rstd * ga[j] + be[j];
             o.store(out + base + col);
         }
     }
@@ -86,25 +104,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
         const size_t base = (size_t)row * H;
         const float mean = mean_in[row], rstd = rstd_in[row];
+        uint4 xr[NV], yr[NV], gr[NV];
+        const T* yp = y ? y : x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int col = (i * 64 + lane) * VEC, cc = col < H ? col : 0;
+            xr[i] = *reinterpret_cast<const uint4*>(x + base + cc);
+            yr[i] = *reinterpret_cast<const uint4*>(yp + base + cc);
+            gr[i] = *reinterpret_cast<const uint4*>(dout + base + cc);
+        }
+        vtx_loads_issued();
         Vec16<T> xh[NV], g[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (i * 64 + lane) * VEC;
             if (col < H) {
-                xh[i].load(x + base + col);
+                vtx_unpack_raw16<T>(xr[i], xh[i].v);
                 if (y) {
-                    Vec16<T> t; t.load(y + base + col);
+                    float t[VEC];
+                    vtx_unpack_raw16<T>(yr[i], t);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) xh[i].v[j] += drop.apply(t.v[j], base + col + j);
+                    for (int j = 0; j < VEC; ++j) xh[i].v[j] += drop.apply(t[j], base + col + j);
                 }
-                g[i].load(dout + base + col);
+                vtx_unpack_raw16<T>(gr[i], g[i].v);
+                float ga[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; j += 4) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(gamma + col + j);
+                    ga[j] = g4.x; ga[j + 1] = g4.y; ga[j + 2] = g4.z; ga[j + 3] = g4.w;
+                }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const float h = (xh[i].v[j] - mean) * rstd;
                     const float d = g[i].v[j];
                     ag[i][j] += d * h; ab[i][j] += d;
-                    const float gg = d * gamma[col + j];
+                    const float gg = d * ga[j];
                     xh[i].v[j] = h; g[i].v[j] = gg;
                     s1 += gg; s2 += gg * h;
                 }

@@ -3,6 +3,7 @@
 // (/root/reference/virtex/modules/visual_backbones.py:68-74; -inf padding, first maximum
 // wins on ties -- post-ReLU inputs tie at 0 all the time, so the tie rule is observable).
 #include "vtx_common.h"
+#include "pool_windows.h"
 
 namespace {
 
@@ -49,20 +50,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
         float best[VEC]; int idx[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { best[j] = -INFINITY; idx[j] = 0; }
+        PoolTaps<T> taps;
+        taps.request(x, n, oh, ow, c0, H, W, C);             // all nine taps in flight, then consumed in (kh, kw) order
         bool first = true;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int k = 0; k < 9; ++k) {
+            const bool ok = (taps.valid >> k) & 1u;
+            float v[VEC];
+            vtx_unpack_raw16<T>(taps.v[k], v);
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-                    Vec16<T> v; v.load(x + (((long)n * H + ih) * W + iw) * C + c0);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j)
-                        if (first || v.v[j] > best[j]) { best[j] = v.v[j]; idx[j] = kh * 3 + kw; }
-                    first = false;
-                }
-            }
+            for (int j = 0; j < VEC; ++j)
+                if (ok && (first || v[j] > best[j])) { best[j] = v[j]; idx[j] = k; }
+            first = first && !ok;
+        }
         Vec16<T> o;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) o.v[j] = best[j];
@@ -87,25 +87,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     for (int p = blockIdx.x * TY + ty; p < P; p += gridDim.x * TY) {
         const int n = pool_qdiv(p, H * W), rem = p - n * H * W;
         const int ih = pool_qdiv(rem, W), iw = rem - ih * W;
+        PoolWindows<T> win;
+        win.request(dy, argmax, n, ih, iw, c0, C, OH, OW);   // the <= 2 x 2 windows containing this pixel, all in flight
         Vec16<T> acc;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc.v[j] = 0.f;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int th = ih + 1 - kh;
-            if (th < 0 || (th & 1) || (th >> 1) >= OH) continue;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int tw = iw + 1 - kw;
-                if (tw < 0 || (tw & 1) || (tw >> 1) >= OW) continue;
-                const long off = (((long)n * OH + (th >> 1)) * OW + (tw >> 1)) * C + c0;
-                Vec16<T> g; g.load(dy + off);
-                const typename AP::W am = *reinterpret_cast<const typename AP::W*>(argmax + off);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    if (AP::get(am, j) == (uint32_t)(kh * 3 + kw)) acc.v[j] += g.v[j];
-            }
-        }
+        win.gather(acc.v);
         acc.store(dx + (long)p * C + c0);
     }
 }

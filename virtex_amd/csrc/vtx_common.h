@@ -204,6 +204,25 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
+// Raw 16-byte vectors: kernels that must have SEVERAL loads in flight request them all as uint4 (address clamped where the
+// element does not exist), call vtx_loads_issued(), and only then unpack / mask.  Written as `if (exists) { load; use; }` hipcc
+// (ROCm 7.2) puts an s_waitcnt vmcnt(0) inside every branch: a chain of memory latencies per thread (round 3: pooling,
+// LayerNorm, embedding, the contraction epilogue).  vtx_loads_issued keeps the scheduler from sinking the requested loads back between their uses (it does, to save registers)
+__device__ __forceinline__ void vtx_loads_issued() {
+#ifndef HIPEMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <class T> __device__ __forceinline__ void vtx_unpack_raw16(uint4 w, float* f);
+template <> __device__ __forceinline__ void vtx_unpack_raw16<bf16_t>(uint4 w, float* f) {
+    const uint32_t u[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void vtx_unpack_raw16<float>(uint4 w, float* f) {
+    f[0] = __uint_as_float(w.x); f[1] = __uint_as_float(w.y); f[2] = __uint_as_float(w.z); f[3] = __uint_as_float(w.w);
+}
+
 // ---------------------------------------------------------------------------------------
 // wave64 / block reductions
 // ---------------------------------------------------------------------------------------

@@ -40,9 +40,11 @@ FUSE_BN_STATS = os.environ.get("VIRTEX_AMD_FUSE_BN_STATS", "1") != "0"
 # last block (whose gradient comes from the text heads) keep the stand-alone kernels.
 FUSE_BN_BWD = os.environ.get("VIRTEX_AMD_FUSE_BN_BWD", "1") != "0"
 # the stem's tail (max-pool backward -> ReLU mask -> BatchNorm backward) in two passes without the pre-pool gradient
-# tensor (vtx_bn_bwd_maxpool).  Measured SLOWER (1.19 vs 1.11 ms of kernel time, step 33.4 vs 33.1 ms): the 3x3/s2
-# gather is instruction-bound (0.9 TB/s) and the fusion runs it twice to save 1 GB of traffic -> off by default.
-FUSE_STEM_TAIL = os.environ.get("VIRTEX_AMD_FUSE_STEM_TAIL", "0") != "0"
+# tensor (vtx_bn_bwd_maxpool).  Rounds 1-2: slower than the three-kernel path, because the gather was a chain of memory
+# latencies (a wait inside the branch around every candidate window).  Round 3: a thread owns a 2 x 2 pixel quad = four
+# windows, everything requested before anything is used (pool_windows.h): 312 us of kernels instead of 618 at the very
+# end of the backward pass, 26.00 -> 25.69 ms/step (profiles/r03_ab_session10.txt) -> on by default.
+FUSE_STEM_TAIL = os.environ.get("VIRTEX_AMD_FUSE_STEM_TAIL", "1") != "0"
 # forward counterpart: BatchNorm + ReLU + max-pool of the stem in one pass, the 411 MB tensor between them never written
 # (pooled values and argmax bit-identical to the three-kernel path).  Round 3, interleaved A/B in one process:
 # 27.72 -> 27.56 ms/step (profiles/r03_ab_session1.txt) -> on by default.
