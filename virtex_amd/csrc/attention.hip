@@ -196,9 +196,11 @@ __device__ __forceinline__ void st4_bf16(bf16_t* p, f32x4_t v) {
                                               f2bf2(v[2], v[3]));
 }
 __device__ __forceinline__ bf16x8_t ld_frag(const bf16_t* base, long ld, int row, int nrows, int col) {
-    // 8 consecutive bf16 of row `row` (zeros past the end of the tile)
-    if (row >= nrows) return bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-    return *reinterpret_cast<const bf16x8_t*>(base + (long)row * ld + col);
+    // 8 consecutive bf16 of row `row` (zeros past the end of the tile).  The load is unconditional (row 0 stands in for rows
+    // past the end) and masked afterwards: as `if (row < nrows) load` every fragment waited for its own round trip
+    const bool in = row < nrows;
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(base + (long)(in ? row : 0) * ld + col);
+    return in ? v : bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
 }
 __device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
     bf16x8_t r;
@@ -206,15 +208,28 @@ __device__ __forceinline__ bf16x8_t pack8(const float* lo, const float* hi) {
     for (int t = 0; t < 4; ++t) { r[t] = (short)f2bf(lo[t]); r[4 + t] = (short)f2bf(hi[t]); }
     return r;
 }
-// rows x 64 bf16 tile -> LDS (pitch VROW), rows >= nrows zero-filled up to `pad_rows`; one wave
-__device__ __forceinline__ void stage_tile(bf16_t* dst, const bf16_t* src, long ld, int nrows, int pad_rows, int lane) {
-    for (int c = lane; c < pad_rows * 8; c += 64) {
-        const int r = c >> 3, col = (c & 7) * 8;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (r < nrows) v = *reinterpret_cast<const uint4*>(src + (long)r * ld + col);
-        *reinterpret_cast<uint4*>(dst + r * VROW + col) = v;
+// rows x 64 bf16 tile -> LDS (pitch VROW), rows >= nrows zero-filled up to PAD rows; one wave.  Two phases so that a kernel
+// can have the loads of all its tiles in flight before the first LDS store waits for any of them.
+template <int PAD> struct TileStage {
+    static constexpr int TRIPS = PAD * 8 / 64;
+    uint4 v[TRIPS];
+    int rows;
+    __device__ __forceinline__ void request(const bf16_t* src, long ld, int nrows, int lane) {
+        rows = nrows;
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int c = lane + 64 * t, r = c >> 3, col = (c & 7) * 8;
+            v[t] = *reinterpret_cast<const uint4*>(src + (long)(r < nrows ? r : 0) * ld + col);
+        }
     }
-}
+    __device__ __forceinline__ void put(bf16_t* dst, int lane) const {       // (the zero fill happens here: a select next to the
+#pragma unroll                                                               //  load would wait for it)
+        for (int t = 0; t < TRIPS; ++t) {
+            const int c = lane + 64 * t, r = c >> 3, col = (c & 7) * 8;
+            *reinterpret_cast<uint4*>(dst + r * VROW + col) = r < rows ? v[t] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+};
 // fragment of the TRANSPOSED tile: rows = columns c0..c0+15 of the LDS tile, k-set {kb + jj} U {kb + 16 + jj}
 __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int c0, int kb, int lane) {
     const int w = lane & 15;
@@ -333,8 +348,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, bf16_t* 
     const bf16_t* q = (const bf16_t*)a.q + (long)b * a.T * a.ldq + h * D;
     const bf16_t* k = (const bf16_t*)a.k + (long)b * a.S * a.ldk + h * D;
     const bf16_t* v = (const bf16_t*)a.v + (long)b * a.S * a.ldv + h * D;
-    stage_tile(sV[wave], v, a.ldv, a.S, SP, lane);
-    const int len = a.lengths ? (int)a.lengths[b] : a.S;
+    const int len = a.lengths ? (int)a.lengths[b] : a.S;      // requested with the tile, not behind it
+    {
+        TileStage<SP> tv;
+        tv.request(v, a.ldv, a.S, lane);
+        vtx_loads_issued();
+        tv.put(sV[wave], lane);
+    }
     float p[2][4][4];
     mfma_probabilities(a, q, k, len, lane, p);
     if (a.drop.thresh) {
@@ -402,10 +422,13 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a, const bf
     const bf16_t* k = (const bf16_t*)a.k + (long)b * a.S * a.ldk + h * D;
     const bf16_t* v = (const bf16_t*)a.v + (long)b * a.S * a.ldv + h * D;
     const bf16_t* go = dout + (long)b * a.T * a.ldo + h * D;
-    stage_tile(sK[wave], k, a.ldk, a.S, SP, lane);
-    stage_tile(sQ[wave], q, a.ldq, a.T, TMAX, lane);
-    stage_tile(sO[wave], go, a.ldo, a.T, TMAX, lane);
-    const int len = a.lengths ? (int)a.lengths[b] : a.S;
+    const int len = a.lengths ? (int)a.lengths[b] : a.S;      // requested with the tiles, not behind them
+    {
+        TileStage<SP> tk; TileStage<TMAX> tq, to;
+        tk.request(k, a.ldk, a.S, lane); tq.request(q, a.ldq, a.T, lane); to.request(go, a.ldo, a.T, lane);
+        vtx_loads_issued();
+        tk.put(sK[wave], lane); tq.put(sQ[wave], lane); to.put(sO[wave], lane);
+    }
     const uint64_t pbase = (uint64_t)bh * (TMAX * SMAX);
     float p[2][4][4];
     mfma_probabilities(a, q, k, len, lane, p);

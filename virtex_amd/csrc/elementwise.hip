@@ -40,8 +40,17 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ parts, float* _
     __shared__ float red[8][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
     float s = 0.f;
-    if (c < C)
-        for (int b = grp; b < nparts; b += 8) s += parts[(size_t)b * C + c];
+    if (c < C) {
+        int b = grp;
+        for (; b + 56 < nparts; b += 64) {       // eight partials in flight, added in the same order as one by one
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = parts[(size_t)(b + 8 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
+        for (; b < nparts; b += 8) s += parts[(size_t)b * C + c];
+    }
     red[grp][threadIdx.x & 31] = s;
     __syncthreads();
     if (grp == 0 && c < C) {

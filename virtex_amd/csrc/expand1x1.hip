@@ -74,6 +74,10 @@ __global__ __launch_bounds__(64 * EX_WAVES, 2) void expand1x1_fwd_kernel(
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) f[ks] = *reinterpret_cast<const bf16x8_t*>(p + ks * 32);
     };
+    // (Round 3, session 12: the drain as straight-line code -- compile-time FULL / NT variants, so that hipcc counts the stores
+    //  instead of guarding the prefetched fragments with vmcnt(0) -- plus a pinned hand-over `fa = fn` at the end of the trip
+    //  was built and measured: this kernel unchanged, the stem's twin 140 -> 169 us.  These kernels are throughput-bound with
+    //  16 waves per CU; a wave waiting for its own stores costs nothing.  Reverted.)
     bf16x8_t fa[KS], fn[KS];
     int s = blockIdx.x * EX_WAVES + wave;
     if (s < nstrips) load_a(s, fa);

@@ -194,8 +194,17 @@ __global__ void ln_bwd_finalize_kernel(const float* __restrict__ partials, float
     __shared__ float red[2][8][32];
     const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
     float a = 0.f, b = 0.f;
-    if (c < H)
-        for (int p = grp; p < nparts; p += 8) { a += partials[((size_t)p * 2) * H + c]; b += partials[((size_t)p * 2 + 1) * H + c]; }
+    if (c < H) {
+        int p = grp;
+        for (; p + 24 < nparts; p += 32) {       // four strips (eight loads) in flight, added in the same order as one by one
+            float ta[4], tb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ta[u] = partials[((size_t)(p + 8 * u) * 2) * H + c]; tb[u] = partials[((size_t)(p + 8 * u) * 2 + 1) * H + c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a += ta[u]; b += tb[u]; }
+        }
+        for (; p < nparts; p += 8) { a += partials[((size_t)p * 2) * H + c]; b += partials[((size_t)p * 2 + 1) * H + c]; }
+    }
     red[0][grp][threadIdx.x & 31] = a; red[1][grp][threadIdx.x & 31] = b;
     __syncthreads();
     if (grp == 0 && c < H) {
