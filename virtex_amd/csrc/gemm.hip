@@ -92,7 +92,8 @@ void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc,
 // ([slices][M][N] fp32 partial sums).
 extern int g_vtx_sw_splitk_blocks;
 int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
-    const long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
+    long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
+    if (vtxg::g_vtx_sw_tile64x256 && M <= 64 && N > 128 && N <= 256) tiles = 1;      // launch_auto takes one 64x256 tile
     const int nkt = vtx_cdiv(K, bk);
     const long target = g_vtx_sw_splitk_blocks;          // VIRTEX_AMD_SPLITK_BLOCKS / vtx_set_switch("splitk_blocks")
     long s = (target + tiles - 1) / tiles;

@@ -1543,6 +1543,7 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
 // efficiency); candidates with BN > what N needs are skipped.
 struct TileCand { int bm, bn, resident; float eff; };
 extern int g_vtx_tile_override;   // tests: force a candidate (-1 = automatic)
+extern int g_vtx_sw_tile64x256;   // vtx_set_switch("tile64x256"): one 64x256 tile for k-major problems with M <= 64, 128 < N <= 256
 extern int g_vtx_sw_stats_tile;   // vtx_set_switch("stats_tile"): which statistics epilogues take 8-wave 128x128 tiles on large M
 extern int g_vtx_sw_mc_eff128;    // percent: relative efficiency of 128x128 tiles for k-major operands (vtx_set_switch("mc_eff128"))
 inline int pick_tile(int M, int N, int splits, bool allow256, bool mc = false) {
@@ -1594,6 +1595,12 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
         const bool stats_tile = rule == 1 || (rule == 2 && EP::SMODE == STATS_FWD) || (rule == 3 && EP::SMODE == STATS_BWD);
         if (stats_tile && v2 && c == 1 && g_vtx_tile_override < 0 && M >= 100000) c = 6;
     }
+    if constexpr (BF && ALT<T, 1>::MC) {
+        // Weight gradients of layers with at most 64 output channels and 129...256 rows of taps x channels (the stem: 64 x 224
+        // over K = 3.2 M pixels): ONE 64 x 256 tile instead of two 64 x 128 ones -- the gradient operand dy, 5x the size of the
+        // image operand, is then read once per K slice instead of twice (the kernel is HBM-bound: 822 -> 411 MB of dy).
+        if (v2 && g_vtx_sw_tile64x256 && g_vtx_tile_override < 0 && M <= 64 && N > 128 && N <= 256) c = 7;
+    }
     g_vtx_last_generation = v2 ? 2 : 1;
     g_vtx_generation_count[v2 ? 2 : 1].fetch_add(1, std::memory_order_relaxed);
 #define VTX_V1(BM_, BN_, SA_, SB_)                                                          \
@@ -1628,6 +1635,9 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
                 case 3: VTX_V2(128, 64, 2, 2, 2, 1) break;
                 case 4: VTX_V2(64, 128, 2, 2, 1, 2) break;
                 case 6: VTX_V2(128, 128, 4, 2, 1, 1) break;     // 8 waves on 128x128: wave tile 32x64 (short epilogue chains)
+                case 7:                                          // k-major operands only (see above)
+                    if constexpr (ALT<T, 1>::MC) { VTX_V2(64, 256, 1, 4, 1, 4) break; }
+                    else { VTX_V2(64, 64, 2, 2, 1, 1) break; }
                 default: VTX_V2(64, 64, 2, 2, 1, 1) break;
             }
             return EP::STATS ? strips : 0;
