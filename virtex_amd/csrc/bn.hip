@@ -16,6 +16,7 @@
 #include "vtx_common.h"
 #include "pool_windows.h"
 
+extern int g_vtx_sw_bn_adj, g_vtx_sw_bn_grid;   // vtx_set_switch("bn_adj" / "bn_grid"): form and grid cap of the flat apply kernels
 extern int g_vtx_sw_bn_fin_wide;     // vtx_set_switch("bn_fin_wide"): 1024-thread finalize / compaction blocks (default off)
 
 namespace {
@@ -191,7 +192,11 @@ __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __r
 // of two), so a thread stays on ONE channel vector for its whole life: the per-channel coefficients are loaded into
 // registers once, and a trip is UNR payload loads, ~2 VALU per element, UNR stores -- the first version reloaded every
 // coefficient table for every vector (six to ten cached loads per 16 bytes of payload) behind a 64-bit modulo.
-template <class T, int UNR>
+// ADJ (round 3, tools/probes/stream_probe.hip): the UNR vectors of a trip are ADJACENT -- a block owns 256 * UNR consecutive
+// vectors per trip (cv divides 256, so a thread still keeps its channel vector) -- instead of one grid stride (16.8 MB) apart.
+// Measured on the 411 MB tensors of stage 1 (2 reads + 1 write): 282 us / 4.37 TB/s in the strided form, 218 us / 5.67 TB/s
+// adjacent with four vectors per thread and 8192 blocks; hipMemcpy moves one such tensor at 5.34 TB/s.
+template <class T, int UNR, bool ADJ>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ residual,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ scale,
@@ -199,12 +204,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        uint8_t* __restrict__ bits, long nvec, int C, int relu) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
-    const long t0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    const long t0 = ADJ ? (long)blockIdx.x * 256 * UNR + threadIdx.x : (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = ADJ ? 256 : (long)gridDim.x * 256;                       // between the vectors of one trip
+    const long trip = (long)gridDim.x * 256 * UNR;
     const int c0 = (int)(t0 & (long)(cv - 1)) * VEC;
     float mu[VEC], sc[VEC], be[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { mu[j] = mean[c0 + j]; sc[j] = scale[c0 + j]; be[j] = beta[c0 + j]; }
-    for (long i0 = t0; i0 < nvec; i0 += UNR * stride) {
+    for (long i0 = t0; i0 < nvec; i0 += trip) {
         Vec16<T> v[UNR], r[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -291,13 +298,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // backward apply when the producing kernel already masked the gradient and emitted the sums (VtxBnBwdFusion):
 // dx = gamma*rstd * (dz - s1/P - xhat*s2/P); reads x and dz, writes dx -- nothing else
 // UNR independent 16-byte vectors per thread and trip, all loads issued before the first use (memory-level parallelism)
-template <class T, int UNR>
+template <class T, int UNR, bool ADJ>
 __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __restrict__ x, const T* __restrict__ dz,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ coef, T* __restrict__ dx, long nvec, int C) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
-    const long t0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    const long t0 = ADJ ? (long)blockIdx.x * 256 * UNR + threadIdx.x : (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = ADJ ? 256 : (long)gridDim.x * 256;                       // between the vectors of one trip (see bn_apply_kernel)
+    const long trip = (long)gridDim.x * 256 * UNR;
     const int c0 = (int)(t0 & (long)(cv - 1)) * VEC;
     // dx = k0*(dz - k1 - xhat*k2), xhat = (x - mu)*rs  ==  k0*dz - (x - mu)*(k0*k2*rs) - k0*k1
     float mu[VEC], a0[VEC], a1[VEC], a2[VEC];
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __rest
         const float k0 = coef[c0 + j], k1 = coef[C + c0 + j], k2 = coef[2 * C + c0 + j];
         mu[j] = mean[c0 + j]; a0[j] = k0; a1[j] = k0 * k2 * rstd[c0 + j]; a2[j] = k0 * k1;
     }
-    for (long i0 = t0; i0 < nvec; i0 += UNR * stride) {
+    for (long i0 = t0; i0 < nvec; i0 += trip) {
         Vec16<T> xv[UNR], g[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -511,6 +520,29 @@ static int apply_grid(long nvec, int cv = 1) {
     g = (g + q - 1) / q * q;
     return (int)g;
 }
+// Form of the flat apply kernels for one launch: adjacent vectors (ADJ) when the channel vectors of a row divide the block
+// (cv <= 256) and the switch allows; unroll by size; grid cap 8192 blocks for ADJ (4096 for the strided form, whose grid must
+// be a multiple of cv / 256).  vtx_set_switch("bn_adj", 0 | 1), ("bn_grid", cap), vtx_set_bn_apply_unroll.
+struct ApplyPlan { bool adj; int unr, grid; };
+static ApplyPlan plan_apply(long nvec, int cv, int max_unr) {
+    ApplyPlan p;
+    p.adj = g_vtx_sw_bn_adj && cv <= 256;
+    if (p.adj) {
+        // tools/bench_bn_apply.py (profiles/r03_bn_apply_forms.txt): four vectors per thread pay on the 411 MB tensors only
+        // (220 vs 229 us), two on everything from 25 MB up (51.6 vs 61.0 us at 103 MB with four)
+        p.unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (16L << 20) ? 4 : nvec >= (1L << 18) ? 2 : 1);
+        if (p.unr > max_unr) p.unr = max_unr;
+        long g = (nvec + 256L * p.unr - 1) / (256L * p.unr);
+        const long cap = g_vtx_sw_bn_grid > 0 ? g_vtx_sw_bn_grid : 8192;
+        p.grid = (int)(g > cap ? cap : (g < 1 ? 1 : g));
+    } else {
+        p.unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (6L << 20) ? 2 : 1);
+        if (p.unr > max_unr) p.unr = max_unr;
+        if (p.unr == 3) p.unr = 2;
+        p.grid = apply_grid(vtx_cdiv(nvec, p.unr), cv);
+    }
+    return p;
+}
 static bool bn_shape_ok(int C, int vec) { return C > 0 && C % vec == 0 && ((C / vec) & (C / vec - 1)) == 0; }
 
 }  // namespace
@@ -557,19 +589,37 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     else
         VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<float>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const float*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
-    const int fwd_unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (6L << 20) ? 2 : 1);
+    const ApplyPlan ap = plan_apply(nvec, C / vec, dtype == VTX_BF16 ? 4 : 1);
+#define VTX_FWD_APPLY(T, U, A, BYTES)                                                                                              \
+    VTX_KLAUNCH("bn_fwd_apply", 0, BYTES, (bn_apply_kernel<T, U, A>), dim3(ap.grid), dim3(256), 0, st, (const T*)x, (const T*)residual, \
+                save_mean, scale, beta, (T*)y, relu_bits, nvec, C, relu)
+    const double fb = (dtype == VTX_BF16 ? 2.0 : 4.0) * P * C * (residual ? 3 : 2);
     if (dtype == VTX_BF16) {
-        if (fwd_unr >= 2)
-            VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t, 2>), dim3(apply_grid(vtx_cdiv(nvec, 2), C / vec)), dim3(256), 0, st, (const bf16_t*)x,
-                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, relu_bits, nvec, C, relu);
-        else
-            VTX_KLAUNCH("bn_fwd_apply", 0, 2.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<bf16_t, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const bf16_t*)x,
-                               (const bf16_t*)residual, save_mean, scale, beta, (bf16_t*)y, relu_bits, nvec, C, relu);
-    } else
-        VTX_KLAUNCH("bn_fwd_apply", 0, 4.0 * P * C * (residual ? 3 : 2), (bn_apply_kernel<float, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const float*)x,
-                           (const float*)residual, save_mean, scale, beta, (float*)y, (uint8_t*)nullptr, nvec, C, relu);
+        if (ap.adj) { if (ap.unr == 4) VTX_FWD_APPLY(bf16_t, 4, true, fb); else if (ap.unr == 2) VTX_FWD_APPLY(bf16_t, 2, true, fb); else VTX_FWD_APPLY(bf16_t, 1, true, fb); }
+        else { if (ap.unr >= 2) VTX_FWD_APPLY(bf16_t, 2, false, fb); else VTX_FWD_APPLY(bf16_t, 1, false, fb); }
+    } else {
+        relu_bits = nullptr;
+        if (ap.adj) VTX_FWD_APPLY(float, 1, true, fb); else VTX_FWD_APPLY(float, 1, false, fb);
+    }
+#undef VTX_FWD_APPLY
     VTX_LAUNCH_CHECK();
     return VTX_OK;
+}
+
+// dx = k0*(dz - k1 - xhat*k2): the flat apply of the fused backward (and of BatchNorms without a ReLU behind them)
+static void launch_bwd_apply_fused(int dtype, const void* x, const void* dz, const float* save_mean, const float* save_rstd,
+                                   const float* coef, void* dx, long nvec, int P, int C, int vec, hipStream_t st) {
+    const ApplyPlan ap = plan_apply(nvec, C / vec, dtype == VTX_BF16 ? 4 : 1);
+#define VTX_BWD_APPLY(T, U, A, BYTES)                                                                                              \
+    VTX_KLAUNCH("bn_bwd_apply", 0, BYTES, (bn_bwd_apply_fused_kernel<T, U, A>), dim3(ap.grid), dim3(256), 0, st, (const T*)x, (const T*)dz, \
+                save_mean, save_rstd, coef, (T*)dx, nvec, C)
+    if (dtype == VTX_BF16) {
+        if (ap.adj) { if (ap.unr == 4) VTX_BWD_APPLY(bf16_t, 4, true, 6.0 * P * C); else if (ap.unr == 2) VTX_BWD_APPLY(bf16_t, 2, true, 6.0 * P * C); else VTX_BWD_APPLY(bf16_t, 1, true, 6.0 * P * C); }
+        else { if (ap.unr == 4) VTX_BWD_APPLY(bf16_t, 4, false, 6.0 * P * C); else if (ap.unr == 2) VTX_BWD_APPLY(bf16_t, 2, false, 6.0 * P * C); else VTX_BWD_APPLY(bf16_t, 1, false, 6.0 * P * C); }
+    } else {
+        if (ap.adj) VTX_BWD_APPLY(float, 1, true, 12.0 * P * C); else VTX_BWD_APPLY(float, 1, false, 12.0 * P * C);
+    }
+#undef VTX_BWD_APPLY
 }
 
 // workspace: same buffer / layout as vtx_bn_fwd (vtx_bn_workspace_floats(C) floats)
@@ -597,18 +647,7 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     if (!ymask && !relu_beta && !dz_out) {
         // no ReLU behind this BatchNorm (the projection shortcuts): dy is the gradient itself, so the apply is the one
         // of the fused path -- read x and dy, write dx, four coefficients per channel in registers, two vectors in flight
-        const int unr = g_bn_apply_unroll ? (g_bn_apply_unroll >= 2 ? 2 : 1) : (nvec >= (6L << 20) ? 2 : 1);
-        const int grid = apply_grid(vtx_cdiv(nvec, unr), C / vec);
-        if (dtype == VTX_BF16) {
-            if (unr == 2)
-                VTX_KLAUNCH("bn_bwd_apply", 0, 6.0 * P * C, (bn_bwd_apply_fused_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x,
-                            (const bf16_t*)dy, save_mean, save_rstd, coef, (bf16_t*)dx, nvec, C);
-            else
-                VTX_KLAUNCH("bn_bwd_apply", 0, 6.0 * P * C, (bn_bwd_apply_fused_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x,
-                            (const bf16_t*)dy, save_mean, save_rstd, coef, (bf16_t*)dx, nvec, C);
-        } else
-            VTX_KLAUNCH("bn_bwd_apply", 0, 12.0 * P * C, (bn_bwd_apply_fused_kernel<float, 1>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st,
-                        (const float*)x, (const float*)dy, save_mean, save_rstd, coef, (float*)dx, nvec, C);
+        launch_bwd_apply_fused(dtype, x, dy, save_mean, save_rstd, coef, dx, nvec, P, C, vec, st);
         VTX_LAUNCH_CHECK();
         return VTX_OK;
     }
@@ -646,17 +685,7 @@ extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const 
     VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(np), 0, st, parts, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, np);
     const long nvec = (long)P * C / vec;
-    // measured (tools/bench_bn_apply.py, profiles/r02_bn_apply_unroll.txt): two vectors in flight +5 % on the >= 50 MB
-    // tensors of stages 1-2, -10 % on the small ones; four are slower everywhere
-    const int unr = g_bn_apply_unroll ? g_bn_apply_unroll : (nvec >= (6L << 20) ? 2 : 1);
-    const int grid = apply_grid(vtx_cdiv(nvec, unr), C / vec);
-#define VTX_BWD_APPLY(T, U, BYTES)                                                                                              \
-    VTX_KLAUNCH("bn_bwd_apply", 0, BYTES, (bn_bwd_apply_fused_kernel<T, U>), dim3(grid), dim3(256), 0, st, (const T*)x, (const T*)dz, \
-                save_mean, save_rstd, coef, (T*)dx, nvec, C)
-    if (dtype == VTX_BF16) {
-        if (unr == 4) VTX_BWD_APPLY(bf16_t, 4, 6.0 * P * C); else if (unr == 2) VTX_BWD_APPLY(bf16_t, 2, 6.0 * P * C); else VTX_BWD_APPLY(bf16_t, 1, 6.0 * P * C);
-    } else VTX_BWD_APPLY(float, 1, 12.0 * P * C);
-#undef VTX_BWD_APPLY
+    launch_bwd_apply_fused(dtype, x, dz, save_mean, save_rstd, coef, dx, nvec, P, C, vec, st);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
