@@ -67,6 +67,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "expand1x1")) g_vtx_sw_expand1x1 = value;
     else if (!strcmp(name, "bn_fin_wide")) g_vtx_sw_bn_fin_wide = value;
     else if (!strcmp(name, "stats_tile")) vtxg::g_vtx_sw_stats_tile = value;
+    else if (!strcmp(name, "tile_order")) vtxg::g_vtx_ablate = (vtxg::g_vtx_ablate & ~32) | (value ? 32 : 0);   // 1: plain block -> tile order (A/B)
     else if (!strcmp(name, "bn_adj")) g_vtx_sw_bn_adj = value;
     else if (!strcmp(name, "bn_grid")) g_vtx_sw_bn_grid = value > 0 ? value : 8192;
     else if (!strcmp(name, "tile64x256")) vtxg::g_vtx_sw_tile64x256 = value;

@@ -1193,7 +1193,9 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
     // taken from the slice-major list of (slice, tile) pairs -- with the tile index alone deciding the XCD, the 8 tiles
     // of a small weight-gradient GEMM would each re-read their panels through a different L2.
     int tile, slice = 0;
-    if (gridDim.y == 1 || (abl & 16)) {
+    if (abl & 32) {                              // A/B switch (vtx_set_switch("tile_order", 1)): plain order, tile = block index
+        tile = blockIdx.x; slice = blockIdx.y;
+    } else if (gridDim.y == 1 || (abl & 16)) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         slice = blockIdx.y;
@@ -1261,7 +1263,7 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
     }
 
 #ifndef VTX_ABLATE          // measurement builds (tools/ablate_gemm.py) compile the ablation switches in
-    abl = 0;                // (bit 4, the A/B switch of the split-K block order, has been consumed above)
+    abl = 0;                // (bits 4 and 5, the A/B switches of the block order, have been consumed above)
 #endif
     // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8]); only vmcnt waits
     constexpr int INFLIGHT = NDMA * (STAGES - 2);       // DMA instructions that may still be pending at a K step
