@@ -76,25 +76,30 @@ def device_batch(B, dev, seed, image_size=224, vocab_size=10000):
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r02_pmc_traffic_final.txt.
-# The dominant kernel is found by NAME (a family's launch sites merged), then its LARGEST launch site is timed alone: the
-# traffic listed here is that site's kernel.  Candidates for the top of the step are within a few percent of each other, so
-# the likely ones are all listed; `traffic` is reported for whichever the live measurement finds dominant.
-TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, round-3 build)"
-TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE), averaged over the site's launches
-    # largest site = bn_bwd_apply_fused_kernel<bf16, 2>, 24 launches/step: (2 x 175.7e3 + 175.6e3) KiB (reads x and dz, writes dx: 2 : 1)
-    "bn_bwd_apply": 539.6e6,
-    # largest site = bn_apply_kernel<bf16, 2>, 24 launches/step: (2 x 142.2e3 + 182.9e3) KiB
-    "bn_fwd_apply": 478.5e6,
+# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r03_pmc_traffic.txt.
+# The dominant kernel is found by NAME (one class per contraction instantiation, one per launch family for the other
+# kernels), then ALL launches of that class are timed alone for three further steps: the traffic listed here is the average
+# over the same launches (the n of the profile = 3 steps x launches per step).  Candidates for the top of the step are
+# within a few percent of each other, so the likely ones are all listed; `traffic` is reported for whichever the live
+# measurement finds dominant, and a WARNING goes to stderr when that class has no entry.
+TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build at the end of round 3: tools/r03_s17.sh, tools/pmc_traffic.py)"
+TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE), averaged over the class's launches
+    # 28 launches/step (1x1 input gradients with the fused BatchNorm backward, all stages): (2 x 156.4e3 + 112.4e3) KiB
+    # = 1.035 x the class's algorithmic bytes (420.7 MB)
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 435.4e6,
+    # the launch family "bn_bwd_apply" = 53 launches/step over four kernels (fused<2>: 47 x 228.9 MB, fused<4>: 4 x 1233.5 MB,
+    # the stem's pool_bn_bwd_apply 1138.9 MB, ...): average over all of them; reads x and dz, writes dx -> FETCH : WRITE = 2 : 1
+    "bn_bwd_apply": 322.4e6,
+    # "bn_fwd_apply" = 53 launches/step (bn_apply<2>: 48 x 186.9 MB, <4>: 4 x 1150.3 MB, the stem's fused tail 775.5 MB)
+    "bn_fwd_apply": 270.7e6,
     # 35 launches/step (1x1 / text weight gradients): (2 x 63.6e3 + 32.8e3) KiB
     "contraction_v2_kernel<256, 128, 4, 2, PlainMC<bf16, 2>, PlainMC<bf16, 1>, EpiStore<float, 0>, 32, 3>": 163.9e6,
-    # 11 launches/step (stage 1-2 input gradients with the fused BatchNorm backward; the bn3 launches read the ReLU mask as
-    # bits since round 3: 932.0 -> 754.9 MB): (2 x 265.1e3 + 207.0e3) KiB
-    "contraction_v2_kernel<128, 128, 4, 2, PlainKC<bf16, 1>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 754.9e6,
-    # 17 launches/step: (2 x 85.2e3 + 53.2e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 229.0e6,
-    # 14 launches/step (text GEMMs, late 1x1 convolutions): (2 x 113.9e3 + 71.1e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 0>, 32, 3>": 306.1e6,
+    # 22 launches/step (1x1 forward convolutions with statistics): (2 x 55.1e3 + 64.9e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 1>, 32, 3>": 179.2e6,
+    # 16 launches/step (3x3 forward convolutions with statistics): (2 x 49.0e3 + 47.0e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, ConvFwdA<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 1>, 32, 3>": 148.4e6,
+    # 14 launches/step (text GEMMs, late 1x1 convolutions): (2 x 114.0e3 + 71.1e3) KiB
+    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 0>, 32, 3>": 306.3e6,
 }
 
 
