@@ -413,6 +413,45 @@ def test_contraction_tile_variants_bf16(backend, cand):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("P,C", [(1000, 64), (777, 256), (130, 2048), (4097, 8)])
+def test_batchnorm_apply_adjacent_form_equals_strided_form(backend, dtype, P, C):
+    """The flat apply kernels of bn.hip walk the tensor with a thread's vectors adjacent (round 3) or one grid stride apart
+    (rounds 1-2; still the form for more than 256 channel vectors per row): outputs, mask bits, dx, dgamma, dbeta bit for
+    bit the same for every unroll factor, ragged sizes included (the default sizes of this suite only reach one vector
+    per thread)."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    if dtype == torch.float32 and C % 4:
+        pytest.skip("channel vectors")
+
+    def run(adj, unr, residual):
+        _lib.call("vtx_set_switch", b"bn_adj", ctypes.c_int(adj)); _lib.call("vtx_set_bn_apply_unroll", ctypes.c_int(unr))
+        try:
+            g = torch.Generator().manual_seed(1)
+            x = torch.randn(P, C, generator=g).to(dtype).to(dev)
+            res = torch.randn(P, C, generator=g).to(dtype).to(dev) if residual else None
+            gamma = torch.rand(C, generator=g) + 0.5; beta = torch.randn(C, generator=g) * 0.1
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            bits = dtype == torch.bfloat16 and residual
+            out = ops.bn_fwd(x.view(1, P, 1, C), gamma.to(dev), beta.to(dev), rm, rv, None, relu=True,
+                             residual=res.view(1, P, 1, C) if residual else None, want_bits=bits)
+            dz = torch.randn(P, C, generator=g).to(dtype).to(dev)
+            dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
+            dx = ops.bn_bwd(x.view(1, P, 1, C), dz.view(1, P, 1, C), None, gamma.to(dev), out[1], out[2], dg, db)
+            return [out[0].cpu(), out[3].cpu() if bits else None, dx.cpu(), dg.cpu(), db.cpu()]
+        finally:
+            _lib.call("vtx_set_switch", b"bn_adj", ctypes.c_int(1)); _lib.call("vtx_set_bn_apply_unroll", ctypes.c_int(0))
+
+    for residual in (False, True):
+        ref = run(0, 1, residual)
+        for unr in (1, 2, 4):
+            for a, b in zip(ref, run(1, unr, residual)):
+                assert (a is None and b is None) or torch.equal(a, b), (residual, unr)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(2, 9, 9, 32, 32, 3, 1, 1), (3, 8, 8, 64, 256, 1, 1, 0), (2, 10, 10, 32, 64, 3, 2, 1)])
 def test_batchnorm_statistics_fused_in_conv_epilogue(backend, case):
     """bf16: the convolution epilogue emits per-strip sums of (y - shift), (y - shift)^2; BN forward fed
