@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int t = blockIdx.x;
     const float* prow = pos + (size_t)t * H;
+    __shared__ __attribute__((aligned(16))) float stage[4][256];
     RowF32<NV> ap, ag, ab;
 #pragma unroll
     for (int i = 0; i < NV; ++i)
@@ -140,14 +141,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (i * 64 + lane) * 4;
+            float de[4] = {0.f, 0.f, 0.f, 0.f};
             if (col < H) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float de = rstd * (g.v[i][j] - s1 - xh.v[i][j] * s2);
-                    ap.v[i][j] += de;
-                    atomicAdd(dwrow + col + j, de);
+                    de[j] = rstd * (g.v[i][j] - s1 - xh.v[i][j] * s2);
+                    ap.v[i][j] += de[j];
                 }
             }
+            // The scatter into the tied matrix: a lane holds 4 consecutive columns, so `atomicAdd(dwrow + col + j)` makes
+            // every wave-instruction touch 64 floats 16 bytes apart (eight cache lines, eight floats each).  Through a
+            // wave-private LDS row the same values go out with lane-contiguous addresses: 256 contiguous bytes per
+            // instruction, a quarter of the requests the L2 atomic units see.
+            *reinterpret_cast<float4*>(&stage[wv][lane * 4]) = make_float4(de[0], de[1], de[2], de[3]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = i * 256 + j * 64 + lane;
+                if (c < H) atomicAdd(dwrow + c, stage[wv][j * 64 + lane]);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __shared__ float red[4][256 + 1];
