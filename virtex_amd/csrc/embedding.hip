@@ -15,6 +15,12 @@ template <int NV> struct RowF32 {  // H fp32 values of one row, 4 per lane per c
     float v[NV][4];
 };
 
+__device__ __forceinline__ void emb_ld4(const float* p, float* v) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+__device__ __forceinline__ void emb_ld4(const bf16_t* p, float* v) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
 __device__ __forceinline__ void emb_st4(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void emb_st4(bf16_t* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3])); }
 
@@ -121,10 +127,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
                 const float4 a = *reinterpret_cast<const float4*>(wrow + col);
                 const float4 p = *reinterpret_cast<const float4*>(prow + col);
                 const float ev[4] = {a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w};
+                float dv[4];
+                emb_ld4(dout + base + col, dv);                 // one 8- / 16-byte load, not four element loads
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float h = (ev[j] - mean) * rstd;
-                    const float d = drop.apply(Elem<T>::ld(dout + base + col + j), base + col + j);
+                    const float d = drop.apply(dv[j], base + col + j);
                     ag.v[i][j] += d * h; ab.v[i][j] += d;
                     const float gg = d * gamma[col + j];
                     xh.v[i][j] = h; g.v[i][j] = gg;
