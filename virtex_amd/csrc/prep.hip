@@ -22,6 +22,15 @@ __global__ __launch_bounds__(256) void image_to_nhwc_kernel(const float* __restr
         const int rem = (int)(i - n * Ho * Wo);
         const int y = rem / Wo - halo, x = rem % Wo - halo;
         const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        if constexpr (sizeof(T) == 2) {
+            if (Cp == 4) {                       // the packed stem layout: one 8-byte store per pixel, not four 2-byte ones
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = (in && c < Cin) ? src[((n * Cin + c) * H + y) * W + x] : 0.f;
+                *reinterpret_cast<uint2*>(dst + i * 4) = make_uint2(f2bf2(v[0], v[1]), f2bf2(v[2], v[3]));
+                continue;
+            }
+        }
         for (int c = 0; c < Cp; ++c) {
             const float v = (in && c < Cin) ? src[((n * Cin + c) * H + y) * W + x] : 0.f;
             Elem<T>::st(dst + i * Cp + c, v);
