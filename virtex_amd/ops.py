@@ -37,7 +37,7 @@ def layernorm_residual_fwd(x, y, gamma, beta, eps, p_drop=0.0, seed=0):
 def _ws_key(device):
     """Scratch buffers are per (device, stream): the same kernels run concurrently on the compute stream, the
     weight-gradient side stream and the shortcut-branch stream (virtex_amd/streams.py)."""
-    return (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    return (device, _lib.current_stream_handle(device) if device.type == "cuda" else 0)
 
 
 _ln_ws = {}

@@ -15,6 +15,28 @@ import os
 import torch
 
 _side_streams = {}
+_fence_events = {}
+_get_cur = getattr(torch._C, "_cuda_getCurrentStream", None)
+_set_cur = getattr(torch._C, "_cuda_setStream", None)
+
+
+def _switch_stream(device, stream):
+    """Make `stream` torch's current stream on `device`; returns what _restore_stream needs.  (Same effect as entering
+    torch.cuda.stream(stream), without building Stream objects and device guards around it.)"""
+    if _get_cur is not None and _set_cur is not None and device.index is not None and device.index == torch.cuda.current_device():
+        prev = _get_cur(device.index)                    # (stream_id, device_index, device_type)
+        _set_cur(stream_id=stream.stream_id, device_index=stream.device_index, device_type=stream.device_type)
+        return prev
+    ctx = torch.cuda.stream(stream)
+    ctx.__enter__()
+    return ctx
+
+
+def _restore_stream(prev):
+    if isinstance(prev, tuple):
+        _set_cur(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
+    else:
+        prev.__exit__(None, None, None)
 
 
 class wgrad_stream:
@@ -39,18 +61,25 @@ class wgrad_stream:
     def __enter__(self):
         if self.active:
             side = wgrad_stream.side(self.device)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            # ~75 of these per step: the fence reuses ONE event per device (a wait captures the record in front of it, so
+            # re-recording it for the next fence is safe) and the stream switch goes through the raw setters -- the
+            # Event() + torch.cuda.stream() pair cost ~15 us of host time per use (tools/host_profile.py)
+            ev = _fence_events.get(self.device)
+            if ev is None:
+                ev = _fence_events[self.device] = torch.cuda.Event()
+            if self.device.index is not None and self.device.index == torch.cuda.current_device():
+                ev.record()                               # torch's current stream on this device
+            else:
+                ev.record(torch.cuda.current_stream(self.device))
             side.wait_event(ev)
             for t in self.inputs:
                 t.record_stream(side)
-            self.ctx = torch.cuda.stream(side)
-            self.ctx.__enter__()
+            self.prev = _switch_stream(self.device, side)
         return self
 
     def __exit__(self, *exc):
         if self.active:
-            self.ctx.__exit__(*exc)
+            _restore_stream(self.prev)
         return False
 
     @staticmethod
