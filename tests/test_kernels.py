@@ -992,3 +992,58 @@ def test_conv3x3_wgrad_streaming_kernel(backend, N, H, W, C, KO):
     assert rel_err(dw.cpu() - dw0, ref) < 1e-5                  # bf16 products are exact in fp32: only the summation order differs
     old = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), 1, 1, split_k=2)
     assert rel_err(dw.cpu(), old.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("N,H,W,C,KO", [(2, 9, 9, 32, 32), (1, 12, 45, 64, 64), (3, 16, 16, 32, 256), (2, 30, 30, 64, 128), (5, 7, 7, 128, 256)])
+def test_conv3x3_kernel_sharing_the_operand_tile_across_a_filter_row(backend, N, H, W, C, KO):
+    """conv3x3_kernel.h: 3x3 / stride 1 / pad 1 forward and input gradient with ONE A tile per (filter row, 32 channels)
+    serving the three taps (tiles of BM - 2 output pixels in linear NHWC order, the taps that would reach across the left /
+    right image edge zeroed in registers, rows above / below the image zero-filled by the buffer load): against torch, against
+    the generic implicit-GEMM kernel (switch off), with the BatchNorm statistics / fused BatchNorm backward epilogues; tiles
+    that start and end in the middle of image rows, odd widths, both tile shapes (KO <= 64: 128 x 64, else 256 x 128)."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(N * H + C + W + KO)
+    x = torch.randn(N, H, W, C, generator=g).to(dt)
+    w = (torch.randn(KO, 3, 3, C, generator=g) / (9 * C) ** 0.5).to(dt)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_()
+    yr = F.conv2d(xr, w.float().permute(0, 3, 1, 2), stride=1, padding=1)
+    dy = torch.randn(yr.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dt)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    wt = w.permute(3, 1, 2, 0).contiguous()
+
+    def run(sw):
+        _lib.call("vtx_set_switch", b"conv3x3_shared", ctypes.c_int(sw))
+        try:
+            ops.profile_start()
+            y = ops.conv2d_fwd(x.to(dev), w.to(dev), 1, 1)
+            shift = torch.zeros(KO, device=dev)
+            y2, st = ops.conv2d_fwd(x.to(dev), w.to(dev), 1, 1, bn_shift=shift)
+            dx = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), x.shape, 1, 1)
+            # fused BatchNorm backward of the layer that produced x (mask recomputed from its input xin)
+            xin = torch.randn(N, H, W, C, generator=torch.Generator().manual_seed(3)).to(dt).to(dev)
+            mean = torch.zeros(C, device=dev); rstd = torch.ones(C, device=dev)
+            gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev)
+            bn = ops.BnBwd(xin.view(-1, C), mean, rstd, gamma=gamma, beta=beta)
+            dz, bst = ops.conv2d_dgrad(dy.to(dev), wt.to(dev), x.shape, 1, 1, bn=bn)
+            recs = ops.profile_stop()
+            parts = st.parts[: st.strips * 2 * KO].view(st.strips, 2, KO).sum(0).cpu()
+            bparts = bst.parts[: bst.strips * 2 * C].view(bst.strips, 2, C).sum(0).cpu()
+            return y.float().cpu(), y2.float().cpu(), parts, dx.float().cpu(), dz.float().cpu(), bparts, recs
+        finally:
+            _lib.call("vtx_set_switch", b"conv3x3_shared", ctypes.c_int(1))
+
+    new, old = run(2), run(0)
+    assert sum(r["launches"] for r in new[6] if "Conv3x3SharedA" in r["name"]) == 4, [r["name"] for r in new[6]]
+    assert not any("Conv3x3SharedA" in r["name"] for r in old[6])
+    assert rel_err(new[0], yr.detach().permute(0, 2, 3, 1)) < 1e-2
+    assert rel_err(new[3], xr.grad.permute(0, 2, 3, 1)) < 1e-2
+    assert torch.equal(new[0], new[1])                                   # the statistics epilogue stores the same values
+    for a, b in ((new[0], old[0]), (new[3], old[3]), (new[4], old[4])):  # same products, same order of taps: fp32 sums in another order
+        assert rel_err(a, b) < 2e-3
+    yq = new[1].view(-1, KO).double()
+    assert rel_err(new[2][0], yq.sum(0).float()) < 1e-3 and rel_err(new[2][1], (yq * yq).sum(0).float()) < 1e-3
+    assert rel_err(new[5], old[5]) < 2e-3

@@ -67,7 +67,7 @@ def main():
                 kv.append((mod, attr, type(getattr(mod, attr))(int(val))))
         variants.append((name, kv, sw, lib))
     defaults = {(m, k): getattr(m, k) for _, kv, _, _ in variants for m, k, _ in kv}
-    sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512, "mc_eff128": 84, "bn_fin_wide": 0, "stats_tile": 0, "bn_adj": 1, "bn_grid": 8192, "tile64x256": 1, "tile_order": 0}
+    sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512, "mc_eff128": 84, "bn_fin_wide": 0, "stats_tile": 0, "bn_adj": 1, "bn_grid": 8192, "tile64x256": 1, "tile_order": 0, "conv3x3_shared": 1}
     res = {n: [] for n, _, _, _ in variants}
     for r in range(a.rounds):
         for name, kv, sw, lib in variants:

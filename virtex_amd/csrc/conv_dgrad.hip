@@ -6,6 +6,7 @@
 // bottleneck's two branches costs no extra pass.
 // Replaces the input-gradient half of aten::convolution_backward.
 #include "conv_common.h"
+#include "conv3x3_kernel.h"
 
 using namespace vtxg;
 
@@ -16,9 +17,16 @@ template <class T>
 static int conv_dgrad_t(const ConvGeo& g, const void* dy, const void* wt, void* dx, const void* residual, hipStream_t st) {
     const int M = g.N * g.H * g.W, Kd = g.R * g.S * g.KO;
     EpiStore<T> ep{(T*)dx, g.C, nullptr, (const T*)residual, g.C, nullptr, ACT_NONE, 1.f, make_dropout(0.f, 0), M, g.C};
+    auto mk_b = [&](auto& b) { b.p = (const T*)wt; b.ld = Kd; b.rows = g.C; b.K = Kd; };
+    if constexpr (sizeof(T) == 2) {      // 3x3 / stride 1 / pad 1: the taps of dy slide like a forward convolution's, flipped
+        if (g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g_vtx_contraction_generation >= 2 && g_vtx_tile_override < 0 &&
+            conv3x3_shared_try(dy, g.N, g.H, g.W, g.KO, g.C, mk_b, ep, 1, st)) {
+            VTX_LAUNCH_CHECK();
+            return VTX_OK;
+        }
+    }
     launch_auto<T, ConvDgradA, PlainKC>(
-        [&](auto& a) { a.dy = (const T*)dy; a.g = g; a.rows = M; a.K = Kd; },
-        [&](auto& b) { b.p = (const T*)wt; b.ld = Kd; b.rows = g.C; b.K = Kd; }, ep, M, g.C, Kd, 1, st);
+        [&](auto& a) { a.dy = (const T*)dy; a.g = g; a.rows = M; a.K = Kd; }, mk_b, ep, M, g.C, Kd, 1, st);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -69,9 +77,13 @@ static int conv_dgrad_bn(const ConvGeo& g, const void* dy, const void* wt, void*
     const int M = g.N * g.H * g.W, Kd = g.R * g.S * g.KO;
     EpiStore<T, STATS_BWD> ep{(T*)dx, g.C, nullptr, (const T*)residual, g.C, nullptr, ACT_NONE, 1.f, make_dropout(0.f, 0), M, g.C};
     vtx_fill_bn_bwd(ep, f, g.C, f->parts);
-    f->strips = launch_auto<T, ConvDgradA, PlainKC>(
-        [&](auto& a) { a.dy = (const T*)dy; a.g = g; a.rows = M; a.K = Kd; },
-        [&](auto& b) { b.p = (const T*)wt; b.ld = Kd; b.rows = g.C; b.K = Kd; }, ep, M, g.C, Kd, 1, st);
+    auto mk_b = [&](auto& b) { b.p = (const T*)wt; b.ld = Kd; b.rows = g.C; b.K = Kd; };
+    int strips = 0;
+    if (g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g_vtx_tile_override < 0)
+        strips = conv3x3_shared_try(dy, g.N, g.H, g.W, g.KO, g.C, mk_b, ep, 1, st);
+    if (strips == 0)
+        strips = launch_auto<T, ConvDgradA, PlainKC>([&](auto& a) { a.dy = (const T*)dy; a.g = g; a.rows = M; a.K = Kd; }, mk_b, ep, M, g.C, Kd, 1, st);
+    f->strips = strips;
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -4,6 +4,7 @@
 // Replaces aten::convolution (cudnn/MIOpen/mkldnn) for the 53 bias-free convs of ResNet-50
 // reached from /root/reference/virtex/modules/visual_backbones.py:68-74.
 #include "conv_common.h"
+#include "conv3x3_kernel.h"
 
 using namespace vtxg;
 
@@ -18,17 +19,23 @@ static int conv_fwd_t(const ConvGeo& g, const void* x, const void* w, void* y, c
     auto mk_a = [&](auto& a) { a.x = (const T*)x; a.g = g; a.rows = M; a.K = Kd; };
     auto mk_b = [&](auto& b) { b.p = (const T*)w; b.ld = Kd; b.rows = g.KO; b.K = Kd; };
     bool done = false;
+    // 3x3 / stride 1 / pad 1 (bf16): the kernel whose A tile serves the three taps of a filter row (conv3x3_kernel.h)
+    const bool c3 = sizeof(T) == 2 && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g_vtx_contraction_generation >= 2 &&
+                    g_vtx_tile_override < 0;
     if constexpr (sizeof(T) == 2) {
         if (stat_parts) {
             EpiStore<T, STATS_FWD> ep{(T*)y, g.KO, bias, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
             ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
-            strips = launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
+            if (c3) strips = conv3x3_shared_try(x, g.N, g.H, g.W, g.C, g.KO, mk_b, ep, 0, st);
+            if (strips == 0) strips = launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
             done = true;
         }
     }
     if (!done) {
         EpiStore<T> ep{(T*)y, g.KO, bias, (const T*)residual, g.KO, nullptr, act, 1.f, make_dropout(0.f, 0), M, g.KO};
-        launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
+        int taken = 0;
+        if constexpr (sizeof(T) == 2) { if (c3) taken = conv3x3_shared_try(x, g.N, g.H, g.W, g.C, g.KO, mk_b, ep, 0, st); }
+        if (!taken) launch_auto<T, ConvFwdA, PlainKC>(mk_a, mk_b, ep, M, g.KO, Kd, 1, st);
     }
     if (stat_strips) *stat_strips = strips;
     VTX_LAUNCH_CHECK();

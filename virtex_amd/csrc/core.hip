@@ -58,6 +58,7 @@ int g_vtx_sw_bn_fin_wide = getenv("VIRTEX_AMD_BN_FIN_WIDE") ? atoi(getenv("VIRTE
 namespace vtxg { int g_vtx_sw_stats_tile = getenv("VIRTEX_AMD_STATS_TILE") ? atoi(getenv("VIRTEX_AMD_STATS_TILE")) : 0; }
 int g_vtx_sw_bn_adj = getenv("VIRTEX_AMD_BN_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_ADJ")) : 1;      // flat BatchNorm apply kernels: adjacent vectors per trip
 int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN_GRID")) : 8192;  // ... and their grid cap
+namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
 namespace vtxg { int g_vtx_sw_mc_eff128 = getenv("VIRTEX_AMD_MC_EFF128") ? atoi(getenv("VIRTEX_AMD_MC_EFF128")) : 84; }   // tile picker: 128x128 efficiency (%) for k-major operands
 extern "C" int vtx_set_switch(const char* name, int value) {
@@ -70,6 +71,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "tile_order")) vtxg::g_vtx_ablate = (vtxg::g_vtx_ablate & ~32) | (value ? 32 : 0);   // 1: plain block -> tile order (A/B)
     else if (!strcmp(name, "bn_adj")) g_vtx_sw_bn_adj = value;
     else if (!strcmp(name, "bn_grid")) g_vtx_sw_bn_grid = value > 0 ? value : 8192;
+    else if (!strcmp(name, "conv3x3_shared")) vtxg::g_vtx_sw_conv3x3_shared = value;
     else if (!strcmp(name, "tile64x256")) vtxg::g_vtx_sw_tile64x256 = value;
     else if (!strcmp(name, "mc_eff128")) vtxg::g_vtx_sw_mc_eff128 = value > 0 ? value : 84;
     else if (!strcmp(name, "splitk_blocks")) g_vtx_sw_splitk_blocks = value > 0 ? value : 512;

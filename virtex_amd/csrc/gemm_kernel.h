@@ -1155,14 +1155,173 @@ __device__ __forceinline__ void mc_rows(vtx_v4s_t (&ra)[MT][2], vtx_v4s_t (&rb)[
     }
 }
 
-#ifndef VTX_EPI_BWD_OCC
-#define VTX_EPI_BWD_OCC 4      // waves per SIMD the 8-wave 128x128 kernels with the fused BatchNorm-backward epilogue are built for
-#endif
-#ifndef VTX_EPI_OPS_PRE
-#define VTX_EPI_OPS_PRE 0      // 1 (with OPS_ALL): ... and already in front of the K loop, together with the first operand tiles
-#endif
+// ------------------------------------------------------------------ the epilogue of a block tile (shared by the kernels below)
+template <int BN, int NW, class EP> struct EpiShape {
+    static constexpr int PPT = EP::SMODE == STATS_NONE ? 1 : (BN + 64 * NW - 1) / (64 * NW);    // parameter-table columns per thread
+};
+// Statistics epilogues: the per-channel parameters of this block's columns are fetched in FRONT of the K loop, into
+// registers, and written to their LDS table after it -- fetched there (rounds 1-2) they were three to four dependent L2
+// round trips in front of the epilogue of blocks whose whole K loop is one or two steps.
+template <int BN, int NW, class EP>
+__device__ __forceinline__ void epi_prefetch(const EP& ep, float (&pre)[EpiShape<BN, NW, EP>::PPT][4], int tid, int n0) {
+    constexpr int PPT = EpiShape<BN, NW, EP>::PPT;
+    if constexpr (EP::SMODE != STATS_NONE) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int c = tid + q * 64 * NW, n = n0 + c;
+            pre[q][0] = pre[q][1] = pre[q][2] = pre[q][3] = 0.f;
+            if (c < BN && n < ep.N) {
+                if constexpr (EP::SMODE == STATS_FWD) {
+                    if (ep.stat_shift) pre[q][0] = ep.stat_shift[n];
+                } else {
+                    pre[q][0] = ep.bn_rstd[n]; pre[q][1] = ep.bn_mean[n];
+                    if (ep.bn_gamma) pre[q][2] = ep.bn_gamma[n];
+                    if (ep.bn_beta) pre[q][3] = ep.bn_beta[n];
+                }
+            }
+        }
+    } else {
+        pre[0][0] = pre[0][1] = pre[0][2] = pre[0][3] = 0.f;
+    }
+}
 #ifndef VTX_EPI_OPS_ALL
 #define VTX_EPI_OPS_ALL 1      // 1: the epilogue operands of ALL 16-row steps of a wave tile are fetched up front (<= 4 chunks)
+#endif
+// acc: the wave's MT x NT accumulator tiles (D = Btile x Atile: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]);
+// lds: the block's stage memory (LDS_BYTES), free once every wave has left the K loop; tile_m / tile_n: the tile's place in
+// the grid (statistics strip / column group)
+template <int BM, int BN, int WM, int WN, int LDS_BYTES, class EP>
+__device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16],
+                                              float (&pre)[EpiShape<BN, WM * WN, EP>::PPT][4], bf16_t* lds, int m0, int n0,
+                                              int tile_m, int tile_n, int tid, int lane, int wave) {
+    constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, MT = WTM / 16, NT = WTN / 16;
+    constexpr int PPT = EpiShape<BN, NW, EP>::PPT;
+    const int wm = wave / WN, wn = wave % WN;
+    // D = Btile x Atile  =>  lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
+    if constexpr (EP::ROWLSE) {
+        rowlse_epilogue<MT, NT>(ep, acc, m0 + wm * WTM, n0 + wn * WTN, lane, tile_n * WN + wn);
+    } else if constexpr (!EP::STAGED) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                ep(m0 + wm * WTM + i * 16 + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j]);
+    } else {
+        // Wide epilogue: 16 rows at a time go through a wave-private LDS strip so that every global
+        // access is 16 bytes per lane and 8 (bf16) / 4 (fp32) full 128/256-byte row segments per
+        // wave-instruction instead of sixteen 32-byte ones.
+        typedef typename EP::Out TO;
+        constexpr int ROWB = WTN * (int)sizeof(TO) + 16;          // padded strip row (bytes)
+        constexpr int CPR = WTN * (int)sizeof(TO) / 16;           // 16-byte chunks per row
+        constexpr int EPV = 16 / (int)sizeof(TO);                 // elements per chunk
+        constexpr int SM = EP::SMODE;
+        constexpr int PAR_OFF = (NW * 16 * ROWB + 15) & ~15;      // statistics: parameter table [4][BN], then
+        constexpr int RED_OFF = PAR_OFF + 4 * BN * 4;             // the cross-wave fold [NW][2][WTN]
+        static_assert(SM == STATS_NONE || (64 % CPR == 0 && RED_OFF + NW * 2 * WTN * 4 <= LDS_BYTES),
+                      "statistics epilogue: a lane must keep its column chunk, and the tables must fit the stage memory");
+        __syncthreads();                                          // every wave is done with the stages
+        char* strip = reinterpret_cast<char*>(lds) + wave * (16 * ROWB);
+        float* par = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PAR_OFF);
+        float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + RED_OFF);
+        float s1[SM != STATS_NONE ? EPV : 1], s2[SM != STATS_NONE ? EPV : 1];
+        if constexpr (SM != STATS_NONE) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < PPT; ++q) {                       // per-channel parameters of this block's columns
+                const int c = tid + q * 64 * NW;
+                if (c < BN) {
+                    if constexpr (SM == STATS_FWD) par[c] = pre[q][0];
+                    else {
+                        par[c] = pre[q][0]; par[BN + c] = -pre[q][1] * pre[q][0];
+                        par[2 * BN + c] = pre[q][2]; par[3 * BN + c] = pre[q][3];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        float4 bv[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (SM == STATS_NONE) {
+            if (ep.bias) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bv[j] = ep.bias4(n0 + wn * WTN + j * 16 + 4 * (lane >> 4));
+            }
+        }
+        constexpr int NCH = (16 * CPR + 63) / 64;                 // chunks a lane drains per 16-row step
+        // wave tiles of at most four output chunks per lane (8 waves on 128x128): the operand chunks of ALL steps up front
+        constexpr bool OPS_ALL = VTX_EPI_OPS_ALL && SM == STATS_BWD && MT * NCH <= 4;
+        typename EP::Ops ops[OPS_ALL ? MT : 1][NCH];
+        if constexpr (OPS_ALL) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int c = lane + 64 * q;
+                    ops[i][q] = ep.load_ops(c < 16 * CPR ? m0 + wm * WTM + i * 16 + c / CPR : ep.M, n0 + wn * WTN + (c % CPR) * EPV);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int mrow = m0 + wm * WTM + i * 16;
+            // the step's global operands (residual, BatchNorm input, mask) first: independent of the accumulators
+            if constexpr (!OPS_ALL) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    const int c = lane + 64 * q;
+                    ops[0][q] = ep.load_ops(c < 16 * CPR ? mrow + c / CPR : ep.M, n0 + wn * WTN + (c % CPR) * EPV);
+                }
+            }
+            const typename EP::RowData rd = ep.row_data(mrow + (lane & 15));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f32x4_t v = ep.transform(mrow + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j], bv[j], rd);
+                st4v<TO>(reinterpret_cast<TO*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int c = lane + 64 * q;
+                if (c < 16 * CPR) {
+                    const int r = c / CPR, ch = c % CPR;
+                    const uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
+                    if constexpr (SM == STATS_NONE) ep.finish(mrow + r, n0 + wn * WTN + ch * EPV, w, ops[OPS_ALL ? i : 0][q]);
+                    else ep.finish_stats(mrow + r, n0 + wn * WTN + ch * EPV, w, ops[OPS_ALL ? i : 0][q], par + wn * WTN + ch * EPV, BN, s1, s2);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (SM != STATS_NONE) {
+            // fold the lanes that drained the same column chunk (they differ in the bits above log2(CPR)) ...
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+#pragma unroll
+                for (int msk = CPR; msk < 64; msk <<= 1) { s1[e] += __shfl_xor(s1[e], msk, 64); s2[e] += __shfl_xor(s2[e], msk, 64); }
+            }
+            if (lane < CPR) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    red[(wave * 2 + 0) * WTN + lane * EPV + e] = s1[e];
+                    red[(wave * 2 + 1) * WTN + lane * EPV + e] = s2[e];
+                }
+            }
+            __syncthreads();
+            // ... then the WM waves of each column range: one partial per (block row, channel), no atomics
+            float* dst = ep.stat_parts + (size_t)tile_m * 2 * ep.N;
+            for (int t = tid; t < 2 * BN; t += 64 * NW) {
+                const int which = t / BN, c = t % BN, wcol = c / WTN, cc = c % WTN;
+                float a = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WM; ++w2) a += red[((w2 * WN + wcol) * 2 + which) * WTN + cc];
+                if (n0 + c < ep.N) dst[(size_t)which * ep.N + n0 + c] = a;
+            }
+        }
+    }
+}
+
+#ifndef VTX_EPI_BWD_OCC
+#define VTX_EPI_BWD_OCC 4      // waves per SIMD the 8-wave 128x128 kernels with the fused BatchNorm-backward epilogue are built for
 #endif
 // Block = WM x WN waves; block tile BM x BN; wave tile (BM/WM) x (BN/WN).  Large tiles matter for the
 // L2 -> LDS bandwidth, not only for LDS: a 128x128 tile needs 2*(128+128)*64 B per 2*128*128*32 flop
@@ -1222,45 +1381,10 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // Statistics epilogues: the per-channel parameters of this block's columns are fetched NOW, into registers, and
-    // written to their LDS table after the K loop -- fetched there (rounds 1-2) they were three to four dependent L2
-    // round trips in front of the epilogue of blocks whose whole K loop is one or two steps.
-    constexpr int PPT = EP::SMODE == STATS_NONE ? 1 : (BN + 64 * NW - 1) / (64 * NW);    // table columns per thread
+    // (statistics epilogues: the per-channel parameters of this block's columns are requested now, see epi_prefetch)
+    constexpr int PPT = EpiShape<BN, NW, EP>::PPT;
     float pre[PPT][4];
-    if constexpr (EP::SMODE != STATS_NONE) {
-#pragma unroll
-        for (int q = 0; q < PPT; ++q) {
-            const int c = tid + q * 64 * NW, n = n0 + c;
-            pre[q][0] = pre[q][1] = pre[q][2] = pre[q][3] = 0.f;
-            if (c < BN && n < ep.N) {
-                if constexpr (EP::SMODE == STATS_FWD) {
-                    if (ep.stat_shift) pre[q][0] = ep.stat_shift[n];
-                } else {
-                    pre[q][0] = ep.bn_rstd[n]; pre[q][1] = ep.bn_mean[n];
-                    if (ep.bn_gamma) pre[q][2] = ep.bn_gamma[n];
-                    if (ep.bn_beta) pre[q][3] = ep.bn_beta[n];
-                }
-            }
-        }
-    }
-
-    // Wave tiles of at most four output chunks per lane (8 waves on 128x128): ALL operand chunks of the fused BatchNorm-
-    // backward epilogue are requested here, in front of the K loop -- the short-K layers this epilogue serves are then ONE
-    // memory latency deep per block (operand tiles and epilogue operands in flight together), not two in a row.
-    constexpr int E_CPR = WTN * (int)sizeof(typename EP::Out) / 16, E_EPV = 16 / (int)sizeof(typename EP::Out);
-    constexpr int E_NCH = (16 * E_CPR + 63) / 64;
-    constexpr bool OPS_ALL = VTX_EPI_OPS_ALL && EP::STAGED && EP::SMODE == STATS_BWD && MT * E_NCH <= 4;
-    constexpr bool OPS_PRE = OPS_ALL && VTX_EPI_OPS_PRE;
-    typename EP::Ops ops[OPS_ALL ? MT : 1][E_NCH];
-    if constexpr (OPS_PRE) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int q = 0; q < E_NCH; ++q) {
-                const int c = lane + 64 * q;
-                ops[i][q] = ep.load_ops(c < 16 * E_CPR ? m0 + wm * WTM + i * 16 + c / E_CPR : ep.M, n0 + wn * WTN + (c % E_CPR) * E_EPV);
-            }
-    }
+    epi_prefetch<BN, NW>(ep, pre, tid, n0);
 
 #ifndef VTX_ABLATE          // measurement builds (tools/ablate_gemm.py) compile the ablation switches in
     abl = 0;                // (bits 4 and 5, the A/B switches of the block order, have been consumed above)
@@ -1337,125 +1461,7 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
             stage = stage + 1 >= STAGES ? 0 : stage + 1;
         }
     }
-    // D = Btile x Atile  =>  lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]
-    if constexpr (EP::ROWLSE) {
-        rowlse_epilogue<MT, NT>(ep, acc, m0 + wm * WTM, n0 + wn * WTN, lane, (tile % tiles_n) * WN + wn);
-    } else if constexpr (!EP::STAGED) {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-                ep(m0 + wm * WTM + i * 16 + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j]);
-    } else {
-        // Wide epilogue: 16 rows at a time go through a wave-private LDS strip so that every global
-        // access is 16 bytes per lane and 8 (bf16) / 4 (fp32) full 128/256-byte row segments per
-        // wave-instruction instead of sixteen 32-byte ones.
-        typedef typename EP::Out TO;
-        constexpr int ROWB = WTN * (int)sizeof(TO) + 16;          // padded strip row (bytes)
-        constexpr int CPR = WTN * (int)sizeof(TO) / 16;           // 16-byte chunks per row
-        constexpr int EPV = 16 / (int)sizeof(TO);                 // elements per chunk
-        constexpr int SM = EP::SMODE;
-        constexpr int PAR_OFF = (NW * 16 * ROWB + 15) & ~15;      // statistics: parameter table [4][BN], then
-        constexpr int RED_OFF = PAR_OFF + 4 * BN * 4;             // the cross-wave fold [NW][2][WTN]
-        static_assert(SM == STATS_NONE || (64 % CPR == 0 && RED_OFF + NW * 2 * WTN * 4 <= STAGES * TILE * 2),
-                      "statistics epilogue: a lane must keep its column chunk, and the tables must fit the stage memory");
-        __syncthreads();                                          // every wave is done with the stages
-        char* strip = reinterpret_cast<char*>(lds) + wave * (16 * ROWB);
-        float* par = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + PAR_OFF);
-        float* red = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + RED_OFF);
-        float s1[SM != STATS_NONE ? EPV : 1], s2[SM != STATS_NONE ? EPV : 1];
-        if constexpr (SM != STATS_NONE) {
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) s1[e] = s2[e] = 0.f;
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) {                       // per-channel parameters of this block's columns
-                const int c = tid + q * 64 * NW;
-                if (c < BN) {
-                    if constexpr (SM == STATS_FWD) par[c] = pre[q][0];
-                    else {
-                        par[c] = pre[q][0]; par[BN + c] = -pre[q][1] * pre[q][0];
-                        par[2 * BN + c] = pre[q][2]; par[3 * BN + c] = pre[q][3];
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        float4 bv[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (SM == STATS_NONE) {
-            if (ep.bias) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) bv[j] = ep.bias4(n0 + wn * WTN + j * 16 + 4 * (lane >> 4));
-            }
-        }
-        constexpr int NCH = (16 * CPR + 63) / 64;                 // chunks a lane drains per 16-row step
-        static_assert(NCH == E_NCH && CPR == E_CPR && EPV == E_EPV, "operand prefetch in front of the K loop");
-        if constexpr (OPS_ALL && !OPS_PRE) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    const int c = lane + 64 * q;
-                    ops[i][q] = ep.load_ops(c < 16 * CPR ? m0 + wm * WTM + i * 16 + c / CPR : ep.M, n0 + wn * WTN + (c % CPR) * EPV);
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int mrow = m0 + wm * WTM + i * 16;
-            // the step's global operands (residual, BatchNorm input, mask) first: independent of the accumulators
-            if constexpr (!OPS_ALL) {
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    const int c = lane + 64 * q;
-                    ops[0][q] = ep.load_ops(c < 16 * CPR ? mrow + c / CPR : ep.M, n0 + wn * WTN + (c % CPR) * EPV);
-                }
-            }
-            const typename EP::RowData rd = ep.row_data(mrow + (lane & 15));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const f32x4_t v = ep.transform(mrow + (lane & 15), n0 + wn * WTN + j * 16 + 4 * (lane >> 4), acc[i][j], bv[j], rd);
-                st4v<TO>(reinterpret_cast<TO*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int c = lane + 64 * q;
-                if (c < 16 * CPR) {
-                    const int r = c / CPR, ch = c % CPR;
-                    const uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
-                    if constexpr (SM == STATS_NONE) ep.finish(mrow + r, n0 + wn * WTN + ch * EPV, w, ops[OPS_ALL ? i : 0][q]);
-                    else ep.finish_stats(mrow + r, n0 + wn * WTN + ch * EPV, w, ops[OPS_ALL ? i : 0][q], par + wn * WTN + ch * EPV, BN, s1, s2);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if constexpr (SM != STATS_NONE) {
-            // fold the lanes that drained the same column chunk (they differ in the bits above log2(CPR)) ...
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-#pragma unroll
-                for (int msk = CPR; msk < 64; msk <<= 1) { s1[e] += __shfl_xor(s1[e], msk, 64); s2[e] += __shfl_xor(s2[e], msk, 64); }
-            }
-            if (lane < CPR) {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                    red[(wave * 2 + 0) * WTN + lane * EPV + e] = s1[e];
-                    red[(wave * 2 + 1) * WTN + lane * EPV + e] = s2[e];
-                }
-            }
-            __syncthreads();
-            // ... then the WM waves of each column range: one partial per (block row, channel), no atomics
-            float* dst = ep.stat_parts + (size_t)(tile / tiles_n) * 2 * ep.N;
-            for (int t = tid; t < 2 * BN; t += 64 * NW) {
-                const int which = t / BN, c = t % BN, wcol = c / WTN, cc = c % WTN;
-                float a = 0.f;
-#pragma unroll
-                for (int w2 = 0; w2 < WM; ++w2) a += red[((w2 * WN + wcol) * 2 + which) * WTN + cc];
-                if (n0 + c < ep.N) dst[(size_t)which * ep.N + n0 + c] = a;
-            }
-        }
-    }
+    tile_epilogue<BM, BN, WM, WN, STAGES * TILE * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
 }
 
 extern int g_vtx_contraction_generation;   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
