@@ -184,3 +184,32 @@ def test_buffer_addressing_at_the_top_of_its_range_and_the_fallback_beyond_it():
             assert rel_err(dw, ref) < 5e-3
         del a, y, dy, dw
         torch.cuda.empty_cache()
+
+
+def test_conv3x3_shared_tile_kernel_at_stage_1_and_2_shapes():
+    """conv3x3_kernel.h at the shapes it takes in the step (>= 100 000 output pixels: 64 filters on 254-pixel tiles, 128 on
+    256 x 128): forward with statistics and input gradient against the generic implicit-GEMM kernel."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select("gpu")
+    for (Bn, H, C) in [(32, 56, 64), (128, 28, 128)]:
+        g = _g(H + C)
+        x = torch.randn(Bn, H, H, C, generator=g).to(DT).to(dev)
+        w = (torch.randn(C, 3, 3, C, generator=g) / (9 * C) ** 0.5).to(DT).to(dev)
+        dy = torch.randn(Bn, H, H, C, generator=g).to(DT).to(dev)
+        wt = w.permute(3, 1, 2, 0).contiguous()
+        out = {}
+        for sw in (1, 0):
+            _lib.call("vtx_set_switch", b"conv3x3_shared", ctypes.c_int(sw))
+            try:
+                ops.profile_start()
+                y, st = ops.conv2d_fwd(x, w, 1, 1, bn_shift=torch.zeros(C, device=dev))
+                dx = ops.conv2d_dgrad(dy, wt, x.shape, 1, 1)
+                recs = ops.profile_stop()
+            finally:
+                _lib.call("vtx_set_switch", b"conv3x3_shared", ctypes.c_int(1))
+            sums = st.parts[: st.strips * 2 * C].view(st.strips, 2, C).sum(0).cpu()
+            out[sw] = (y.float().cpu(), dx.float().cpu(), sums, sum(r["launches"] for r in recs if "Conv3x3SharedA" in r["name"]))
+        assert out[1][3] == 2 and out[0][3] == 0
+        assert rel_err(out[1][0], out[0][0]) < 2e-3 and rel_err(out[1][1], out[0][1]) < 2e-3
+        assert rel_err(out[1][2], out[0][2]) < 2e-3

@@ -204,7 +204,10 @@ inline int conv3x3_shared_try(const void* a_ptr, int Nimg, int H, int W, int CH,
         return tiles_m;                                                                                                   \
     }
     const int c = Nout <= 64 ? 3 : pick_tile(M, Nout, 1, true);          // the contraction kernel's cost model chooses the tile
-    if (Nout <= 64 || c == 3 || c == 5) VTX_C3(128, 64, 2, 2, 1)
+    // 64 filters: four waves on 254-pixel tiles (half the per-tile prologue / epilogue per output of the 126-pixel tile:
+    // 64->64 @56x56 forward 99.7 -> 97.3 us, input gradient 108.7 -> 98.8); small problems keep the 126-pixel tile
+    if (Nout <= 64 && M >= (g_vtx_sw_conv3x3_shared >= 2 ? 512 : 100000)) VTX_C3(256, 64, 4, 1, 1)
+    else if (Nout <= 64 || c == 3 || c == 5) VTX_C3(128, 64, 2, 2, 1)
     else if (c == 2 || c == 4) VTX_C3(128, 128, 2, 2, 2)
     else VTX_C3(256, 128, 4, 2, 1)
 #undef VTX_C3
