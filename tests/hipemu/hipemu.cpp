@@ -12,6 +12,7 @@
 namespace hipemu {
 
 thread_local ThreadCtx tls;
+int g_dma_late = 0;
 
 namespace {
 
@@ -95,6 +96,7 @@ void prepare(FiberImpl& f) {
     s[7] = nullptr;
     f.sp = (void*)s;
     f.st = RUN;
+    f.npend = 0;
 }
 
 void run_block(Worker& w, dim3 block) {
@@ -262,3 +264,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
 }
 
 }  // namespace hipemu
+
+// tests: 1 = LDS-DMA lands at the issuing lane's covering s_waitcnt (latest), 0 = at issue (earliest)
+extern "C" void hipemu_set_dma_late(int on) { hipemu::g_dma_late = on; }
+extern "C" int hipemu_get_dma_late() { return hipemu::g_dma_late; }

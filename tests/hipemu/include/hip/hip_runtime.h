@@ -62,11 +62,37 @@ struct ThreadCtx {           // one per OS worker thread
     char* dyn = nullptr;
 };
 extern thread_local ThreadCtx tls;
+// LDS-DMA issued but not yet "landed" (only in the late-landing mode, see hipemu_set_dma_late)
+struct PendingDma { void* dst; int size; char data[16]; };
 struct Fiber {
     uint3_ tid;
     int linear, wave, lane;
+    // late-landing LDS-DMA: what this lane has issued and no s_waitcnt vmcnt has retired yet (oldest first)
+    PendingDma pend[64];
+    int npend = 0;
     // scheduler state lives in the runtime
 };
+// Late-landing mode (tests of the counted-vmcnt pipelines): an LDS-DMA writes its LDS bytes only when the ISSUING lane
+// executes an s_waitcnt whose vmcnt leaves it out (or __syncthreads, which hipcc fences with vmcnt(0) while a DMA is in
+// flight) -- the LATEST moment the hardware allows.  A kernel that reads a staged tile before wait + barrier then sees
+// the old bytes and fails its test; the default (0) mode lands every DMA at issue, the EARLIEST moment, which exposes
+// a stage issued before the last read of the bytes it overwrites.  Unretired DMAs of a finished lane are dropped.
+extern int g_dma_late;
+inline void dma_retire(int leave) {
+    Fiber* f = tls.cur;
+    if (f->npend <= leave) return;
+    const int n = f->npend - leave;
+    for (int i = 0; i < n; ++i) memcpy(f->pend[i].dst, f->pend[i].data, f->pend[i].size);
+    for (int i = n; i < f->npend; ++i) f->pend[i - n] = f->pend[i];
+    f->npend = leave;
+}
+inline void dma_write(void* dst, const void* src16, int size) {
+    if (!g_dma_late) { memcpy(dst, src16, size); return; }
+    Fiber* f = tls.cur;
+    if (f->npend >= 64) { fprintf(stderr, "hipemu: more than 64 LDS-DMA in flight in one lane (vmcnt is 6 bits)\n"); abort(); }
+    PendingDma& p = f->pend[f->npend++];
+    p.dst = dst; p.size = size; memcpy(p.data, src16, size);
+}
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
 void block_barrier();
 void* wave_exchange(const void* mine, size_t bytes);  // returns base of 64 slots (stride 64 B)
@@ -83,7 +109,7 @@ const uint3_& cur_tid();
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu::launch((grid), (block), (shmem), [=]() { kernel(__VA_ARGS__); })
 
-inline void __syncthreads() { hipemu::block_barrier(); }
+inline void __syncthreads() { hipemu::dma_retire(0); hipemu::block_barrier(); }
 inline int __lane_id() { return hipemu::tls.cur->lane; }
 
 // ---- wave cross-lane ops -------------------------------------------------------------
@@ -205,7 +231,8 @@ inline hipemu_f32x16 hipemu_mfma_32x32x2_f32(float a, float b, hipemu_f32x16 c) 
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_16x16x4_f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_32x32x2_f32(a, b, c)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-#define __builtin_amdgcn_s_waitcnt(x) ((void)0)   /* loads and LDS-DMA are synchronous in the emulator */
+/* gfx9 s_waitcnt immediate: vmcnt = bits [3:0] | [15:14] << 4.  Only LDS-DMA is modelled (late-landing mode). */
+#define __builtin_amdgcn_s_waitcnt(x) hipemu::dma_retire((int)(((x) & 0xF) | ((((x) >> 14) & 3) << 4)))
 #define __builtin_amdgcn_s_barrier() hipemu::block_barrier()
 /* wave_barrier is only a scheduling fence on hardware (a wave runs in lockstep); the fibres of a wave do not */
 #define __builtin_amdgcn_wave_barrier() do { int z_ = 0; (void)hipemu::wave_exchange(&z_, sizeof(z_)); } while (0)
@@ -236,7 +263,7 @@ inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 // ---- LDS-DMA and LDS transpose read (gfx950) ---------------------------------------------
 // global_load_lds: lane l copies `size` bytes from its own global address to lds_base + l*size.
 inline void hipemu_global_load_lds(const void* src, void* lds_base, int size, int offset) {
-    memcpy((char*)lds_base + offset + hipemu::tls.cur->lane * size, src, size);
+    hipemu::dma_write((char*)lds_base + offset + hipemu::tls.cur->lane * size, src, size);
 }
 #define __builtin_amdgcn_global_load_lds(src, dst, size, off, aux) \
     hipemu_global_load_lds((const void*)(uintptr_t)(src), (void*)(uintptr_t)(dst), (size), (off))
@@ -249,7 +276,10 @@ typedef hipemu_rsrc __amdgpu_buffer_rsrc_t;
 inline hipemu_rsrc hipemu_make_rsrc(const void* p, int num) { return hipemu_rsrc{(const char*)p, (uint32_t)num}; }
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) hipemu_make_rsrc((p), (num))
 inline void hipemu_buffer_load_lds(hipemu_rsrc r, void* lds_base, int size, unsigned voff, unsigned soff, int imm) {
-    char* dst = (char*)lds_base + hipemu::tls.cur->lane * size;
+    char* const dst_lds = (char*)lds_base + hipemu::tls.cur->lane * size;
+    char tmp[16];
+    char* dst = tmp;
+    if (size > 16) abort();
     for (int d = 0; d < size; d += 4) {
         const unsigned long long o = (unsigned long long)voff + (unsigned)imm + (unsigned)d;
         if (o + 4 > r.bytes) { memset(dst + d, 0, 4); continue; }
@@ -260,6 +290,7 @@ inline void hipemu_buffer_load_lds(hipemu_rsrc r, void* lds_base, int size, unsi
         }
         memcpy(dst + d, r.base + o + soff, 4);
     }
+    hipemu::dma_write(dst_lds, tmp, size);
 }
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, size, voff, soff, imm, aux) \
     hipemu_buffer_load_lds((rsrc), (void*)(uintptr_t)(dst), (size), (unsigned)(voff), (unsigned)(soff), (imm))

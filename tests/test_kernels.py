@@ -1047,3 +1047,114 @@ def test_conv3x3_kernel_sharing_the_operand_tile_across_a_filter_row(backend, N,
     yq = new[1].view(-1, KO).double()
     assert rel_err(new[2][0], yq.sum(0).float()) < 1e-3 and rel_err(new[2][1], (yq * yq).sum(0).float()) < 1e-3
     assert rel_err(new[5], old[5]) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------- generation 3 (gemm_v3.h)
+def _set_dma_late(backend, late):
+    """emulator only: 1 = an LDS-DMA lands at the issuing lane's covering s_waitcnt vmcnt (the latest the hardware allows:
+    a read placed before wait + barrier sees stale bytes), 0 = at issue (the earliest: a stage issued in front of the last
+    read of the bytes it replaces corrupts that read)"""
+    import ctypes
+    from virtex_amd import _lib
+    if backend == "emu":
+        _lib.lib().hipemu_set_dma_late(ctypes.c_int(late))
+
+
+GEN3_PARAMS = [pytest.param("emu", 0, marks=pytest.mark.emu), pytest.param("emu", 1, marks=pytest.mark.emu),
+               pytest.param("gpu", 0, marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("backend,late", GEN3_PARAMS)
+@pytest.mark.parametrize("cand", [20, 21])
+def test_contraction_generation3_gemm(backend, late, cand):
+    """The phase-interleaved kernels (20: 256x256 blocks, 21: 256x128) on plain matrices: one K tile, odd and even tile
+    counts (the 256x256 loop works off two tiles per trip, the 256x128 loop three), a ragged K tail, ragged M / N, every
+    epilogue flavour of vtx_gemm_nt, against torch fp32 on the same bf16 operands."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(100 + cand)
+    try:
+        _set_dma_late(backend, late)
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
+        for (M, N, K) in ((300, 520, 64), (300, 520, 192), (520, 300, 200), (260, 132, 448), (257, 516, 512)):
+            a = torch.randn(M, K, generator=g).to(dt); b = torch.randn(N, K, generator=g).to(dt)
+            bias = torch.randn(N, generator=g); res = torch.randn(M, N, generator=g).to(dt)
+            out = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), res.to(dev), act=ops.ACT_GELU)
+            assert _generation() == 3
+            ref = F.gelu(a.float() @ b.float().t() + bias) + res.float()
+            assert rel_err(out.float().cpu(), ref) < 1e-2, (M, N, K)
+            out32 = ops.gemm_nt(a.to(dev), b.to(dev), bias.to(dev), out_f32=True)
+            assert rel_err(out32.cpu(), a.float() @ b.float().t() + bias) < 2e-5 * K ** 0.5, (M, N, K)
+        # statistics of the stored output (forward convolutions) ...
+        M, N, K = 700, 256, 320
+        a = torch.randn(M, K, generator=g).to(dt); b = (torch.randn(N, K, generator=g) / K ** 0.5).to(dt)
+        shift = 0.3 * torch.randn(N, generator=g)
+        y, st = ops.gemm_nt(a.to(dev), b.to(dev), bn_shift=shift.to(dev))
+        assert _generation() == 3 and st is not None and st.strips == (M + 255) // 256
+        parts = st.parts[: st.strips * 2 * N].view(st.strips, 2, N).cpu()
+        d = y.float().cpu() - shift
+        assert torch.allclose(parts[:, 0].sum(0), d.sum(0), atol=2e-2, rtol=1e-3)
+        assert torch.allclose(parts[:, 1].sum(0), (d * d).sum(0), rtol=1e-3)
+        # ... and the fused BatchNorm backward (input-gradient convolutions)
+        x = (0.7 * torch.randn(M, N, generator=g) + 0.3).to(dt); res = torch.randn(M, N, generator=g).to(dt)
+        mean = x.float().mean(0); rstd = (x.float().var(0, unbiased=False) + 1e-5).rsqrt()
+        gamma = 0.5 + torch.rand(N, generator=g); beta = 0.2 * torch.randn(N, generator=g)
+        z = a.float() @ b.float().t() + res.float()
+        dz_r, s1_r, s2_r, _ = _bn_bwd_reference(z, x.float(), mean, rstd, gamma, beta, None, "remask")
+        bn = ops.BnBwd(x.to(dev), mean.to(dev), rstd.to(dev), gamma=gamma.to(dev), beta=beta.to(dev))
+        dz, st = ops.gemm_nt_bnbwd(a.to(dev), b.to(dev), bn, residual=res.to(dev))
+        assert _generation() == 3 and st is not None and st.strips == (M + 255) // 256
+        assert rel_err(dz.float().cpu(), dz_r) < 1e-2
+        parts = st.parts[: st.strips * 2 * N].view(st.strips, 2, N).cpu()
+        assert rel_err(parts[:, 0].sum(0), s1_r) < 1e-2 and rel_err(parts[:, 1].sum(0), s2_r) < 1e-2
+        # tied projection + cross-entropy: row log-sum-exp partials per column group, softmax-gradient epilogue
+        R, V, H = 300, 1000, 128
+        h = torch.randn(R, H, generator=g).to(dt); w = (0.3 * torch.randn(V, H, generator=g)).to(dt)
+        bias = 0.2 * torch.randn(V, generator=g)
+        tgt = torch.randint(1, V, (R,), generator=g); tgt[::7] = 0
+        logits = (h.float() @ w.float().t() + bias).requires_grad_()
+        ref = F.cross_entropy(logits, tgt, ignore_index=0)
+        ref.backward()
+        lc, lse = ops.tied_ce_fwd(h.to(dev), w.to(dev), bias.to(dev), tgt.to(dev), 0)
+        assert _generation() == 3
+        assert abs(lc[0].item() - ref.item()) < 2e-4 * abs(ref.item())
+        assert torch.allclose(lse.cpu(), torch.logsumexp(logits.detach(), 1), rtol=2e-4, atol=2e-4)
+        dl = ops.tied_ce_bwd(h.to(dev), w.to(dev), bias.to(dev), tgt.to(dev), lse, lc, torch.tensor([1.7]).to(dev), 0)
+        assert rel_err(dl.float().cpu(), 1.7 * logits.grad) < 1e-2
+    finally:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+        _set_dma_late(backend, 0)
+
+
+@pytest.mark.parametrize("backend,late", GEN3_PARAMS)
+@pytest.mark.parametrize("cand", [20, 21])
+def test_contraction_generation3_convolutions(backend, late, cand):
+    """The same kernels behind the im2col-free gathers: 3x3 stride 1 forward / input gradient (tap masks, negative tap
+    offsets), the stride-2 parity decomposition (four tap lists) and a strided 1x1, 64 channels (one K tile per tap)."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(200 + cand)
+    try:
+        _set_dma_late(backend, late)
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
+        for (k, stride, H, C, KO) in ((3, 1, 9, 64, 64), (3, 2, 10, 64, 128), (1, 2, 8, 128, 64), (3, 1, 7, 128, 64)):
+            pad = k // 2
+            x = torch.randn(3, H, H, C, generator=g).to(dt)
+            w = (torch.randn(KO, k, k, C, generator=g) / (k * k * C) ** 0.5).to(dt)
+            xr = x.float().permute(0, 3, 1, 2).requires_grad_(); wr = w.float().permute(0, 3, 1, 2)
+            yr = F.conv2d(xr, wr, stride=stride, padding=pad)
+            dy = torch.randn(yr.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dt)
+            yr.backward(dy.float().permute(0, 3, 1, 2))
+            y = ops.conv2d_fwd(x.to(dev), w.to(dev), stride, pad)
+            assert _generation() == 3
+            assert rel_err(y.float().cpu(), yr.detach().permute(0, 2, 3, 1)) < 1e-2, (k, stride, H)
+            dx = ops.conv2d_dgrad(dy.to(dev), w.permute(3, 1, 2, 0).contiguous().to(dev), x.shape, stride, pad)
+            assert _generation() == 3
+            assert rel_err(dx.float().cpu(), xr.grad.permute(0, 2, 3, 1)) < 1e-2, (k, stride, H)
+    finally:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+        _set_dma_late(backend, 0)

@@ -33,11 +33,11 @@ extern "C" const char* vtx_backend(void) {
 // Runtime switch used for A/B measurements of the two contraction-kernel generations.
 namespace vtxg { int g_vtx_contraction_generation = 2; int g_vtx_ablate = getenv("VIRTEX_AMD_KFLAGS") ? atoi(getenv("VIRTEX_AMD_KFLAGS")) : 0;   /* 16: tile-major split-K block order (A/B) */ int g_vtx_tile_override = -1; thread_local int g_vtx_last_colgroups = 0; thread_local int g_vtx_last_generation = 0; }
 extern "C" int vtx_last_contraction_generation(void) { return vtxg::g_vtx_last_generation; }
-namespace vtxg { std::atomic<long> g_vtx_generation_count[3]; }
+namespace vtxg { std::atomic<long> g_vtx_generation_count[4]; }
 extern "C" int vtx_contraction_generation_counts(long* gen1, long* gen2, int reset) {
     if (gen1) *gen1 = vtxg::g_vtx_generation_count[1].load();
-    if (gen2) *gen2 = vtxg::g_vtx_generation_count[2].load();
-    if (reset) { vtxg::g_vtx_generation_count[1] = 0; vtxg::g_vtx_generation_count[2] = 0; }
+    if (gen2) *gen2 = vtxg::g_vtx_generation_count[2].load() + vtxg::g_vtx_generation_count[3].load();   // the LDS-DMA generations
+    if (reset) { vtxg::g_vtx_generation_count[1] = 0; vtxg::g_vtx_generation_count[2] = 0; vtxg::g_vtx_generation_count[3] = 0; }
     return VTX_OK;
 }
 extern "C" int vtx_set_contraction_generation(int gen) {
@@ -60,6 +60,7 @@ int g_vtx_sw_bn_adj = getenv("VIRTEX_AMD_BN_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_A
 int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN_GRID")) : 8192;  // ... and their grid cap
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
+namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 0; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, 1 automatic
 namespace vtxg { int g_vtx_sw_mc_eff128 = getenv("VIRTEX_AMD_MC_EFF128") ? atoi(getenv("VIRTEX_AMD_MC_EFF128")) : 84; }   // tile picker: 128x128 efficiency (%) for k-major operands
 extern "C" int vtx_set_switch(const char* name, int value) {
     VTX_CHECK(name, VTX_ERR_ARG, "vtx_set_switch: null name");
@@ -71,6 +72,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "tile_order")) vtxg::g_vtx_ablate = (vtxg::g_vtx_ablate & ~32) | (value ? 32 : 0);   // 1: plain block -> tile order (A/B)
     else if (!strcmp(name, "bn_adj")) g_vtx_sw_bn_adj = value;
     else if (!strcmp(name, "bn_grid")) g_vtx_sw_bn_grid = value > 0 ? value : 8192;
+    else if (!strcmp(name, "gen3")) vtxg::g_vtx_sw_gen3 = value;
     else if (!strcmp(name, "conv3x3_shared")) vtxg::g_vtx_sw_conv3x3_shared = value;
     else if (!strcmp(name, "tile64x256")) vtxg::g_vtx_sw_tile64x256 = value;
     else if (!strcmp(name, "mc_eff128")) vtxg::g_vtx_sw_mc_eff128 = value > 0 ? value : 84;

@@ -1465,7 +1465,7 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
 }
 
 extern int g_vtx_contraction_generation;   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
-extern std::atomic<long> g_vtx_generation_count[3];   // launches per generation (process-wide; vtx_contraction_generation_counts)
+extern std::atomic<long> g_vtx_generation_count[4];   // launches per generation (process-wide; vtx_contraction_generation_counts)
 extern thread_local int g_vtx_last_generation;  // 1 / 2: which kernel generation this thread's last launch_auto picked
 extern thread_local int g_vtx_last_colgroups;   // column groups (tiles_n x waves per tile row) of this thread's last launch: EpiRowLse partials
 extern int g_vtx_ablate;   // measurement only: bit0 no MFMA, bit1 no fragment reads, bit2 no DMA, bit3 no barrier
@@ -1547,6 +1547,8 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
     return tiles_m;         // number of statistics strips (block rows) this launch produced
 }
 
+#include "gemm_v3.h"
+
 // Tile choice.  Score = (tile efficiency) x (wave quantisation of the grid over 256 CUs) x (padding
 // efficiency); candidates with BN > what N needs are skipped.
 struct TileCand { int bm, bn, resident; float eff; };
@@ -1584,6 +1586,21 @@ inline int pick_tile(int M, int N, int splits, bool allow256, bool mc = false) {
     return best;
 }
 
+// Generation 3 or not: 0 = no, 1 = 256x256 blocks, 2 = 256x128 blocks.  Tile override 20 / 21 forces them (tests, sweeps).
+extern int g_vtx_sw_gen3;
+inline int pick_gen3(int M, int N, int K, int splits) {
+    if (g_vtx_tile_override == 20) return 1;
+    if (g_vtx_tile_override == 21) return 2;
+    if (g_vtx_tile_override >= 0 || !g_vtx_sw_gen3) return 0;
+    if (K < 512 || M < 1024 || N < 128 || splits > 1) return 0;
+    // one block per CU: what counts is how many rounds of 256 blocks the grid takes and how full the last one is
+    const long t256 = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, 256), t128 = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, 128);
+    auto cost = [](long tiles, double area, double eff) { return (double)((tiles + 255) / 256) * area / eff; };
+    const double c256 = N > 128 ? cost(t256, 256.0 * 256.0, 1.0) : 1e30;
+    const double c128 = cost(t128, 256.0 * 128.0, 0.85);
+    return c256 <= c128 ? 1 : 2;
+}
+
 // Returns the number of BatchNorm-statistics strips written (0 when the kernel generation that ran
 // does not produce them: the caller then falls back to the stand-alone reduction).
 template <class T, template <class, int> class ALT, template <class, int> class BLT, class EP, class FA, class FB>
@@ -1609,15 +1626,26 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
         // image operand, is then read once per K slice instead of twice (the kernel is HBM-bound: 822 -> 411 MB of dy).
         if (v2 && g_vtx_sw_tile64x256 && g_vtx_tile_override < 0 && M <= 64 && N > 128 && N <= 256) c = 7;
     }
-    g_vtx_last_generation = v2 ? 2 : 1;
-    g_vtx_generation_count[v2 ? 2 : 1].fetch_add(1, std::memory_order_relaxed);
 #define VTX_V1(BM_, BN_, SA_, SB_)                                                          \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); launch_v1<T, BM_, BN_>(a, b, ep, M, N, K, split_k, st); }
 #define VTX_V2(BM_, BN_, WM_, WN_, SA_, SB_)                                                \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); strips = launch_v2<BM_, BN_, WM_, WN_>(a, b, ep, M, N, K, split_k, st); }
     int strips = 0;
+    if constexpr (BF && !ALT<T, 1>::MC && !BLT<T, 1>::MC) {
+        // generation 3 (gemm_v3.h): 8-wave 256x256 / 256x128 blocks with the phase-interleaved K loop
+        const int g3 = v2 ? pick_gen3(M, N, K, split_k) : 0;
+        if (g3 && buf_ok(64)) {
+            g_vtx_last_generation = 3;
+            g_vtx_generation_count[3].fetch_add(1, std::memory_order_relaxed);
+            if (g3 == 1) { ALT<T, 4> a; make_a(a); BLT<T, 4> b; make_b(b); strips = launch_v3<256>(a, b, ep, M, N, K, split_k, st); }
+            else { ALT<T, 4> a; make_a(a); BLT<T, 2> b; make_b(b); strips = launch_v3<128>(a, b, ep, M, N, K, split_k, st); }
+            return EP::STATS ? strips : 0;
+        }
+    }
 #define VTX_V2X(BM_, BN_, WM_, WN_, BK_, ST_, SA_, SB_)                                    \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); strips = launch_v2<BM_, BN_, WM_, WN_, BK_, ST_>(a, b, ep, M, N, K, split_k, st); }
+    g_vtx_last_generation = v2 ? 2 : 1;
+    g_vtx_generation_count[v2 ? 2 : 1].fetch_add(1, std::memory_order_relaxed);
     if constexpr (BF && !ALT<T, 1>::MC && !BLT<T, 1>::MC && !EP::STATS) {
         // Row-major operands, small grids: when 256x128 tiles would not even give every CU one block, LDS
         // capacity is free, so stage 64-deep K steps -- every LDS-DMA row is a whole 128-byte line (measured

@@ -1,0 +1,429 @@
+// Generation 3 of the contraction kernel (included by gemm_kernel.h, namespace vtxg): a deep-pipelined K loop for the
+// MFMA-leaning classes -- text-head GEMMs, 3x3 / strided convolutions and 1x1 convolutions of the 14x14 / 7x7 stages,
+// forward and input gradient (row-major "KC" operand pairs).  Same loaders, same epilogues, same C = epi(A B^T) contract
+// as generation 2; what changes is the shape of the K loop:
+//
+//   * 8 waves, ONE block per CU, 64-deep K tiles staged by LDS-DMA in UNITS of 128 rows x 64 k (16 KiB = two 1-KiB
+//     wave-instructions per wave).  A unit is not a contiguous row range of the tile: it holds, for every wave along the
+//     operand's axis, the rows of ONE sub-block of that wave's tile (unit row r <-> operand row (r / QR) * WT + u * QR +
+//     r % QR), so that a unit is consumed -- by all of its readers -- in exactly one phase and can be re-staged right after.
+//   * a K tile is worked off in PHASES of 16 MFMAs per wave; every phase is
+//         fragment reads of the phase (ds_read_b128) | stage one or two units (LDS-DMA) | [counted waits] | s_barrier |
+//         lgkmcnt(0) | 16 MFMAs at raised priority | s_barrier
+//     and the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run staggered by ONE barrier, so that on every
+//     SIMD one wave is in its MFMA cluster while the other issues its reads and DMAs.
+//   * the DMA queue is never drained inside the loop: `s_waitcnt vmcnt(6)` once per K tile leaves three units (one and a
+//     half K-tile halves) in flight across the barriers.
+//
+// Hazard rules the schedules below are built on (cdna_hip_programming.md section 5, "The 256^2 8-phase template"):
+//   RAW  a staged unit is read one phase AFTER the phase whose counted vmcnt retires it (the wait sits in front of that
+//        phase's first barrier; with the groups staggered by a barrier, a reader has then passed a barrier behind EVERY
+//        wave's wait);
+//   WAR  a unit is re-staged two phases after the phase that issued its last reads -- or one phase after, when an lgkmcnt
+//        in front of the reading phase's first barrier retired those reads (the four B reads of a 12-read phase, issued
+//        first: lgkmcnt(8)).
+// The CPU emulator checks RAW in its late-landing DMA mode (a DMA lands at the issuing lane's covering vmcnt) and the
+// issue-order part of WAR in its default mode (a DMA lands at issue): tests/test_kernels.py runs the v3 cases in both.
+#pragma once
+
+#ifdef HIPEMU
+#define VTX3_WAIT_VM(N) hipemu::dma_retire(N)
+#define VTX3_WAIT_LGKM(N) ((void)0)
+#define VTX3_FENCE() ((void)0)
+#else
+#define VTX3_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#define VTX3_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory")
+#define VTX3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+constexpr int V3_UNIT = 128 * 64;          // elements of a staged unit (128 rows x 64 k, 16 KiB)
+
+// Stages the units of one operand.  WT = rows of the operand one wave's tile spans, QR = rows of one sub-block.
+template <int WT, int QR, class L> struct UnitStager {
+    static_assert(!L::MC, "generation 3 takes row-major (k-contiguous) operands");
+    static_assert(WT % QR == 0 && 128 % QR == 0 && QR % 16 == 0, "sub-blocks tile the wave tile and the unit");
+    static constexpr int NU = WT / QR;       // units per K tile
+    typename L::BState st;                   // slot 2u + j: wave-instruction j of unit u
+    __amdgpu_buffer_rsrc_t rsrc;
+
+    __device__ __forceinline__ void init(const L& l, int row0, int wave, int lane) {
+        const BufView v = l.view();
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(v.base), (short)0, (int)v.bytes, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = 8 * (wave + 8 * j) + (lane >> 3);          // unit row this lane stages (128-byte rows: 8 lanes each)
+                const int orow = (r / QR) * WT + u * QR + (r % QR);      // operand row inside the block tile
+                l.template binit<64>(st, 2 * u + j, row0 + orow, 8 * swz_slot64(lane & 7, r));
+            }
+    }
+    // wave-instruction J of unit U of the K tile starting at k0; valid == false (wave-uniform: the tile lies beyond this
+    // block's K range) delivers zeros -- the DMA count per phase stays what the vmcnt immediates assume
+    template <int U, int J> __device__ __forceinline__ void issue1(const L& l, int k0, bool valid, bf16_t* unit, int wave) {
+        const uint32_t so = valid ? l.template soff<64>(k0) : 0u;
+        uint32_t vo;
+        if constexpr (L::TAILS) vo = l.template voff<false, 64>(st, 2 * U + J, k0);
+        else vo = l.template voff<true, 64>(st, 2 * U + J, k0);
+        if (!valid) vo = VTX_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(unit + (wave + 8 * J) * 512),
+                                                 16, (int)vo, (int)so, 0, 0);
+    }
+    template <int U> __device__ __forceinline__ void issue(const L& l, int k0, bool valid, bf16_t* unit, int wave) {
+        issue1<U, 0>(l, k0, valid, unit, wave);
+        issue1<U, 1>(l, k0, valid, unit, wave);
+    }
+};
+
+__device__ __forceinline__ bf16x8_t v3_ld(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+
+// element offset, inside a unit, of this lane's fragment of unit rows r0 .. r0+15 (r0 % 16 == 0) for the k half h
+__device__ __forceinline__ int v3_lane_off(int r0, int lane, int h) {
+    return (r0 + (lane & 15)) * 64 + (((4 * h + (lane >> 4)) ^ ((lane >> 1) & 7)) * 8);
+}
+
+// XCD-aware block -> (tile, slice) map of the contraction kernels (see contraction_v2_kernel)
+__device__ __forceinline__ void v3_block_tile(int abl, int& tile, int& slice) {
+    if (abl & 32) { tile = blockIdx.x; slice = blockIdx.y; return; }
+    if (gridDim.y == 1 || (abl & 16)) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        slice = blockIdx.y;
+    } else {
+        const int T = gridDim.x, nwg = T * gridDim.y, L = blockIdx.y * T + blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, idx = L >> 3;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        slice = w / T; tile = w - slice * T;
+    }
+}
+
+// A/B builds (python -m virtex_amd.build --variant X --define ...): VTX3_NO_LGKM0 leaves the fragment waits to hipcc's own
+// lgkmcnt ladder inside the MFMA cluster, VTX3_NO_PRIO drops the priority flips, VTX3_NO_STAGGER runs the two wave groups in
+// lockstep (what the stagger is worth)
+#ifdef VTX3_NO_LGKM0
+#define V3_WAIT_FRAGS() ((void)0)
+#else
+#define V3_WAIT_FRAGS() VTX3_WAIT_LGKM(0)
+#endif
+#ifdef VTX3_NO_PRIO
+#define V3_PRIO(x) ((void)0)
+#else
+#define V3_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+#ifdef VTX3_NO_STAGGER
+#define V3_STAGGER(cond) ((void)0)
+#else
+#define V3_STAGGER(cond) do { if (cond) __builtin_amdgcn_s_barrier(); } while (0)
+#endif
+// the synchronised half of a phase: everything the phase issued is behind the first barrier; MFMAs between the barriers
+#define V3_COMPUTE_BEGIN()                \
+    VTX3_FENCE();                         \
+    __builtin_amdgcn_s_barrier();         \
+    V3_WAIT_FRAGS();                      \
+    VTX3_FENCE();                         \
+    V3_PRIO(1);
+#define V3_COMPUTE_END()                  \
+    V3_PRIO(0);                           \
+    VTX3_FENCE();                         \
+    __builtin_amdgcn_s_barrier();         \
+    VTX3_FENCE();
+
+// ------------------------------------------------------------------ 256 x 256: waves 2 (M) x 4 (N), wave tile 128 x 64
+// Units per K tile: A0 A1 (sub-blocks of 64 rows), B0 B1 (sub-blocks of 32 rows); two LDS buffers E / O of four units.
+// K tile t (buffer E, phases 1-4; t+1: buffer O, phases 5-8), per wave:
+//   phase 1  reads b0 (4) then a0 (8)   MFMA a0 x b0     phase 2  reads b1 (4)   MFMA a0 x b1
+//   phase 3  reads a1 (8)               MFMA a1 x b1     phase 4  no reads       MFMA a1 x b0
+// Staging (one unit per phase), tile indices relative to the iteration's even tile t:
+//   1: O.A1 <- t+1   2: E.B0 <- t+2   3: E.A0 <- t+2   4: E.B1 <- t+2   [vmcnt(6): O complete]
+//   5: E.A1 <- t+2   6: O.B0 <- t+3   7: O.A0 <- t+3   8: O.B1 <- t+3   [vmcnt(6): E complete]
+// WAR: E.B0 last read in phase 1 behind lgkmcnt(8) -> phase 2; E.A0 phase 1 -> 3; E.B1 phase 2 -> 4; E.A1 phase 3 -> 5; O alike.
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
+                                                                        int abl) {
+    constexpr int BM = 256, BN = 256, WM = 2, WN = 4, MT = 8, NT = 4;
+    constexpr int BUF = 4 * V3_UNIT;
+    typedef UnitStager<128, 64, AL> SA;
+    typedef UnitStager<64, 32, BL> SB;
+    HIP_DYNAMIC_SHARED(bf16_t, lds)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    int tile, slice;
+    v3_block_tile(abl, tile, slice);
+    set_slice(ep, slice);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int nkt = (K + 63) >> 6;
+    const int kt0 = slice * kt_per_split;
+    const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
+
+    SA sa; SB sb;
+    sa.init(al, m0, wave, lane);
+    sb.init(bl, n0, wave, lane);
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int PPT = EpiShape<BN, 8, EP>::PPT;
+    float pre[PPT][4];
+    epi_prefetch<BN, 8>(ep, pre, tid, n0);
+
+    bf16_t* const E = lds;
+    bf16_t* const O = lds + BUF;
+    constexpr int A0 = 0, A1 = V3_UNIT, B0 = 2 * V3_UNIT, B1 = 3 * V3_UNIT;
+    const int al0 = v3_lane_off(wm * 64, lane, 0), al1 = v3_lane_off(wm * 64, lane, 1);
+    const int bl0 = v3_lane_off(wn * 32, lane, 0), bl1 = v3_lane_off(wn * 32, lane, 1);
+    bf16x8_t fa[4][2], fb[2][2][2];
+
+#define V3_READ_A(X, U)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
+        fa[i][0] = v3_ld((X) + (U) + al0 + i * 1024);                           \
+        fa[i][1] = v3_ld((X) + (U) + al1 + i * 1024);                           \
+    }
+#define V3_READ_B(X, U, Q)                                                     \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                             \
+        fb[Q][j][0] = v3_ld((X) + (U) + bl0 + j * 1024);                        \
+        fb[Q][j][1] = v3_ld((X) + (U) + bl1 + j * 1024);                        \
+    }
+// (a tile past the end of the block's K range was staged as zeros: its MFMAs run and add nothing -- a branch around them
+//  leaves hipcc with fragment reads it believes pending on one path, and it pads every later read with an s_waitcnt)
+#define V3_MMA(UA, UB)                                                                                                \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
+                acc[(UA) * 4 + i][(UB) * 2 + j] =                                                                     \
+                    __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[UB][j][h], fa[i][h], acc[(UA) * 4 + i][(UB) * 2 + j], 0, 0, 0);
+
+    if (kt0 < kt1) {
+        // prologue: the whole first tile, three units of the second
+        sb.template issue<0>(bl, kt0 * 64, true, E + B0, wave);
+        sa.template issue<0>(al, kt0 * 64, true, E + A0, wave);
+        sb.template issue<1>(bl, kt0 * 64, true, E + B1, wave);
+        sa.template issue<1>(al, kt0 * 64, true, E + A1, wave);
+        {
+            const bool v1 = kt0 + 1 < kt1;
+            sb.template issue<0>(bl, (kt0 + 1) * 64, v1, O + B0, wave);
+            sa.template issue<0>(al, (kt0 + 1) * 64, v1, O + A0, wave);
+            sb.template issue<1>(bl, (kt0 + 1) * 64, v1, O + B1, wave);
+        }
+        VTX3_WAIT_VM(6);
+        __builtin_amdgcn_s_barrier();
+        V3_STAGGER(wave >= 4);                                // the second wave group runs one barrier behind
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            const bool v1 = kt + 1 < kt1, v2 = kt + 2 < kt1, v3 = kt + 3 < kt1;
+            const int k1 = (kt + 1) * 64, k2 = (kt + 2) * 64, k3 = (kt + 3) * 64;
+            // ---- phase 1
+            V3_READ_B(E, B0, 0)
+            VTX3_FENCE();
+            V3_READ_A(E, A0)
+            sa.template issue<1>(al, k1, v1, O + A1, wave);
+            VTX3_FENCE();
+            VTX3_WAIT_LGKM(8);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(0, 0)
+            V3_COMPUTE_END()
+            // ---- phase 2
+            V3_READ_B(E, B1, 1)
+            sb.template issue<0>(bl, k2, v2, E + B0, wave);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(0, 1)
+            V3_COMPUTE_END()
+            // ---- phase 3
+            V3_READ_A(E, A1)
+            sa.template issue<0>(al, k2, v2, E + A0, wave);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(1, 1)
+            V3_COMPUTE_END()
+            // ---- phase 4
+            sb.template issue<1>(bl, k2, v2, E + B1, wave);
+            VTX3_FENCE();
+            VTX3_WAIT_VM(6);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(1, 0)
+            V3_COMPUTE_END()
+            // ---- phase 5
+            V3_READ_B(O, B0, 0)
+            VTX3_FENCE();
+            V3_READ_A(O, A0)
+            sa.template issue<1>(al, k2, v2, E + A1, wave);
+            VTX3_FENCE();
+            VTX3_WAIT_LGKM(8);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(0, 0)
+            V3_COMPUTE_END()
+            // ---- phase 6
+            V3_READ_B(O, B1, 1)
+            sb.template issue<0>(bl, k3, v3, O + B0, wave);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(0, 1)
+            V3_COMPUTE_END()
+            // ---- phase 7
+            V3_READ_A(O, A1)
+            sa.template issue<0>(al, k3, v3, O + A0, wave);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(1, 1)
+            V3_COMPUTE_END()
+            // ---- phase 8
+            sb.template issue<1>(bl, k3, v3, O + B1, wave);
+            VTX3_FENCE();
+            VTX3_WAIT_VM(6);
+            V3_COMPUTE_BEGIN()
+            V3_MMA(1, 0)
+            V3_COMPUTE_END()
+        }
+        VTX3_WAIT_VM(0);                                      // the zero-fill units staged past the end
+        V3_STAGGER(wave < 4);                                 // the first group catches up
+    }
+#undef V3_READ_A
+#undef V3_READ_B
+#undef V3_MMA
+    tile_epilogue<BM, BN, WM, WN, 2 * BUF * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
+}
+
+// ------------------------------------------------------------------ 256 x 128: waves 4 (M) x 2 (N), wave tile 64 x 64
+// Units per K tile: A0 A1 (sub-blocks of 32 rows), B (the wave's 64 columns; all 128 rows of the tile); THREE LDS buffers
+// of three units (144 KiB): K tile t lives in buffer t % 3 and is worked off in two phases,
+//   phase 1  reads b (8) then a0 (4)    MFMA a0 x b      phase 2  reads a1 (4)    MFMA a1 x b
+// while tile t+2 is staged into buffer (t+2) % 3 = (t-1) % 3 (three wave-instructions per phase: B, A0.0 | A0.1, A1; every
+// unit was last read two phases earlier) and `vmcnt(6)` in phase 2 leaves exactly that tile in flight: tile t+1 is complete.
+template <class AL, class BL, class EP>
+__global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
+                                                                        int abl) {
+    constexpr int BM = 256, BN = 128, WM = 4, WN = 2, MT = 4, NT = 4;
+    constexpr int BUF = 3 * V3_UNIT;
+    typedef UnitStager<64, 32, AL> SA;
+    typedef UnitStager<64, 64, BL> SB;
+    HIP_DYNAMIC_SHARED(bf16_t, lds)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile, slice;
+    v3_block_tile(abl, tile, slice);
+    set_slice(ep, slice);
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int nkt = (K + 63) >> 6;
+    const int kt0 = slice * kt_per_split;
+    const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
+
+    SA sa; SB sb;
+    sa.init(al, m0, wave, lane);
+    sb.init(bl, n0, wave, lane);
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int PPT = EpiShape<BN, 8, EP>::PPT;
+    float pre[PPT][4];
+    epi_prefetch<BN, 8>(ep, pre, tid, n0);
+
+    constexpr int A0 = 0, A1 = V3_UNIT, B = 2 * V3_UNIT;
+    const int al0 = v3_lane_off(wm * 32, lane, 0), al1 = v3_lane_off(wm * 32, lane, 1);
+    const int bl0 = v3_lane_off(wn * 64, lane, 0), bl1 = v3_lane_off(wn * 64, lane, 1);
+    bf16x8_t fa[2][2], fb[4][2];
+
+#define V3_READ_A(X, U)                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                             \
+        fa[i][0] = v3_ld((X) + (U) + al0 + i * 1024);                           \
+        fa[i][1] = v3_ld((X) + (U) + al1 + i * 1024);                           \
+    }
+#define V3_READ_B(X)                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                             \
+        fb[j][0] = v3_ld((X) + B + bl0 + j * 1024);                             \
+        fb[j][1] = v3_ld((X) + B + bl1 + j * 1024);                             \
+    }
+#define V3_MMA(UA)                                                                                                    \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
+                acc[(UA) * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][h], fa[i][h], acc[(UA) * 2 + i][j], 0, 0, 0);
+// one K tile: X = its buffer, Y = the buffer tile +2 is staged into, V = tile +2 exists
+#define V3_TILE(X, Y, K2, V)                                                   \
+    V3_READ_B(X)                                                               \
+    VTX3_FENCE();                                                              \
+    V3_READ_A(X, A0)                                                           \
+    sb.template issue<0>(bl, K2, V, (Y) + B, wave);                            \
+    sa.template issue1<0, 0>(al, K2, V, (Y) + A0, wave);                       \
+    V3_COMPUTE_BEGIN()                                                         \
+    V3_MMA(0)                                                                  \
+    V3_COMPUTE_END()                                                           \
+    V3_READ_A(X, A1)                                                           \
+    sa.template issue1<0, 1>(al, K2, V, (Y) + A0, wave);                       \
+    sa.template issue<1>(al, K2, V, (Y) + A1, wave);                           \
+    VTX3_FENCE();                                                              \
+    VTX3_WAIT_VM(6);                                                           \
+    V3_COMPUTE_BEGIN()                                                         \
+    V3_MMA(1)                                                                  \
+    V3_COMPUTE_END()
+
+    if (kt0 < kt1) {
+        bf16_t* const X0 = lds;
+        bf16_t* const X1 = lds + BUF;
+        bf16_t* const X2 = lds + 2 * BUF;
+        sb.template issue<0>(bl, kt0 * 64, true, X0 + B, wave);
+        sa.template issue<0>(al, kt0 * 64, true, X0 + A0, wave);
+        sa.template issue<1>(al, kt0 * 64, true, X0 + A1, wave);
+        {
+            const bool v1 = kt0 + 1 < kt1;
+            sb.template issue<0>(bl, (kt0 + 1) * 64, v1, X1 + B, wave);
+            sa.template issue<0>(al, (kt0 + 1) * 64, v1, X1 + A0, wave);
+            sa.template issue<1>(al, (kt0 + 1) * 64, v1, X1 + A1, wave);
+        }
+        VTX3_WAIT_VM(6);
+        __builtin_amdgcn_s_barrier();
+        V3_STAGGER(wave >= 4);
+        for (int kt = kt0; kt < kt1; kt += 3) {
+            V3_TILE(X0, X2, (kt + 2) * 64, kt + 2 < kt1)
+            V3_TILE(X1, X0, (kt + 3) * 64, kt + 3 < kt1)
+            V3_TILE(X2, X1, (kt + 4) * 64, kt + 4 < kt1)
+        }
+        VTX3_WAIT_VM(0);
+        V3_STAGGER(wave < 4);
+    }
+#undef V3_READ_A
+#undef V3_READ_B
+#undef V3_MMA
+#undef V3_TILE
+    tile_epilogue<BM, BN, WM, WN, 3 * BUF * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
+}
+
+// ------------------------------------------------------------------ host side
+extern int g_vtx_sw_gen3;        // vtx_set_switch("gen3"): 0 = generation 3 only when forced by the tile override (20 / 21), 1 = automatic
+
+template <int BN, class AL, class BL, class EP>
+inline int launch_v3(const AL& al, const BL& bl, const EP& ep_in, int M, int N, int K, int split_k, hipStream_t st) {
+    constexpr int BM = 256, WN = BN == 256 ? 4 : 2;
+    const int tiles_m = vtx_cdiv(M, BM), tiles_n = vtx_cdiv(N, BN);
+    const int nkt = vtx_cdiv(K, 64);
+    if (split_k < 1) split_k = 1;
+    if (split_k > nkt) split_k = nkt > 0 ? nkt : 1;
+    const int per = vtx_cdiv(nkt, split_k);
+    split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
+    constexpr size_t lds_bytes = BN == 256 ? 2 * 4 * V3_UNIT * 2 : 3 * 3 * V3_UNIT * 2;
+    auto kern = [] {
+        if constexpr (BN == 256) return contraction_v3_256x256_kernel<AL, BL, EP>;
+        else return contraction_v3_256x128_kernel<AL, BL, EP>;
+    }();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        attr_set = true;
+    }
+    dim3 grid(tiles_m * tiles_n, split_k), block(512);
+    g_vtx_last_colgroups = tiles_n * WN;
+    EP ep = ep_in;
+    if constexpr (EP::STAGED) ep.nt = vtx_nt_policy((double)M * N * sizeof(typename EP::Out));
+    bool prof = g_vtx_prof_on != 0;
+    if (prof) {
+        static const int cls = vtx_prof_register(__PRETTY_FUNCTION__);
+        prof = g_vtx_prof_only < 0 || g_vtx_prof_only == cls;
+        if (prof) {
+            hipEvent_t e0, e1;
+            vtx_prof_events(cls, 2.0 * M * N * K, 2.0 * (algo_elems(al) + algo_elems(bl)) + epi_bytes(ep, (double)M * N, split_k), &e0, &e1);
+            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds_bytes, st, e0, e1, 0, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
+            return tiles_m;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
+    return tiles_m;
+}
