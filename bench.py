@@ -319,6 +319,7 @@ def main(argv=None, device=None, backend=None):
                                         compute_dtype=dt).to(dev).train()
     vd.broadcast_parameters(model)
     buckets = vd.GradientBuckets(model)
+    buckets.measure_exposed = True      # data_parallel.comm_exposed_ms_per_rank (two events per step; off in production)
     opt = FusedPretrainOptimizer(model, buckets, start_step=100)   # inside warm-up: non-zero LR
     batches = [device_batch(a.batch, dev, 1000 * rank + i, a.image_size, a.vocab_size) for i in range(2)]
 

@@ -40,19 +40,23 @@ const char* vtx_backend(void);    /* "hip:gfx950" (product) or "hipemu" (CPU tes
 const char* vtx_last_error(void); /* thread-local */
 /* 2 (default): LDS-DMA (buffer descriptors) + transpose-read bf16 contraction kernel; 1: register-staged kernel (A/B tests) */
 int vtx_set_contraction_generation(int gen);
-int vtx_set_ablation(int bits);        /* measurement only (tools/ablate_gemm.py) */
+int vtx_set_ablation(int bits);        /* measurement only (tools/ablate_gemm.py, tools/ablate_gen3.py) */
+int vtx_set_debug_buffer(void* dev);   /* measurement builds (-DVTX_ABLATE) only: per-wave time stamps of the generation-3 kernels */
 int vtx_set_tile_override(int cand);   /* tests: force a block tile; -1 = automatic */
 /* Measurement switches of the specialised kernels, by name: "wgrad3x3" (0 off, 1 by image size, 2 always), "stem_stream",
- * "expand1x1" (0 / 1), "splitk_blocks" (block target of the split-K weight gradients, default 512).  Defaults come from
+ * "expand1x1" (0 / 1), "splitk_blocks" (block target of the split-K weight gradients, default 512), "gen3" (generation-3
+ * contraction kernels, gemm_v3.h: 0 only when forced by tile override 20 / 21, n >= 2: taken when the cost model predicts
+ * at least n % of the generation-2 class rate, default 80; VIRTEX_AMD_GEN3).  Defaults come from
  * VIRTEX_AMD_WGRAD3X3 / _STEM_STREAM / _EXPAND1X1 / _SPLITK_BLOCKS.  No reference counterpart. */
 int vtx_set_switch(const char* name, int value);
 /* Which contraction kernel this thread's last GEMM-shaped launch ran on: 2 = the DMA kernel (operands addressed through
  * buffer descriptors: needs bf16, operands < 2 GB, convolution channel counts that are multiples of the 32-deep K step),
+ * 3 = the phase-interleaved 8-wave DMA kernel (gemm_v3.h: row-major operand pairs, 64-deep K tiles),
  * 1 = the register-staged kernel (fp32, and everything the DMA kernel does not take).  Tests use it to prove coverage. */
 int vtx_last_contraction_generation(void);
 /* Process-wide launch counts per generation since the last reset (any thread: backward runs on autograd's threads).
  * A bf16 training step of the supported models must not touch generation 1 -- tests assert it, so that a shape that
- * silently falls off the DMA kernel shows up as a failure, not as a slower step. */
+ * silently falls off the DMA kernel shows up as a failure, not as a slower step.  gen2 counts generations 2 and 3. */
 int vtx_contraction_generation_counts(long* gen1, long* gen2, int reset);
 
 /* ---- LayerNorm(x + dropout(y)) --------------------------------------------------------

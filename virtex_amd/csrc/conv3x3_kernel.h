@@ -184,6 +184,8 @@ inline int conv3x3_shared_try(const void* a_ptr, int Nimg, int H, int W, int CH,
     {                                                                                                                     \
         PlainKC<bf16_t, SB_> b; make_b(b);                                                                                \
         if (!b.buf_ok(32)) return 0;                                                                                      \
+        g_vtx_last_generation = 2;                      /* an LDS-DMA kernel: what vtx_last_contraction_generation reports */ \
+        g_vtx_generation_count[2].fetch_add(1, std::memory_order_relaxed);                                                \
         const int tiles_m = vtx_cdiv(M, BM_ - 2), tiles_n = vtx_cdiv(Nout, BN_);                                          \
         constexpr size_t lds_bytes = (2 * (size_t)BM_ * 32 + 3 * (size_t)BN_ * 32) * 2;                                  \
         auto kern = conv3x3_shared_kernel<BM_, BN_, WM_, WN_, PlainKC<bf16_t, SB_>, EP>;                                  \

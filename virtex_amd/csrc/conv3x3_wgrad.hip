@@ -231,7 +231,8 @@ int vtx_conv3x3_wgrad_try(int N, int H, int W, int C, int KO, int R, int S, int 
     const int Hp = H + 2, Wp = W + 2;
     const long P = (long)N * Hp * Wp;
     const int lead = ((Wp + 1 + 31) / 32) * 32, nl = 2 * lead / 32;
-    if (P >= (1L << 24) || W3_RING / 32 < nl + W3_PF + 4 || Wp < 9) return 0;   // ring margins for two steps per barrier (W <= 61)
+    if (P >= (1L << 24) || W3_RING / 32 < nl + W3_PF + 4 || Wp < 9 || Hp < 5) return 0;   // ring margins for two steps per barrier (W <= 61);
+                                                                                         // the loader carries at most ONE image per 32-position step (<= 4 rows of >= 9): Hp >= 5
     // by image size (switch value 1): the padding positions are multiplied as zeros -- +7 % MFMA work at 56x56, +15 % at
     // 28x28, +31 % at 14x14, +65 % at 7x7, where the implicit-GEMM kernel (whose operands then fit the caches) wins
     if (on == 1 && (H < 28 || W < 28)) return 0;

@@ -45,6 +45,8 @@ extern "C" int vtx_set_contraction_generation(int gen) {
     vtxg::g_vtx_contraction_generation = gen;
     return VTX_OK;
 }
+namespace vtxg { unsigned long long* g_vtx_dbg = nullptr; }
+extern "C" int vtx_set_debug_buffer(void* p) { vtxg::g_vtx_dbg = (unsigned long long*)p; return VTX_OK; }   // measurement builds (-DVTX_ABLATE) only
 extern "C" int vtx_set_ablation(int bits) { vtxg::g_vtx_ablate = bits; return VTX_OK; }
 // Run-time switches of the specialised kernels (each starts from its VIRTEX_AMD_* environment variable): what the
 // interleaved step-level A/B of tools/ab_step.py flips between rounds inside one process.
@@ -60,7 +62,7 @@ int g_vtx_sw_bn_adj = getenv("VIRTEX_AMD_BN_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_A
 int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN_GRID")) : 8192;  // ... and their grid cap
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
-namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 0; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, 1 automatic
+namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 80; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, n >= 2: taken when the cost model predicts n % of the generation-2 class rate (step A/B: 80 -> 24.26, 100 -> 24.46, off 24.65 ms/step)
 namespace vtxg { int g_vtx_sw_mc_eff128 = getenv("VIRTEX_AMD_MC_EFF128") ? atoi(getenv("VIRTEX_AMD_MC_EFF128")) : 84; }   // tile picker: 128x128 efficiency (%) for k-major operands
 extern "C" int vtx_set_switch(const char* name, int value) {
     VTX_CHECK(name, VTX_ERR_ARG, "vtx_set_switch: null name");

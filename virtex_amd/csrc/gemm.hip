@@ -34,7 +34,7 @@ int gemm_nt_t(int M, int N, int K, const void* A, long lda, const void* B, long 
             if (s < 0) return s;
             if (s > 0) { if (stat_strips) *stat_strips = s; return VTX_OK; }
         }
-        if (stat_parts && !bias && N % 8 == 0 && ldc == N) {     // statistics epilogues are compiled without the bias path
+        if (stat_parts && !bias && !preact && act == ACT_NONE && drop.thresh == 0u && N % 8 == 0 && ldc == N) {     // statistics epilogues are compiled without the bias / activation / dropout paths
             EpiStore<TO, STATS_FWD> ep{(TO*)C, ldc, bias, (const TO*)residual, ldr, (TO*)preact, act, alpha, drop, M, N};
             ep.stat_parts = stat_parts; ep.stat_shift = stat_shift;
             strips = launch_auto<T, PlainKC, PlainKC>(mk_a, mk_b, ep, M, N, K, 1, st);
@@ -93,7 +93,9 @@ void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc,
 extern int g_vtx_sw_splitk_blocks;
 int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
     long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
-    if (vtxg::g_vtx_sw_tile64x256 && M <= 64 && N > 128 && N <= 256) tiles = 1;      // launch_auto takes one 64x256 tile
+    // launch_auto takes one 64x256 tile -- only on the bf16 LDS-DMA kernel (bk == 32) and without a forced tile
+    if (vtxg::g_vtx_sw_tile64x256 && bk == 32 && vtxg::g_vtx_contraction_generation >= 2 && vtxg::g_vtx_tile_override < 0 &&
+        M <= 64 && N > 128 && N <= 256) tiles = 1;
     const int nkt = vtx_cdiv(K, bk);
     const long target = g_vtx_sw_splitk_blocks;          // VIRTEX_AMD_SPLITK_BLOCKS / vtx_set_switch("splitk_blocks")
     long s = (target + tiles - 1) / tiles;

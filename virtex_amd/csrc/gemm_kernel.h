@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "vtx_common.h"
 
@@ -599,21 +600,27 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         if constexpr (STATS_MODE == STATS_NONE) {                // statistics epilogues belong to bias-free convolutions
             if (bias) { v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         }
-        const long o = (long)m * ldc + n;
-        if (preact) st4v<T>(preact + o, v);
-        if (act == ACT_GELU) {
+        // statistics epilogues belong to the bias-free, activation-free convolutions in front of / behind a BatchNorm: the
+        // activation / dropout / pre-activation code is not even compiled into them (it was: GELU, the dropout hash and the
+        // softmax gradient made up most of the instructions of the fused-BatchNorm-backward kernels, skipped at run time
+        // behind a dozen branches per 16x16 tile)
+        if constexpr (STATS_MODE == STATS_NONE) {
+            const long o = (long)m * ldc + n;
+            if (preact) st4v<T>(preact + o, v);
+            if (act == ACT_GELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-        } else if (act == ACT_RELU) {
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            } else if (act == ACT_RELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-        } else if (STATS_MODE == STATS_NONE && act == ACT_SOFTMAX_GRAD) {
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            } else if (act == ACT_SOFTMAX_GRAD) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = rd.g * (__expf(v[j] - rd.l) - ((long long)(n + j) == rd.t ? 1.f : 0.f));
-        }
-        if (drop.thresh) {
+                for (int j = 0; j < 4; ++j) v[j] = rd.g * (__expf(v[j] - rd.l) - ((long long)(n + j) == rd.t ? 1.f : 0.f));
+            }
+            if (drop.thresh) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = drop.apply(v[j], (uint64_t)(o + j));
+                for (int j = 0; j < 4; ++j) v[j] = drop.apply(v[j], (uint64_t)(o + j));
+            }
         }
         return v;
     }
@@ -681,17 +688,17 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
             v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
         }
     }
-    __device__ __forceinline__ void finish_stats(int m, int n, uint4 w, const Ops& ops, const float* par, int PBN, float* s1,
-                                                 float* s2) const {
-        if (m >= M || n >= N) return;
+    // The statistics arithmetic of ONE 16-byte chunk: w = the chunk's stored-format accumulators, r = its residual (BWD: ops.res,
+    // FWD: passed in), mb = its mask bits; returns the chunk to store and adds its sums to s1 / s2.  Shared by the general path
+    // (finish_stats: bounds, row map, per-tensor strides) and the interior-tile path (finish_stats_at): identical roundings.
+    __device__ __forceinline__ uint4 stats_math(uint4 w, bool has_res, uint4 r16, uint4 x16, uint32_t mb, bool remask,
+                                                const float* par, int PBN, float* s1, float* s2) const {
         constexpr int EPV = 16 / (int)sizeof(T);
-        const long mr = out_row(m);
         float f[EPV];
         unpack16<T>(w, f);
-        if (residual) {
+        if (has_res) {
             float r[EPV];
-            if constexpr (STATS_MODE == STATS_BWD) unpack16<T>(ops.res, r);
-            else unpack16<T>(*reinterpret_cast<const uint4*>(residual + mr * ldr + n), r);
+            unpack16<T>(r16, r);
 #pragma unroll
             for (int e = 0; e < EPV; ++e) f[e] += r[e];
         }
@@ -702,20 +709,12 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
             unpack16<T>(w, f);                   // statistics of what is stored (what the BatchNorm will read)
 #pragma unroll
             for (int e = 0; e < EPV; ++e) { const float d = f[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+            return w;
         } else {
             // four elements (two stored words) at a time: the 16 parameter values of a half are all the registers the
             // table costs (the kernel class lives on six waves per SIMD = 80 VGPRs)
             static_assert(STATS_MODE != STATS_BWD || sizeof(T) == 2, "the fused BatchNorm backward epilogue is bf16");
-            const bool remask = !bn_y && !bn_ybits && bn_beta;      // mask recomputed from x (interior BatchNorms)
-            uint32_t mb = bn_ybits ? ops.mb : 0xffu;
-            if (!bn_ybits && bn_y) {                 // the mask as the whole post-ReLU tensor (VIRTEX_AMD_RELU_BITS=0)
-                float y[EPV];
-                unpack16<T>(*reinterpret_cast<const uint4*>(bn_y + mr * ldy + n), y);
-                mb = 0u;
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) mb |= y[e] > 0.f ? 1u << e : 0u;
-            }
-            const uint32_t xi[4] = {ops.x.x, ops.x.y, ops.x.z, ops.x.w};
+            const uint32_t xi[4] = {x16.x, x16.y, x16.z, x16.w};
             uint32_t wo[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -746,10 +745,58 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { s1[4 * h + e] += g[e]; s2[4 * h + e] += g[e] * xh[e]; }
             }
-            w = make_uint4(wo[0], wo[1], wo[2], wo[3]);
+            return make_uint4(wo[0], wo[1], wo[2], wo[3]);
         }
+    }
+    __device__ __forceinline__ void finish_stats(int m, int n, uint4 w, const Ops& ops, const float* par, int PBN, float* s1,
+                                                 float* s2) const {
+        if (m >= M || n >= N) return;
+        constexpr int EPV = 16 / (int)sizeof(T);
+        const long mr = out_row(m);
+        uint4 r16 = make_uint4(0u, 0u, 0u, 0u), x16 = r16;
+        if constexpr (STATS_MODE == STATS_BWD) { r16 = ops.res; x16 = ops.x; }
+        else if (residual) r16 = *reinterpret_cast<const uint4*>(residual + mr * ldr + n);
+        uint32_t mb = 0xffu;
+        bool remask = false;
+        if constexpr (STATS_MODE == STATS_BWD) {
+            remask = !bn_y && !bn_ybits && bn_beta;      // mask recomputed from x (interior BatchNorms)
+            mb = bn_ybits ? ops.mb : 0xffu;
+            if (!bn_ybits && bn_y) {                     // the mask as the whole post-ReLU tensor (VIRTEX_AMD_RELU_BITS=0)
+                float y[EPV];
+                unpack16<T>(*reinterpret_cast<const uint4*>(bn_y + mr * ldy + n), y);
+                mb = 0u;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) mb |= y[e] > 0.f ? 1u << e : 0u;
+            }
+        }
+        w = stats_math(w, residual != nullptr, r16, x16, mb, remask, par, PBN, s1, s2);
         if (nt) st16_nt(out + mr * ldc + n, u32x4_t{w.x, w.y, w.z, w.w});
         else *reinterpret_cast<uint4*>(out + mr * ldc + n) = w;
+    }
+    // ---- interior tiles (block-uniform: every row and column of the tile exists, no row map, every tensor dense with row
+    // stride N, no whole-tensor mask): the chunk is addressed by ONE precomputed element offset e = m*N + n shared by out,
+    // residual, bn_x and (>> 3) the mask bits -- no bounds logic, no per-chunk 64-bit multiplies, no row-map division
+    __device__ __forceinline__ Ops load_ops_at(long e) const {
+        Ops o;
+        o.res = o.x = make_uint4(0u, 0u, 0u, 0u);
+        o.mb = 0u;
+        if constexpr (STATS_MODE == STATS_BWD) {
+            if (residual) o.res = *reinterpret_cast<const uint4*>(residual + e);
+            o.x = *reinterpret_cast<const uint4*>(bn_x + e);
+            const uint8_t* bp = bn_ybits ? bn_ybits + (e >> 3) : reinterpret_cast<const uint8_t*>(bn_rstd);   // (see load_ops)
+            o.mb = *bp;
+        }
+        return o;
+    }
+    __device__ __forceinline__ void finish_stats_at(long e, uint4 w, const Ops& ops, const float* par, int PBN, float* s1, float* s2) const {
+        uint32_t mb = 0xffu;
+        bool remask = false;
+        if constexpr (STATS_MODE == STATS_BWD) { remask = !bn_ybits && bn_beta; mb = bn_ybits ? ops.mb : 0xffu; }
+        uint4 r16 = make_uint4(0u, 0u, 0u, 0u), x16 = r16;
+        if constexpr (STATS_MODE == STATS_BWD) { r16 = ops.res; x16 = ops.x; }
+        w = stats_math(w, STATS_MODE == STATS_BWD && residual != nullptr, r16, x16, mb, remask, par, PBN, s1, s2);
+        if (nt) st16_nt(out + e, u32x4_t{w.x, w.y, w.z, w.w});
+        else *reinterpret_cast<uint4*>(out + e) = w;
     }
     __device__ __forceinline__ void operator()(int m, int n, f32x4_t acc) const {
         if (m >= M || n >= N) return;
@@ -784,6 +831,18 @@ template <class T, int STATS_MODE = STATS_NONE> struct EpiStore {
         st4<T>(out + o, v);
     }
 };
+// Host side: may this launch take the kernel instantiation whose statistics epilogue is compiled for INTERIOR tiles only
+// (tile_epilogue<..., LEAN = true>)?  Every tile of the grid must lie inside the matrix, every tensor must be dense with row
+// stride N, no row map, no whole-tensor mask -- at bs = 256 every BatchNorm-carrying convolution of ResNet-50 qualifies
+// (M = 256 * H * W is a multiple of every block height).
+template <class EP> inline bool lean_host_ok(const EP&, int, int, int, int) { return false; }
+template <class T, int S> inline bool lean_host_ok(const EpiStore<T, S>& ep, int M, int N, int BM, int BN) {
+    if (sizeof(T) != 2 || S == STATS_NONE) return false;
+    static const bool off = getenv("VIRTEX_AMD_LEAN_EPILOGUE") && atoi(getenv("VIRTEX_AMD_LEAN_EPILOGUE")) == 0;      // A/B
+    if (off || ep.map_on || ep.ldc != N || (N & 7) || M % BM != 0 || N % BN != 0) return false;
+    if (S == STATS_FWD) return ep.residual == nullptr;
+    return !ep.bn_y && ep.ldx == N && (!ep.residual || ep.ldr == N) && (!ep.bn_ybits || ep.ldy == N);
+}
 // out(fp32) += alpha * acc     (split-K partial sums and "+=" gradient accumulation)
 struct EpiAtomic {
     struct Ops {};
@@ -1190,7 +1249,7 @@ __device__ __forceinline__ void epi_prefetch(const EP& ep, float (&pre)[EpiShape
 // acc: the wave's MT x NT accumulator tiles (D = Btile x Atile: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]);
 // lds: the block's stage memory (LDS_BYTES), free once every wave has left the K loop; tile_m / tile_n: the tile's place in
 // the grid (statistics strip / column group)
-template <int BM, int BN, int WM, int WN, int LDS_BYTES, class EP>
+template <int BM, int BN, int WM, int WN, int LDS_BYTES, class EP, bool LEAN = false>
 __device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16],
                                               float (&pre)[EpiShape<BN, WM * WN, EP>::PPT][4], bf16_t* lds, int m0, int n0,
                                               int tile_m, int tile_n, int tid, int lane, int wave) {
@@ -1240,6 +1299,51 @@ __device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 1
             }
             __syncthreads();
         }
+        // Interior tiles of the bf16 statistics epilogues (block-uniform test; round 4): no bounds logic, no row map, one
+        // element offset per chunk -- the general loop below spends most of its instructions on those (measured on the
+        // 8-wave kernels of gemm_v3.h, nothing overlapping: 11 500 / 19 800 cycles per 64x64 wave tile forward / backward
+        // against 4 000 for a plain store)
+        constexpr bool lean_done = LEAN;          // the host picked the instantiation (lean_host_ok): no second code path, no
+        static_assert(!LEAN || (SM != STATS_NONE && sizeof(TO) == 2 && (16 * CPR) % 64 == 0), "lean epilogue: bf16 statistics modes");   // run-time test
+        if constexpr (LEAN) {
+            {
+                constexpr int NCHL = 16 * CPR / 64, RSTEP = 64 / CPR;      // chunks per lane and step; rows between them
+                const int ch = lane % CPR, r0 = lane / CPR;
+                const long e0 = (long)(m0 + wm * WTM + r0) * ep.N + (n0 + wn * WTN + ch * EPV);
+                const float* parl = par + wn * WTN + ch * EPV;
+                const char* rd_ptr = strip + r0 * ROWB + ch * 16;
+                const float alpha = ep.alpha;
+                // wave tiles of at most four chunks per lane: the operand chunks of ALL steps are requested up front
+                constexpr bool ALL = VTX_EPI_OPS_ALL && SM == STATS_BWD && MT * NCHL <= 4;
+                typename EP::Ops o[ALL ? MT : 1][NCHL];
+                if constexpr (ALL) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int q = 0; q < NCHL; ++q) o[i][q] = ep.load_ops_at(e0 + (long)(i * 16 + q * RSTEP) * ep.N);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        st4v<TO>(reinterpret_cast<TO*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), acc[i][j] * alpha);
+                    if constexpr (!ALL) {
+                        // the step's accumulators are on their way to the strip (their registers are free) BEFORE the operand
+                        // chunks are requested: the 256x128 kernel lives on 128 VGPRs (two blocks per CU)
+                        vtx_loads_issued();
+#pragma unroll
+                        for (int q = 0; q < NCHL; ++q) o[0][q] = ep.load_ops_at(e0 + (long)(i * 16 + q * RSTEP) * ep.N);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int q = 0; q < NCHL; ++q) {
+                        const uint4 w = *reinterpret_cast<const uint4*>(rd_ptr + q * RSTEP * ROWB);
+                        ep.finish_stats_at(e0 + (long)(i * 16 + q * RSTEP) * ep.N, w, o[ALL ? i : 0][q], parl, BN, s1, s2);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
         float4 bv[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1253,7 +1357,8 @@ __device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 1
         // wave tiles of at most four output chunks per lane (8 waves on 128x128): the operand chunks of ALL steps up front
         constexpr bool OPS_ALL = VTX_EPI_OPS_ALL && SM == STATS_BWD && MT * NCH <= 4;
         typename EP::Ops ops[OPS_ALL ? MT : 1][NCH];
-        if constexpr (OPS_ALL) {
+        if constexpr (OPS_ALL && !lean_done) {
+            {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -1261,7 +1366,9 @@ __device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 1
                     const int c = lane + 64 * q;
                     ops[i][q] = ep.load_ops(c < 16 * CPR ? m0 + wm * WTM + i * 16 + c / CPR : ep.M, n0 + wn * WTN + (c % CPR) * EPV);
                 }
+            }
         }
+        if constexpr (!lean_done) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int mrow = m0 + wm * WTM + i * 16;
@@ -1291,6 +1398,7 @@ __device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 1
                 }
             }
             __builtin_amdgcn_wave_barrier();
+        }
         }
         if constexpr (SM != STATS_NONE) {
             // fold the lanes that drained the same column chunk (they differ in the bits above log2(CPR)) ...
@@ -1326,7 +1434,7 @@ __device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 1
 // Block = WM x WN waves; block tile BM x BN; wave tile (BM/WM) x (BN/WN).  Large tiles matter for the
 // L2 -> LDS bandwidth, not only for LDS: a 128x128 tile needs 2*(128+128)*64 B per 2*128*128*32 flop
 // = 64 flop/B, i.e. 39 TB/s of cache bandwidth at the MFMA peak (L2 delivers ~34); 256x256 needs half.
-template <int BM, int BN, int WM, int WN, class AL, class BL, class EP, int BK = 32, int STAGES = 3>
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EP, int BK = 32, int STAGES = 3, bool LEAN = false>
 // Second launch bound = minimum waves per SIMD the register allocation must leave room for: 8-wave blocks on 128x128
 // tiles are meant to run THREE per CU (six waves per SIMD = 80 VGPRs: the HBM-bound layers live on blocks in flight),
 // 8-wave blocks on 256x128 tiles two (128 VGPRs), 4-wave blocks on 128x128 tiles three (168), on 128x64 / 64x128 four (128).
@@ -1461,7 +1569,7 @@ void contraction_v2_kernel(AL al, BL bl, EP ep, int K, int tiles_n,
             stage = stage + 1 >= STAGES ? 0 : stage + 1;
         }
     }
-    tile_epilogue<BM, BN, WM, WN, STAGES * TILE * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
+    tile_epilogue<BM, BN, WM, WN, STAGES * TILE * 2, EP, LEAN>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
 }
 
 extern int g_vtx_contraction_generation;   // 2 (default): DMA kernel for bf16; 1: register-staged kernel
@@ -1519,10 +1627,16 @@ inline int launch_v2(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
     const int per = vtx_cdiv(nkt, split_k);       // K == 0: no K steps, the epilogue alone runs
     split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
     constexpr size_t lds_bytes = STAGES * (size_t)(BM + BN) * BK * 2;
-    auto kern = contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP, BK, STAGES>;
+    auto kern = contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP, BK, STAGES, false>;
+    if constexpr (EP::STATS && EP::STAGED) {
+        // every tile interior, dense tensors: the instantiation whose statistics epilogue carries no bounds / row-map logic
+        if (lean_host_ok(ep_in, M, N, BM, BN)) kern = contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP, BK, STAGES, true>;
+    }
     static bool attr_set = false;
     if (lds_bytes > 65536 && !attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipFuncSetAttribute((const void*)contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP, BK, STAGES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if constexpr (EP::STATS && EP::STAGED)
+            hipFuncSetAttribute((const void*)contraction_v2_kernel<BM, BN, WM, WN, AL, BL, EP, BK, STAGES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
     dim3 grid(tiles_m * tiles_n, split_k), block(64 * WM * WN);
@@ -1587,17 +1701,28 @@ inline int pick_tile(int M, int N, int splits, bool allow256, bool mc = false) {
 }
 
 // Generation 3 or not: 0 = no, 1 = 256x256 blocks, 2 = 256x128 blocks.  Tile override 20 / 21 forces them (tests, sweeps).
+// Cost model from the per-wave time stamps of profiles/r04_gen3_stamps.txt (shader-clock cycles, one block per CU, so a
+// launch takes ceil(tiles / 256) rounds of  prologue + K tiles x cycles per K tile + epilogue ):
+//                         prologue   per 64-deep K tile            epilogue: plain / statistics / fused BatchNorm backward
+//   256x256               4 400      2 812 (gather loaders 3 700)   6 600 / 11 300 / 24 300
+//   256x128               4 400      1 819 (gather loaders 2 450)   4 000 /  7 100 / 13 400
+// and taken when its predicted rate beats what generation 2 reaches on the class (850 TFLOP/s plain matrices, 950 gathers).
 extern int g_vtx_sw_gen3;
-inline int pick_gen3(int M, int N, int K, int splits) {
+inline int pick_gen3(int M, int N, int K, int splits, bool gather, int smode) {
     if (g_vtx_tile_override == 20) return 1;
     if (g_vtx_tile_override == 21) return 2;
     if (g_vtx_tile_override >= 0 || !g_vtx_sw_gen3) return 0;
-    if (K < 512 || M < 1024 || N < 128 || splits > 1) return 0;
-    // one block per CU: what counts is how many rounds of 256 blocks the grid takes and how full the last one is
+    if (K < 256 || M < 1024 || N < 128 || splits > 1) return 0;
+    const double nkt = (double)vtx_cdiv(K, 64);
+    const double epi256 = smode == STATS_NONE ? 6600.0 : smode == STATS_FWD ? 11300.0 : 24300.0;
+    const double epi128 = smode == STATS_NONE ? 4000.0 : smode == STATS_FWD ? 7100.0 : 13400.0;
     const long t256 = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, 256), t128 = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, 128);
-    auto cost = [](long tiles, double area, double eff) { return (double)((tiles + 255) / 256) * area / eff; };
-    const double c256 = N > 128 ? cost(t256, 256.0 * 256.0, 1.0) : 1e30;
-    const double c128 = cost(t128, 256.0 * 128.0, 0.85);
+    const double c256 = N > 128 ? (double)((t256 + 255) / 256) * (4400.0 + nkt * (gather ? 3700.0 : 2812.0) + epi256) : 1e30;
+    const double c128 = (double)((t128 + 255) / 256) * (4400.0 + nkt * (gather ? 2450.0 : 1819.0) + epi128);
+    const double cyc = c256 <= c128 ? c256 : c128;
+    const double rate = 2.0 * M * N * (double)K / (cyc / 2.1e9);                  // FLOP/s at the ~2.1 GHz the stamps were taken at
+    const double need = (gather ? 950e12 : 850e12) * (g_vtx_sw_gen3 >= 2 ? 0.01 * g_vtx_sw_gen3 : 1.0);   // gen3 = 2..: threshold in percent (sweeps)
+    if (rate < need) return 0;
     return c256 <= c128 ? 1 : 2;
 }
 
@@ -1633,7 +1758,7 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
     int strips = 0;
     if constexpr (BF && !ALT<T, 1>::MC && !BLT<T, 1>::MC) {
         // generation 3 (gemm_v3.h): 8-wave 256x256 / 256x128 blocks with the phase-interleaved K loop
-        const int g3 = v2 ? pick_gen3(M, N, K, split_k) : 0;
+        const int g3 = v2 ? pick_gen3(M, N, K, split_k, !std::is_same<ALT<T, 1>, PlainKC<T, 1>>::value, EP::SMODE) : 0;
         if (g3 && buf_ok(64)) {
             g_vtx_last_generation = 3;
             g_vtx_generation_count[3].fetch_add(1, std::memory_order_relaxed);

@@ -36,6 +36,21 @@
 #define VTX3_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+// measurement builds (-DVTX_ABLATE, tools/ablate_gen3.py): bit 0 no MFMA, bit 1 no fragment reads, bit 2 no DMA inside the loop,
+// bit 6 (64) no K loop at all, bit 7 (128) no epilogue
+#ifdef VTX_ABLATE
+#define V3_ABL(bits) (abl & (bits))
+// time stamps of wave `wave` of block blockIdx.x (shader clock): dbg[(block * 8 + wave) * 4 + slot], slots: 0 kernel entry,
+// 1 first tile landed (K loop starts), 2 K loop done, 3 epilogue done (vtx_set_debug_buffer)
+#define V3_STAMP(slot)                                                                                          \
+    do {                                                                                                        \
+        if (dbg && lane == 0) dbg[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 4 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define V3_ABL(bits) false
+#define V3_STAMP(slot) ((void)0)
+#endif
+
 constexpr int V3_UNIT = 128 * 64;          // elements of a staged unit (128 rows x 64 k, 16 KiB)
 
 // Stages the units of one operand.  WT = rows of the operand one wave's tile spans, QR = rows of one sub-block.
@@ -128,6 +143,91 @@ __device__ __forceinline__ void v3_block_tile(int abl, int& tile, int& slice) {
     __builtin_amdgcn_s_barrier();         \
     VTX3_FENCE();
 
+
+// ------------------------------------------------------------------ the lean epilogue of interior tiles
+// With ONE block per CU nothing overlaps a block's epilogue, and the general tile_epilogue (run-time activation / dropout /
+// pre-activation / row-map dispatch and bounds checks around every 16x16 tile, fully unrolled over the 8 row steps of a
+// 128-row wave tile) measured 37 000 cycles on the 256x256 kernel -- 13 K tiles' worth (profiles/r04_gen3_ablation.txt).
+// Blocks whose tile lies inside the matrix and whose epilogue is {alpha, bias, none / GELU / ReLU, residual, store} -- every
+// text-head GEMM of the step -- take this path instead: ACT is a compile-time constant, no bounds logic, two wave-private
+// strips used alternately (the LDS round trip of step i+1 overlaps the stores of step i), 16-byte stores.  Same arithmetic,
+// same rounding points as EpiStore::transform / finish.
+template <class EP> struct V3Lean { static constexpr bool OK = false; };
+template <class T> struct V3Lean<EpiStore<T, STATS_NONE>> { static constexpr bool OK = true; };
+
+template <int ACT, int WTM, int WTN, class T>
+__device__ __forceinline__ void v3_lean_store(const EpiStore<T, STATS_NONE>& ep, f32x4_t (&acc)[WTM / 16][WTN / 16], bf16_t* lds,
+                                              int mw, int nw, int lane, int wave) {
+    constexpr int MT = WTM / 16, NT = WTN / 16;
+    constexpr int ROWB = WTN * (int)sizeof(T) + 16;            // padded strip row (bytes)
+    constexpr int CPR = WTN * (int)sizeof(T) / 16;             // 16-byte chunks per row
+    constexpr int EPV = 16 / (int)sizeof(T);
+    constexpr int NCH = 16 * CPR / 64;                         // chunks a lane moves per 16-row step
+    static_assert(16 * CPR % 64 == 0, "whole wave-instructions per step");
+    char* const strip0 = reinterpret_cast<char*>(lds) + wave * (2 * 16 * ROWB);
+    float4 bv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bv[j] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + nw + j * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float alpha = ep.alpha;
+    const bool has_res = ep.residual != nullptr;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        char* const strip = strip0 + (i & 1) * (16 * ROWB);
+        uint4 res[NCH];
+        if (has_res) {                                         // requested before the step's trip through the strip
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int c = lane + 64 * q;
+                res[q] = *reinterpret_cast<const uint4*>(ep.residual + (long)(mw + i * 16 + c / CPR) * ep.ldr + nw + (c % CPR) * EPV);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            f32x4_t v = acc[i][j] * alpha;
+            v[0] += bv[j].x; v[1] += bv[j].y; v[2] += bv[j].z; v[3] += bv[j].w;
+            if constexpr (ACT == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if constexpr (ACT == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            st4v<T>(reinterpret_cast<T*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = lane + 64 * q, r = c / CPR, ch = c % CPR;
+            uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
+            if (has_res) w = add16<T>(w, res[q]);
+            T* dst = ep.out + (long)(mw + i * 16 + r) * ep.ldc + nw + ch * EPV + ep.split_off;
+            if (ep.nt) st16_nt(dst, u32x4_t{w.x, w.y, w.z, w.w});
+            else *reinterpret_cast<uint4*>(dst) = w;
+        }
+        // (the other strip is written next: this one is re-written two steps from now, behind the next wave barrier)
+    }
+}
+
+// true when the block took the lean path
+template <int BM, int BN, int WM, int WN, class EP>
+__device__ __forceinline__ bool v3_lean_epilogue(const EP& ep, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16], bf16_t* lds, int m0, int n0,
+                                                 int lane, int wave) {
+    if constexpr (V3Lean<EP>::OK) {
+        const bool lean = m0 + BM <= ep.M && n0 + BN <= ep.N && !ep.preact && ep.drop.thresh == 0u && !ep.map_on &&
+                          (ep.act == ACT_NONE || ep.act == ACT_GELU || ep.act == ACT_RELU) && (ep.N & 3) == 0;
+        if (!lean) return false;
+        constexpr int WTM = BM / WM, WTN = BN / WN;
+        const int mw = m0 + (wave / WN) * WTM, nw = n0 + (wave % WN) * WTN;
+        __syncthreads();                                       // every wave is done with the stage memory
+        if (ep.act == ACT_NONE) v3_lean_store<ACT_NONE, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
+        else if (ep.act == ACT_GELU) v3_lean_store<ACT_GELU, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
+        else v3_lean_store<ACT_RELU, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
+        return true;
+    } else {
+        return false;
+    }
+}
+
 // ------------------------------------------------------------------ 256 x 256: waves 2 (M) x 4 (N), wave tile 128 x 64
 // Units per K tile: A0 A1 (sub-blocks of 64 rows), B0 B1 (sub-blocks of 32 rows); two LDS buffers E / O of four units.
 // K tile t (buffer E, phases 1-4; t+1: buffer O, phases 5-8), per wave:
@@ -137,9 +237,9 @@ __device__ __forceinline__ void v3_block_tile(int abl, int& tile, int& slice) {
 //   1: O.A1 <- t+1   2: E.B0 <- t+2   3: E.A0 <- t+2   4: E.B1 <- t+2   [vmcnt(6): O complete]
 //   5: E.A1 <- t+2   6: O.B0 <- t+3   7: O.A0 <- t+3   8: O.B1 <- t+3   [vmcnt(6): E complete]
 // WAR: E.B0 last read in phase 1 behind lgkmcnt(8) -> phase 2; E.A0 phase 1 -> 3; E.B1 phase 2 -> 4; E.A1 phase 3 -> 5; O alike.
-template <class AL, class BL, class EP>
+template <class AL, class BL, class EP, bool LEAN = false>
 __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
-                                                                        int abl) {
+                                                                        int abl, unsigned long long* dbg) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, MT = 8, NT = 4;
     constexpr int BUF = 4 * V3_UNIT;
     typedef UnitStager<128, 64, AL> SA;
@@ -148,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    V3_STAMP(0);
     int tile, slice;
     v3_block_tile(abl, tile, slice);
     set_slice(ep, slice);
@@ -174,27 +275,35 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
     const int al0 = v3_lane_off(wm * 64, lane, 0), al1 = v3_lane_off(wm * 64, lane, 1);
     const int bl0 = v3_lane_off(wn * 32, lane, 0), bl1 = v3_lane_off(wn * 32, lane, 1);
     bf16x8_t fa[4][2], fb[2][2][2];
+    if (V3_ABL(2)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i][0] = fa[i][1] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[q][j][0] = fb[q][j][1] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
 
 #define V3_READ_A(X, U)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
+    if (!V3_ABL(2)) _Pragma("unroll") for (int i = 0; i < 4; ++i) {                             \
         fa[i][0] = v3_ld((X) + (U) + al0 + i * 1024);                           \
         fa[i][1] = v3_ld((X) + (U) + al1 + i * 1024);                           \
     }
 #define V3_READ_B(X, U, Q)                                                     \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                             \
+    if (!V3_ABL(2)) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                             \
         fb[Q][j][0] = v3_ld((X) + (U) + bl0 + j * 1024);                        \
         fb[Q][j][1] = v3_ld((X) + (U) + bl1 + j * 1024);                        \
     }
 // (a tile past the end of the block's K range was staged as zeros: its MFMAs run and add nothing -- a branch around them
 //  leaves hipcc with fragment reads it believes pending on one path, and it pads every later read with an s_waitcnt)
 #define V3_MMA(UA, UB)                                                                                                \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                     \
+    if (!V3_ABL(1)) _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                     \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
                 acc[(UA) * 4 + i][(UB) * 2 + j] =                                                                     \
                     __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[UB][j][h], fa[i][h], acc[(UA) * 4 + i][(UB) * 2 + j], 0, 0, 0);
 
-    if (kt0 < kt1) {
+    if (kt0 < kt1 && !V3_ABL(64)) {
         // prologue: the whole first tile, three units of the second
         sb.template issue<0>(bl, kt0 * 64, true, E + B0, wave);
         sa.template issue<0>(al, kt0 * 64, true, E + A0, wave);
@@ -209,6 +318,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
         VTX3_WAIT_VM(6);
         __builtin_amdgcn_s_barrier();
         V3_STAGGER(wave >= 4);                                // the second wave group runs one barrier behind
+        V3_STAMP(1);
         for (int kt = kt0; kt < kt1; kt += 2) {
             const bool v1 = kt + 1 < kt1, v2 = kt + 2 < kt1, v3 = kt + 3 < kt1;
             const int k1 = (kt + 1) * 64, k2 = (kt + 2) * 64, k3 = (kt + 3) * 64;
@@ -216,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
             V3_READ_B(E, B0, 0)
             VTX3_FENCE();
             V3_READ_A(E, A0)
-            sa.template issue<1>(al, k1, v1, O + A1, wave);
+            if (!V3_ABL(4)) sa.template issue<1>(al, k1, v1, O + A1, wave);
             VTX3_FENCE();
             VTX3_WAIT_LGKM(8);
             V3_COMPUTE_BEGIN()
@@ -224,18 +334,18 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
             V3_COMPUTE_END()
             // ---- phase 2
             V3_READ_B(E, B1, 1)
-            sb.template issue<0>(bl, k2, v2, E + B0, wave);
+            if (!V3_ABL(4)) sb.template issue<0>(bl, k2, v2, E + B0, wave);
             V3_COMPUTE_BEGIN()
             V3_MMA(0, 1)
             V3_COMPUTE_END()
             // ---- phase 3
             V3_READ_A(E, A1)
-            sa.template issue<0>(al, k2, v2, E + A0, wave);
+            if (!V3_ABL(4)) sa.template issue<0>(al, k2, v2, E + A0, wave);
             V3_COMPUTE_BEGIN()
             V3_MMA(1, 1)
             V3_COMPUTE_END()
             // ---- phase 4
-            sb.template issue<1>(bl, k2, v2, E + B1, wave);
+            if (!V3_ABL(4)) sb.template issue<1>(bl, k2, v2, E + B1, wave);
             VTX3_FENCE();
             VTX3_WAIT_VM(6);
             V3_COMPUTE_BEGIN()
@@ -245,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
             V3_READ_B(O, B0, 0)
             VTX3_FENCE();
             V3_READ_A(O, A0)
-            sa.template issue<1>(al, k2, v2, E + A1, wave);
+            if (!V3_ABL(4)) sa.template issue<1>(al, k2, v2, E + A1, wave);
             VTX3_FENCE();
             VTX3_WAIT_LGKM(8);
             V3_COMPUTE_BEGIN()
@@ -253,18 +363,18 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
             V3_COMPUTE_END()
             // ---- phase 6
             V3_READ_B(O, B1, 1)
-            sb.template issue<0>(bl, k3, v3, O + B0, wave);
+            if (!V3_ABL(4)) sb.template issue<0>(bl, k3, v3, O + B0, wave);
             V3_COMPUTE_BEGIN()
             V3_MMA(0, 1)
             V3_COMPUTE_END()
             // ---- phase 7
             V3_READ_A(O, A1)
-            sa.template issue<0>(al, k3, v3, O + A0, wave);
+            if (!V3_ABL(4)) sa.template issue<0>(al, k3, v3, O + A0, wave);
             V3_COMPUTE_BEGIN()
             V3_MMA(1, 1)
             V3_COMPUTE_END()
             // ---- phase 8
-            sb.template issue<1>(bl, k3, v3, O + B1, wave);
+            if (!V3_ABL(4)) sb.template issue<1>(bl, k3, v3, O + B1, wave);
             VTX3_FENCE();
             VTX3_WAIT_VM(6);
             V3_COMPUTE_BEGIN()
@@ -273,11 +383,15 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
         }
         VTX3_WAIT_VM(0);                                      // the zero-fill units staged past the end
         V3_STAGGER(wave < 4);                                 // the first group catches up
+        V3_STAMP(2);
     }
 #undef V3_READ_A
 #undef V3_READ_B
 #undef V3_MMA
-    tile_epilogue<BM, BN, WM, WN, 2 * BUF * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
+    if (V3_ABL(128)) return;
+    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave))
+        tile_epilogue<BM, BN, WM, WN, 2 * BUF * 2, EP, LEAN>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
+    V3_STAMP(3);
 }
 
 // ------------------------------------------------------------------ 256 x 128: waves 4 (M) x 2 (N), wave tile 64 x 64
@@ -286,9 +400,9 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
 //   phase 1  reads b (8) then a0 (4)    MFMA a0 x b      phase 2  reads a1 (4)    MFMA a1 x b
 // while tile t+2 is staged into buffer (t+2) % 3 = (t-1) % 3 (three wave-instructions per phase: B, A0.0 | A0.1, A1; every
 // unit was last read two phases earlier) and `vmcnt(6)` in phase 2 leaves exactly that tile in flight: tile t+1 is complete.
-template <class AL, class BL, class EP>
+template <class AL, class BL, class EP, bool LEAN = false>
 __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
-                                                                        int abl) {
+                                                                        int abl, unsigned long long* dbg) {
     constexpr int BM = 256, BN = 128, WM = 4, WN = 2, MT = 4, NT = 4;
     constexpr int BUF = 3 * V3_UNIT;
     typedef UnitStager<64, 32, AL> SA;
@@ -297,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    V3_STAMP(0);
     int tile, slice;
     v3_block_tile(abl, tile, slice);
     set_slice(ep, slice);
@@ -321,19 +436,25 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
     const int al0 = v3_lane_off(wm * 32, lane, 0), al1 = v3_lane_off(wm * 32, lane, 1);
     const int bl0 = v3_lane_off(wn * 64, lane, 0), bl1 = v3_lane_off(wn * 64, lane, 1);
     bf16x8_t fa[2][2], fb[4][2];
+    if (V3_ABL(2)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i][0] = fa[i][1] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j][0] = fb[j][1] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    }
 
 #define V3_READ_A(X, U)                                                        \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                             \
+    if (!V3_ABL(2)) _Pragma("unroll") for (int i = 0; i < 2; ++i) {                             \
         fa[i][0] = v3_ld((X) + (U) + al0 + i * 1024);                           \
         fa[i][1] = v3_ld((X) + (U) + al1 + i * 1024);                           \
     }
 #define V3_READ_B(X)                                                           \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                             \
+    if (!V3_ABL(2)) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                             \
         fb[j][0] = v3_ld((X) + B + bl0 + j * 1024);                             \
         fb[j][1] = v3_ld((X) + B + bl1 + j * 1024);                             \
     }
 #define V3_MMA(UA)                                                                                                    \
-    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                     \
+    if (!V3_ABL(1)) _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                     \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                 \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                             \
                 acc[(UA) * 2 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][h], fa[i][h], acc[(UA) * 2 + i][j], 0, 0, 0);
@@ -342,21 +463,21 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
     V3_READ_B(X)                                                               \
     VTX3_FENCE();                                                              \
     V3_READ_A(X, A0)                                                           \
-    sb.template issue<0>(bl, K2, V, (Y) + B, wave);                            \
-    sa.template issue1<0, 0>(al, K2, V, (Y) + A0, wave);                       \
+    if (!V3_ABL(4)) { sb.template issue<0>(bl, K2, V, (Y) + B, wave);          \
+                      sa.template issue1<0, 0>(al, K2, V, (Y) + A0, wave); }   \
     V3_COMPUTE_BEGIN()                                                         \
     V3_MMA(0)                                                                  \
     V3_COMPUTE_END()                                                           \
     V3_READ_A(X, A1)                                                           \
-    sa.template issue1<0, 1>(al, K2, V, (Y) + A0, wave);                       \
-    sa.template issue<1>(al, K2, V, (Y) + A1, wave);                           \
+    if (!V3_ABL(4)) { sa.template issue1<0, 1>(al, K2, V, (Y) + A0, wave);     \
+                      sa.template issue<1>(al, K2, V, (Y) + A1, wave); }       \
     VTX3_FENCE();                                                              \
     VTX3_WAIT_VM(6);                                                           \
     V3_COMPUTE_BEGIN()                                                         \
     V3_MMA(1)                                                                  \
     V3_COMPUTE_END()
 
-    if (kt0 < kt1) {
+    if (kt0 < kt1 && !V3_ABL(64)) {
         bf16_t* const X0 = lds;
         bf16_t* const X1 = lds + BUF;
         bf16_t* const X2 = lds + 2 * BUF;
@@ -372,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
         VTX3_WAIT_VM(6);
         __builtin_amdgcn_s_barrier();
         V3_STAGGER(wave >= 4);
+        V3_STAMP(1);
         for (int kt = kt0; kt < kt1; kt += 3) {
             V3_TILE(X0, X2, (kt + 2) * 64, kt + 2 < kt1)
             V3_TILE(X1, X0, (kt + 3) * 64, kt + 3 < kt1)
@@ -379,15 +501,20 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
         }
         VTX3_WAIT_VM(0);
         V3_STAGGER(wave < 4);
+        V3_STAMP(2);
     }
 #undef V3_READ_A
 #undef V3_READ_B
 #undef V3_MMA
 #undef V3_TILE
-    tile_epilogue<BM, BN, WM, WN, 3 * BUF * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
+    if (V3_ABL(128)) return;
+    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave))
+        tile_epilogue<BM, BN, WM, WN, 3 * BUF * 2, EP, LEAN>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
+    V3_STAMP(3);
 }
 
 // ------------------------------------------------------------------ host side
+extern unsigned long long* g_vtx_dbg;   // measurement builds: time-stamp buffer of the generation-3 kernels (vtx_set_debug_buffer), else null
 extern int g_vtx_sw_gen3;        // vtx_set_switch("gen3"): 0 = generation 3 only when forced by the tile override (20 / 21), 1 = automatic
 
 template <int BN, class AL, class BL, class EP>
@@ -400,13 +527,18 @@ inline int launch_v3(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
     const int per = vtx_cdiv(nkt, split_k);
     split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
     constexpr size_t lds_bytes = BN == 256 ? 2 * 4 * V3_UNIT * 2 : 3 * 3 * V3_UNIT * 2;
-    auto kern = [] {
-        if constexpr (BN == 256) return contraction_v3_256x256_kernel<AL, BL, EP>;
-        else return contraction_v3_256x128_kernel<AL, BL, EP>;
-    }();
+    auto pick = [](auto lean) {
+        if constexpr (BN == 256) return contraction_v3_256x256_kernel<AL, BL, EP, decltype(lean)::value>;
+        else return contraction_v3_256x128_kernel<AL, BL, EP, decltype(lean)::value>;
+    };
+    auto kern = pick(std::false_type{});
+    if constexpr (EP::STATS && EP::STAGED) {
+        if (lean_host_ok(ep_in, M, N, BM, BN)) kern = pick(std::true_type{});
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipFuncSetAttribute((const void*)pick(std::false_type{}), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if constexpr (EP::STATS && EP::STAGED) hipFuncSetAttribute((const void*)pick(std::true_type{}), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
     dim3 grid(tiles_m * tiles_n, split_k), block(512);
@@ -420,10 +552,10 @@ inline int launch_v3(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
         if (prof) {
             hipEvent_t e0, e1;
             vtx_prof_events(cls, 2.0 * M * N * K, 2.0 * (algo_elems(al) + algo_elems(bl)) + epi_bytes(ep, (double)M * N, split_k), &e0, &e1);
-            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds_bytes, st, e0, e1, 0, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
+            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds_bytes, st, e0, e1, 0, al, bl, ep, K, tiles_n, per, g_vtx_ablate, g_vtx_dbg);
             return tiles_m;
         }
     }
-    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate);
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate, g_vtx_dbg);
     return tiles_m;
 }

@@ -213,6 +213,8 @@ class GradientBuckets:
             self.buckets.append((bstart, off, bcount))
         self.pending = [0] * len(self.buckets)
         self.exposed = []            # (event before, event after) the compute stream's wait for the collectives, per step
+        # diagnostic only (bench.py sets it; VIRTEX_AMD_DP_MEASURE_EXPOSED=1): time the compute stream's wait in finish()
+        self.measure_exposed = os.environ.get("VIRTEX_AMD_DP_MEASURE_EXPOSED", "0") == "1"
         self.early = set()           # parameters announced by gradsink.mark_ready() in the current step
         self.last_early = 0
         self.handles = []
@@ -314,13 +316,16 @@ class GradientBuckets:
             # how long the compute stream sits in this wait = the part of the gradient exchange the backward pass did NOT
             # hide; two events per step, read (and synchronised) only by comm_exposed_ms()
             cur = torch.cuda.current_stream()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-            cur.wait_stream(self.side)
-            e1.record(cur)
-            self.exposed.append((e0, e1))
-            if len(self.exposed) > 4096:
-                del self.exposed[:2048]
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_stream(self.side)
+                e1.record(cur)
+                self.exposed.append((e0, e1))
+                if len(self.exposed) > 4096:
+                    del self.exposed[:2048]
+            else:
+                cur.wait_stream(self.side)
         else:
             for h in self.handles:
                 h.wait()

@@ -18,12 +18,33 @@ _side_streams = {}
 _fence_events = {}
 _get_cur = getattr(torch._C, "_cuda_getCurrentStream", None)
 _set_cur = getattr(torch._C, "_cuda_setStream", None)
+_fast_ok = None      # None: the raw setters have not been probed yet; False: this torch build does not take them
+
+
+def _probe_fast_path(device, stream):
+    """The raw setters are private torch API (a 3-tuple from _cuda_getCurrentStream, keyword arguments of _cuda_setStream):
+    verified ONCE with a set / get / restore round trip; any surprise switches the module to torch.cuda.stream() for good."""
+    global _fast_ok
+    try:
+        prev = _get_cur(device.index)
+        assert isinstance(prev, tuple) and len(prev) == 3
+        _set_cur(stream_id=stream.stream_id, device_index=stream.device_index, device_type=stream.device_type)
+        now = _get_cur(device.index)
+        _set_cur(stream_id=prev[0], device_index=prev[1], device_type=prev[2])
+        _fast_ok = tuple(now) == (stream.stream_id, stream.device_index, stream.device_type) and tuple(_get_cur(device.index)) == tuple(prev)
+    except Exception:
+        _fast_ok = False
+    return _fast_ok
 
 
 def _switch_stream(device, stream):
     """Make `stream` torch's current stream on `device`; returns what _restore_stream needs.  (Same effect as entering
     torch.cuda.stream(stream), without building Stream objects and device guards around it.)"""
-    if _get_cur is not None and _set_cur is not None and device.index is not None and device.index == torch.cuda.current_device():
+    fast = _fast_ok
+    if fast is None and _get_cur is not None and _set_cur is not None and device.index is not None \
+            and device.index == torch.cuda.current_device():
+        fast = _probe_fast_path(device, stream)
+    if fast and device.index is not None and device.index == torch.cuda.current_device():
         prev = _get_cur(device.index)                    # (stream_id, device_index, device_type)
         _set_cur(stream_id=stream.stream_id, device_index=stream.device_index, device_type=stream.device_type)
         return prev
