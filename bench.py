@@ -75,32 +75,28 @@ def device_batch(B, dev, seed, image_size=224, vocab_size=10000):
 
 
 PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355X_MICROARCH.md)
-# HBM bytes per launch of the dominant kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes
-# (FETCH_SIZE, WRITE_SIZE; units/corrections per the guide) of this same command: profiles/r03_pmc_traffic.txt.
-# The dominant kernel is found by NAME (one class per contraction instantiation, one per launch family for the other
-# kernels), then ALL launches of that class are timed alone for three further steps: the traffic listed here is the average
-# over the same launches (the n of the profile = 3 steps x launches per step).  Candidates for the top of the step are
-# within a few percent of each other, so the likely ones are all listed; `traffic` is reported for whichever the live
-# measurement finds dominant, and a WARNING goes to stderr when that class has no entry.
-TRAFFIC_SOURCE = "profiles/r03_pmc_traffic.txt (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, build at the end of round 3: tools/r03_s17.sh, tools/pmc_traffic.py)"
-TRAFFIC_PER_LAUNCH = {   # kernel name -> HBM bytes per launch (FETCH_SIZE doubled per the gfx950 rule + WRITE_SIZE), averaged over the class's launches
-    # 28 launches/step (1x1 input gradients with the fused BatchNorm backward, all stages): (2 x 156.4e3 + 112.4e3) KiB
-    # = 1.035 x the class's algorithmic bytes (420.7 MB)
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>": 435.4e6,
-    # the launch family "bn_bwd_apply" = 53 launches/step over four kernels (fused<2>: 47 x 228.9 MB, fused<4>: 4 x 1233.5 MB,
-    # the stem's pool_bn_bwd_apply 1138.9 MB, ...): average over all of them; reads x and dz, writes dx -> FETCH : WRITE = 2 : 1
-    "bn_bwd_apply": 322.4e6,
-    # "bn_fwd_apply" = 53 launches/step (bn_apply<2>: 48 x 186.9 MB, <4>: 4 x 1150.3 MB, the stem's fused tail 775.5 MB)
-    "bn_fwd_apply": 270.7e6,
-    # 35 launches/step (1x1 / text weight gradients): (2 x 63.6e3 + 32.8e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainMC<bf16, 2>, PlainMC<bf16, 1>, EpiStore<float, 0>, 32, 3>": 163.9e6,
-    # 22 launches/step (1x1 forward convolutions with statistics): (2 x 55.1e3 + 64.9e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 1>, 32, 3>": 179.2e6,
-    # 16 launches/step (3x3 forward convolutions with statistics): (2 x 49.0e3 + 47.0e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, ConvFwdA<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 1>, 32, 3>": 148.4e6,
-    # 14 launches/step (text GEMMs, late 1x1 convolutions): (2 x 114.0e3 + 71.1e3) KiB
-    "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 0>, 32, 3>": 306.3e6,
-}
+# HBM bytes per launch of every kernel class in the DEFAULT workload, from separate rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
+# units / corrections per the guide) of this same command -- profiles/traffic_table.json, written by tools/pmc_traffic.py --json
+# (tools/round_end.sh) together with the sha256 of the kernel sources it was measured on.  A table measured on OTHER sources
+# is not reported: roofline.traffic = null and an error on stderr (round 3 kept the numbers in this file, where a kernel change
+# invalidated them silently).
+TRAFFIC_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_table.json")
+
+
+def load_traffic_table():
+    """(per-launch bytes by class name, source string) or ({}, None) when the table is missing or stale."""
+    try:
+        with open(TRAFFIC_TABLE) as fh:
+            t = json.load(fh)
+    except (OSError, ValueError):
+        print(f"bench.py: ERROR -- {TRAFFIC_TABLE} missing or unreadable: roofline.traffic = null (regenerate with tools/round_end.sh)", file=sys.stderr)
+        return {}, None
+    from virtex_amd.build import csrc_hash
+    if t.get("csrc_sha256") != csrc_hash():
+        print("bench.py: ERROR -- profiles/traffic_table.json was measured on different kernel sources (sha256 mismatch): "
+              "roofline.traffic = null until tools/round_end.sh regenerates it", file=sys.stderr)
+        return {}, None
+    return t.get("per_launch_bytes", {}), f"profiles/traffic_table.json ({t.get('source')}; {t.get('rule')})"
 
 
 def _kernel_name(bracket):
@@ -125,9 +121,12 @@ def _kernel_name(bracket):
     # the kernel's own template parameter order (launch_v2 lists BK/STAGES earlier); __PRETTY_FUNCTION__ drops
     # defaulted template arguments, rocprofv3 prints them
     order = ["BM", "BN", "WM", "WN", "AL", "BL", "EP", "BK", "STAGES"]
+    gen3 = "BM" not in kv                           # launch_v3<BN, AL, BL, EP>: the generation-3 kernels are named by their tile
+    if gen3:
+        order = ["AL", "BL", "EP"]
     name = ", ".join(kv[k] for k in order if k in kv).replace("vtxg::", "").replace("unsigned short", "bf16")
     name = name.replace("EpiStore<bf16>", "EpiStore<bf16, 0>").replace("EpiStore<float>", "EpiStore<float, 0>")
-    return f"contraction_v2_kernel<{name}>"
+    return f"contraction_v3_256x{kv.get('BN', '?')}_kernel<{name}>" if gen3 else f"contraction_v2_kernel<{name}>"
 
 
 FAMILY_OF = {   # HBM-bound kernel -> family reported under roofline.families
@@ -176,15 +175,16 @@ def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1):
     tbs = dom["bytes"] / dom["seconds"] / 1e12
     f_mfma, f_hbm = tf / peak_tf, tbs / PEAK_HBM_TBS
     bound = "mfma" if f_mfma >= f_hbm else "hbm"
-    traffic = TRAFFIC_PER_LAUNCH.get(dom["name"]) if default_workload else None
-    if default_workload and traffic is None:
-        print(f"bench.py: WARNING -- no PMC traffic entry for the dominant kernel {dom['name']!r}: re-run the FETCH_SIZE / "
-              "WRITE_SIZE passes (tools/round_end.sh) and add it to TRAFFIC_PER_LAUNCH; reporting traffic = null", file=sys.stderr)
+    table, table_source = load_traffic_table() if default_workload else ({}, None)
+    traffic = table.get(dom["name"])
+    if default_workload and table_source and traffic is None:
+        print(f"bench.py: ERROR -- profiles/traffic_table.json has no entry for the dominant kernel {dom['name']!r}; "
+              "reporting traffic = null", file=sys.stderr)
     out = {"bound": bound, "kernel": dom["name"],
            "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": peak_tf if bound == "mfma" else PEAK_HBM_TBS * 1e3,
            "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(max(f_mfma, f_hbm), 4),
            "traffic": traffic, "traffic_unit": "bytes/launch",
-           "traffic_source": (TRAFFIC_SOURCE if traffic is not None else None),
+           "traffic_source": (table_source if traffic is not None else None),
            "launches": dom["launches"], "avg_launch_us": round(dom["seconds"] / dom["launches"] * 1e6, 1),
            "flops_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes": dom["bytes"] / dom["launches"],
            "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4), "share_of_kernel_time": round(share, 3)}

@@ -67,3 +67,30 @@ def test_single_rank_flow_through_the_data_parallel_engine():
     assert r.returncode == 0, r.stderr[-3000:]
     rec = _json_line(r.stdout)
     assert rec["n_gpus"] == 1 and rec["value"] > 0 and "error" not in rec["fidelity"]
+
+
+def test_traffic_table_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch, capsys):
+    """roofline.traffic comes from profiles/traffic_table.json only while the sha256 of the kernel sources it was measured on
+    matches the tree (virtex_amd.build.csrc_hash); a stale or missing table yields no number and an error on stderr."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from virtex_amd.build import csrc_hash
+    p = tmp_path / "traffic_table.json"
+    monkeypatch.setattr(bench, "TRAFFIC_TABLE", str(p))
+    table, src = bench.load_traffic_table()
+    assert table == {} and src is None and "missing" in capsys.readouterr().err
+    p.write_text(json.dumps({"csrc_sha256": "0" * 64, "per_launch_bytes": {"k": 1.0}, "source": "s", "rule": "r"}))
+    table, src = bench.load_traffic_table()
+    assert table == {} and src is None and "different kernel sources" in capsys.readouterr().err
+    p.write_text(json.dumps({"csrc_sha256": csrc_hash(), "per_launch_bytes": {"k": 1.0}, "source": "s", "rule": "r"}))
+    table, src = bench.load_traffic_table()
+    assert table == {"k": 1.0} and "traffic_table.json" in src
+    # the class names bench.py derives from the library's profile classes: generation 2 by tile, generation 3 by kernel
+    assert bench._kernel_name("[BM = 256, BN = 128, WM = 4, WN = 2, BK = 32, STAGES = 3, AL = vtxg::PlainKC<unsigned short, 2>, "
+                              "BL = vtxg::PlainKC<unsigned short, 1>, EP = vtxg::EpiStore<unsigned short, 2>]") == \
+        "contraction_v2_kernel<256, 128, 4, 2, PlainKC<bf16, 2>, PlainKC<bf16, 1>, EpiStore<bf16, 2>, 32, 3>"
+    assert bench._kernel_name("[BN = 256, AL = vtxg::PlainKC<unsigned short, 4>, BL = vtxg::PlainKC<unsigned short, 4>, "
+                              "EP = vtxg::EpiStore<unsigned short>]") == \
+        "contraction_v3_256x256_kernel<PlainKC<bf16, 4>, PlainKC<bf16, 4>, EpiStore<bf16, 0>>"

@@ -14,10 +14,10 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ks -- python $R/bench.py 
 cd $R
 python tools/rocpd_stats.py $(find gpurun_out/prof_kt -name "*.db" | head -1) 60 > gpurun_out/kernel_stats.txt
 python tools/rocpd_stats.py $(find gpurun_out/prof_ks -name "*.db" | head -1) 60 > gpurun_out/kernel_stats_serial.txt
-[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) contraction > gpurun_out/pmc_fetch.txt 2>&1
-[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) contraction > gpurun_out/pmc_write.txt 2>&1
-[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) bn_ > gpurun_out/pmc_fetch_bn.txt 2>&1
-[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) bn_ > gpurun_out/pmc_write_bn.txt 2>&1
+[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) "" > gpurun_out/pmc_fetch.txt 2>&1
+[ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) "" > gpurun_out/pmc_write.txt 2>&1
+# the table bench.py's roofline.traffic reads, stamped with the hash of the kernel sources (copy both into profiles/)
+[ -n "$SKIP_PMC" ] || python tools/pmc_traffic.py gpurun_out/pmc_fetch.txt gpurun_out/pmc_write.txt --json gpurun_out/traffic_table.json > gpurun_out/pmc_traffic.txt 2>&1
 find gpurun_out -name "*.db" -delete
 grep -h '^{' gpurun_out/prof_ks.log | tail -1 > gpurun_out/bench_serial.json
 cat gpurun_out/gpu_tests.txt

@@ -29,6 +29,20 @@ EMU_FLAGS = ["-x", "c++", "-O2", "-g", "-std=c++17", "-fPIC", "-pthread", "-DHIP
              "-Wno-pass-failed", "-ffp-contract=off"]
 
 
+def csrc_hash() -> str:
+    """sha256 over every kernel source and header (name + content, sorted): what a measured PMC traffic table is valid for
+    (profiles/traffic_table.json, bench.py's roofline.traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(ROOT, "include", "virtex_amd.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
