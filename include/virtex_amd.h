@@ -353,6 +353,16 @@ int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float* slow, cons
                            const int* chunk_len, const int* chunk_seg, int nchunks, const float* seg_lr,
                            const float* seg_wd, float lr_mult, float momentum, float grad_scale,
                            const float* sumsq, float max_norm, int do_lookahead, float alpha, void* stream);
+/* The same step with the two per-step scalars in DEVICE memory -- sched[0] = LR multiplier (reference:
+ * virtex/optim/lr_scheduler.py:174-183 evaluated on the device), sched[1] = 1.0f when the step ends with the Lookahead
+ * synchronisation (virtex/optim/lookahead.py:93-102), else 0.0f: a captured hipGraph of the training step freezes by-value
+ * arguments.  vtx_set_dropout_epoch registers a device word that every dropout-carrying kernel mixes into its seed for
+ * the same reason (NULL switches it off). */
+int vtx_sgd_lookahead_step_dev(float* p, const float* g, float* m, float* slow, const long long* chunk_off,
+                               const int* chunk_len, const int* chunk_seg, int nchunks, const float* seg_lr,
+                               const float* seg_wd, const float* sched /*[2], device*/, float momentum, float grad_scale,
+                               const float* sumsq, float max_norm, float alpha, void* stream);
+int vtx_set_dropout_epoch(const void* dev_u32);
 
 #ifdef __cplusplus
 }

@@ -202,3 +202,75 @@ def test_state_dict_is_in_named_parameter_order(backend):
     bad2 = {**sf, "param_groups": sf["param_groups"][:-1]}
     with pytest.raises(ValueError):
         fused_g.load_state_dict(bad2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_device_side_schedule_equals_host_side_schedule(backend):
+    """What a replayed hipGraph of the step runs (virtex_amd/graph.py): step counter, LR multiplier (warm-up, then cos^2) and the
+    Lookahead phase live in device memory and reach the optimizer kernel through a pointer (vtx_sgd_lookahead_step_dev).
+    Twelve steps across the end of the warm-up and two Lookahead syncs must equal the by-value path; the host mirrors
+    (step index, Lookahead counter) are recovered by sync_host(), and a state dict taken afterwards resumes either path."""
+    dev = select(backend)
+    torch.manual_seed(0)
+    base = _Toy()
+    base.visual.cnn[0].weight.data = base.visual.cnn[0].weight.data.contiguous(memory_format=torch.channels_last)
+    ma, mb = copy.deepcopy(base).to(dev), copy.deepcopy(base).to(dev)
+    ba, bb = vd.GradientBuckets(ma, bucket_mb=0.01), vd.GradientBuckets(mb, bucket_mb=0.01)
+    oa = FusedPretrainOptimizer(ma, ba, total_steps=50, warmup_steps=10, start_step=3)
+    ob = FusedPretrainOptimizer(mb, bb, total_steps=50, warmup_steps=10, start_step=3)
+    ob.enable_device_schedule()
+    try:
+        _steps(ma, oa, ba, dev, range(12))
+        _steps(mb, ob, bb, dev, range(12))
+        for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.allclose(p.detach().cpu(), q.detach().cpu(), rtol=1e-6, atol=1e-7), n
+        ob.sync_host()
+        assert ob.step_idx == oa.step_idx == 15 and ob.kc == oa.kc
+        assert int(ob.dev["epoch"].item()) == 12                  # the dropout epoch advanced once per step
+        sd = ob.state_dict()
+        assert sd["virtex_amd"] == oa.state_dict()["virtex_amd"]
+    finally:
+        ob.disable_device_schedule()
+    assert ob.dev is None
+    _steps(ma, oa, ba, dev, range(12, 15))
+    _steps(mb, ob, bb, dev, range(12, 15))                        # back on the by-value path, same trajectory
+    for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert torch.allclose(p.detach().cpu(), q.detach().cpu(), rtol=1e-6, atol=1e-7), n
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_dropout_epoch_changes_the_masks_on_the_device(backend):
+    """vtx_set_dropout_epoch: the kernels mix a device word into their (by-value) seed at entry, so that launches with
+    identical arguments -- a replayed graph -- draw different masks once the word has changed, and identical ones while it
+    has not (forward and backward of one step)."""
+    from virtex_amd import ops
+    dev = select(backend)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 256, generator=g).to(dev); y = torch.randn(64, 256, generator=g).to(dev)
+    gamma, beta = torch.ones(256, device=dev), torch.zeros(256, device=dev)
+    epoch = torch.zeros(1, dtype=torch.int32, device=dev)
+    plain = ops.layernorm_residual_fwd(x, y, gamma, beta, 1e-5, 0.5, 1234)[0].clone()
+    try:
+        ops.set_dropout_epoch(epoch)
+        a = ops.layernorm_residual_fwd(x, y, gamma, beta, 1e-5, 0.5, 1234)[0].clone()
+        b = ops.layernorm_residual_fwd(x, y, gamma, beta, 1e-5, 0.5, 1234)[0].clone()
+        epoch.add_(1)
+        c = ops.layernorm_residual_fwd(x, y, gamma, beta, 1e-5, 0.5, 1234)[0].clone()
+    finally:
+        ops.set_dropout_epoch(None)
+    assert torch.equal(a, b) and torch.equal(a, plain)            # epoch 0 adds nothing to the seed
+    assert not torch.equal(a, c)
+    # the backward of the same step re-derives the same mask: dy is dz where the mask kept the element, 0 elsewhere
+    epoch.fill_(7)
+    try:
+        ops.set_dropout_epoch(epoch)
+        out, mean, rstd = ops.layernorm_residual_fwd(x, y, gamma, beta, 1e-5, 0.5, 99)
+        dg, db = torch.zeros(256, device=dev), torch.zeros(256, device=dev)
+        dout = torch.randn(64, 256, generator=g).to(dev)
+        dz, dy = ops.layernorm_residual_bwd(x, y, gamma, mean, rstd, dout, dg, db, 0.5, 99)
+    finally:
+        ops.set_dropout_epoch(None)
+    kept_bwd = dy != 0
+    frac = kept_bwd.float().mean().item()
+    assert 0.4 < frac < 0.6
+    assert torch.allclose(dy[kept_bwd], 2.0 * dz[kept_bwd], rtol=1e-5, atol=1e-6)

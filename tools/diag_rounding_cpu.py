@@ -5,6 +5,9 @@
      (straight-through: the backward is exact fp32 arithmetic on the perturbed activations)
   C  fp32 oracle, forward exact, every activation GRADIENT leaving a backbone conv / BN rounded to bf16
   D  like B but rounded to fp16 (11-bit significand: the reference's own AMP dtype)
+  E  like B, but every ReLU takes its MASK from the exact fp32 forward of the same batch (round 4: what "fp32-exact ReLU
+     masks" could buy at best -- an upper bound: in training mode the mask depends on the batch statistics, which no
+     convolution epilogue knows, so a kernel could only approximate it)
 
 each against the plain fp32 oracle on the same batch: per-tensor relative L2 and cosine of the 159 backbone
 gradients.  B ~ A and C << B  =>  the deviation is the forward's 16-bit activations flipping ReLU masks
@@ -55,6 +58,33 @@ def hook_backbone(model, fwd_dtype=None, bwd_dtype=None):
                 return out
             hs.append(m.register_forward_hook(h))
     return hs
+
+
+def record_relu_masks(model, batch):
+    """masks (output > 0) of every ReLU call of the backbone, in call order, from a plain forward"""
+    masks, hs = [], []
+    for m in model.visual.cnn.modules():
+        if isinstance(m, nn.ReLU):
+            hs.append(m.register_forward_hook(lambda mod, inp, out: masks.append((out > 0).clone())))
+    model.train()
+    with torch.no_grad():
+        model(batch)
+    for h in hs:
+        h.remove()
+    return masks
+
+
+def hook_relu_masks(model, masks):
+    """every ReLU call of the backbone returns input * recorded mask (exact gradient of that: the mask)"""
+    state = {"k": 0}
+    for m in model.visual.cnn.modules():
+        if isinstance(m, nn.ReLU):
+            m.inplace = False
+            def h(mod, inp, out):
+                k = state["k"]; state["k"] += 1
+                return inp[0] * masks[k].to(inp[0].dtype)
+            m.register_forward_hook(h)
+    return state
 
 
 def grads_of(model, batch, autocast=None):
@@ -109,6 +139,14 @@ def main():
         hook_backbone(m, fd, bd)
         l, g = grads_of(m, batch)
         compare(tag, ref, g, lref, l)
+    # E: bf16 forward activations, ReLU masks of the exact forward.  (BatchNorm in train mode leaves the running statistics
+    # of a deep copy changed by the recording pass: irrelevant for the gradients, which use batch statistics.)
+    masks = record_relu_masks(copy.deepcopy(om), batch)
+    m = copy.deepcopy(om)
+    hook_backbone(m, torch.bfloat16, None)
+    hook_relu_masks(m, masks)
+    l, g = grads_of(m, batch)
+    compare("E = B with fp32-exact ReLU masks", ref, g, lref, l)
 
 
 if __name__ == "__main__":

@@ -96,6 +96,7 @@ __device__ __forceinline__ void scores_softmax(const float* sQ, const float* sK,
 
 template <class T>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a, T* __restrict__ o) {
+    a.drop = a.drop.resolved();
     __shared__ float sQ[TMAX * D], sK[SMAX * KP], sV[SMAX * KP], sP[TMAX * SMAX];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -122,6 +123,7 @@ template <class T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, const T* __restrict__ dout, T* __restrict__ dq,
                                                        T* __restrict__ dk, T* __restrict__ dv, long lddq,
                                                        long lddk, long lddv) {
+    a.drop = a.drop.resolved();
     __shared__ float sQ[TMAX * D], sO[TMAX * D], sK[SMAX * KP], sV[SMAX * KP], sP[TMAX * SMAX], sG[TMAX * SMAX];
     const int tid = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -340,6 +342,7 @@ __device__ __forceinline__ void store_rows(bf16_t* dst, long ld, int nrows, int 
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a, bf16_t* __restrict__ o, int nbh) {
+    a.drop = a.drop.resolved();
     __shared__ __attribute__((aligned(16))) bf16_t sV[4][SP * VROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.x * 4 + wave;
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a, const bf
                                                             bf16_t* __restrict__ dq, bf16_t* __restrict__ dk,
                                                             bf16_t* __restrict__ dv, long lddq, long lddk, long lddv,
                                                             int nbh) {
+    a.drop = a.drop.resolved();
     __shared__ __attribute__((aligned(16))) bf16_t sK[2][SP * VROW], sQ[2][TMAX * VROW], sO[2][TMAX * VROW], sC[2][TMAX * VROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bh = blockIdx.x * 2 + wave;

@@ -45,6 +45,9 @@ extern "C" int vtx_set_contraction_generation(int gen) {
     vtxg::g_vtx_contraction_generation = gen;
     return VTX_OK;
 }
+const uint32_t* g_vtx_dropout_epoch = nullptr;
+// Device word mixed into every dropout seed by the kernels themselves (Dropout::resolved): lets a replayed hipGraph of the step draw fresh masks.  nullptr = off.
+extern "C" int vtx_set_dropout_epoch(const void* dev_u32) { g_vtx_dropout_epoch = (const uint32_t*)dev_u32; return VTX_OK; }
 namespace vtxg { unsigned long long* g_vtx_dbg = nullptr; }
 extern "C" int vtx_set_debug_buffer(void* p) { vtxg::g_vtx_dbg = (unsigned long long*)p; return VTX_OK; }   // measurement builds (-DVTX_ABLATE) only
 extern "C" int vtx_set_ablation(int bits) { vtxg::g_vtx_ablate = bits; return VTX_OK; }

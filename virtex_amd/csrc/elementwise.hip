@@ -78,6 +78,7 @@ template <class T>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ da,
                                                        T* __restrict__ dh, long nvec, Dropout drop) {
     constexpr int VEC = Elem<T>::VEC;
+    drop = drop.resolved();
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         Vec16<T> x, g; x.load(h + i * VEC); g.load(da + i * VEC);
 #pragma unroll

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ out,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int rows, int Tlen, int H, int V,
     int padding_idx, float eps, Dropout drop) {
+    drop = drop.resolved();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const T* __restrict__ dout, float* __restrict__ dwords, float* __restrict__ dpos,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int Tlen, int H, int V, int padding_idx,
     Dropout drop) {
+    drop = drop.resolved();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int t = blockIdx.x;
     const float* prow = pos + (size_t)t * H;

@@ -882,9 +882,12 @@ struct EpiRowLse {
     __device__ __forceinline__ void operator()(int, int, f32x4_t) const {}
 };
 
-// the K slice a block works on (split-K): only the storing epilogue cares
+// the K slice a block works on (split-K): only the storing epilogue cares (and resolves its dropout epoch, vtx_common.h)
 template <class EP> __device__ __forceinline__ void set_slice(EP&, int) {}
-template <class T, int S> __device__ __forceinline__ void set_slice(EpiStore<T, S>& ep, int slice) { ep.split_off = (long)slice * ep.split_stride; }
+template <class T, int S> __device__ __forceinline__ void set_slice(EpiStore<T, S>& ep, int slice) {
+    ep.split_off = (long)slice * ep.split_stride;
+    ep.drop = ep.drop.resolved();
+}
 
 // mw / nw: first row / column of the wave tile; group: index of this column range (tile_n * waves-per-row + wn)
 template <int MT, int NT, class EP>

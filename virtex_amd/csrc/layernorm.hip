@@ -18,6 +18,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean_out,
     float* __restrict__ rstd_out, int rows, int H, float eps, Dropout drop) {
     constexpr int VEC = Elem<T>::VEC;
+    drop = drop.resolved();
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;  // whole wave exits together (row is wave-uniform)
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const T* __restrict__ dout, T* __restrict__ dz, T* __restrict__ dy,
     float* __restrict__ partials, int rows, int H, Dropout drop) {
     constexpr int VEC = Elem<T>::VEC;
+    drop = drop.resolved();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float ag[NV][VEC], ab[NV][VEC];
 #pragma unroll

@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void sgd_lookahead_kernel(
     float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ slow,
     const long long* __restrict__ chunk_off, const int* __restrict__ chunk_len, const int* __restrict__ chunk_seg,
     const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, float lr_mult, float momentum,
-    float grad_scale, const float* __restrict__ sumsq, float max_norm, int do_lookahead, float alpha) {
+    float grad_scale, const float* __restrict__ sumsq, float max_norm, int do_lookahead, float alpha,
+    const float* __restrict__ sched) {
+    // sched (optional, device memory): {LR multiplier, Lookahead-sync flag} of THIS step, computed on the device -- a
+    // captured hipGraph of the step freezes the by-value arguments (vtx_sgd_lookahead_step_dev)
+    if (sched) { lr_mult = sched[0]; do_lookahead = sched[1] != 0.f; }
     const int c = blockIdx.x;
     const long off = chunk_off[c];
     const int len = chunk_len[c], seg = chunk_seg[c];
@@ -87,18 +91,40 @@ extern "C" int vtx_sumsq(const float* x, long n, float* partials, float* out, vo
     return VTX_OK;
 }
 
-extern "C" int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float* slow,
-                                      const long long* chunk_off, const int* chunk_len, const int* chunk_seg,
-                                      int nchunks, const float* seg_lr, const float* seg_wd, float lr_mult,
-                                      float momentum, float grad_scale, const float* sumsq, float max_norm,
-                                      int do_lookahead, float alpha, void* stream) {
+static int sgd_lookahead_launch(float* p, const float* g, float* m, float* slow,
+                               const long long* chunk_off, const int* chunk_len, const int* chunk_seg,
+                               int nchunks, const float* seg_lr, const float* seg_wd, float lr_mult,
+                               float momentum, float grad_scale, const float* sumsq, float max_norm,
+                               int do_lookahead, float alpha, const float* sched, void* stream) {
     VTX_CHECK(p && g && m && slow && chunk_off && chunk_len && chunk_seg && seg_lr && seg_wd, VTX_ERR_ARG,
               "sgd_lookahead_step: null pointer");
     VTX_CHECK(max_norm <= 0.f || sumsq, VTX_ERR_ARG, "sgd_lookahead_step: clipping needs the sum of squares");
     if (nchunks <= 0) return VTX_OK;
     VTX_KLAUNCH("optimizer_step", 0, 4.0 * CHUNK * (double)nchunks * (do_lookahead ? 7 : 5), sgd_lookahead_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, slow, chunk_off,
                        chunk_len, chunk_seg, seg_lr, seg_wd, lr_mult, momentum, grad_scale, sumsq, max_norm,
-                       do_lookahead, alpha);
+                       do_lookahead, alpha, sched);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
+}
+
+extern "C" int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float* slow,
+                                      const long long* chunk_off, const int* chunk_len, const int* chunk_seg,
+                                      int nchunks, const float* seg_lr, const float* seg_wd, float lr_mult,
+                                      float momentum, float grad_scale, const float* sumsq, float max_norm,
+                                      int do_lookahead, float alpha, void* stream) {
+    return sgd_lookahead_launch(p, g, m, slow, chunk_off, chunk_len, chunk_seg, nchunks, seg_lr, seg_wd, lr_mult, momentum, grad_scale,
+                                sumsq, max_norm, do_lookahead, alpha, nullptr, stream);
+}
+
+// The same step with the two per-step scalars read from DEVICE memory: sched[0] = LR multiplier, sched[1] = 1.0f when this
+// step ends with the Lookahead synchronisation (every k-th), else 0.0f -- what a captured hipGraph of the training step
+// needs (virtex_amd/graph.py keeps the step counter, the schedule and this pair on the device).
+extern "C" int vtx_sgd_lookahead_step_dev(float* p, const float* g, float* m, float* slow,
+                                          const long long* chunk_off, const int* chunk_len, const int* chunk_seg,
+                                          int nchunks, const float* seg_lr, const float* seg_wd, const float* sched,
+                                          float momentum, float grad_scale, const float* sumsq, float max_norm,
+                                          float alpha, void* stream) {
+    VTX_CHECK(sched, VTX_ERR_ARG, "sgd_lookahead_step_dev: null schedule pointer");
+    return sgd_lookahead_launch(p, g, m, slow, chunk_off, chunk_len, chunk_seg, nchunks, seg_lr, seg_wd, 0.f, momentum, grad_scale,
+                                sumsq, max_norm, 1, alpha, sched, stream);
 }

@@ -274,17 +274,30 @@ __device__ __forceinline__ uint32_t vtx_hash32(uint32_t seed, uint32_t idx_lo, u
     x ^= x >> 12;
     return x;
 }
+// `epoch` (optional, device memory; vtx_set_dropout_epoch): a step counter mixed into the seed ON THE DEVICE, so that a
+// captured hipGraph of the training step -- whose by-value seeds are frozen at capture time -- still draws new masks
+// every replay (the forward and backward launches of one step read the same value; the optimizer step increments it).
+// A kernel resolves it once at entry (`drop = drop.resolved()`), never per element.
 struct Dropout {
     uint32_t seed;
     uint32_t thresh;  // keep iff hash >= thresh ; thresh = p * 2^32
     float scale;      // 1/(1-p)
+    const uint32_t* epoch;
     __device__ __forceinline__ float apply(float v, uint64_t idx) const {
         if (thresh == 0u) return v;
         return vtx_hash32(seed, (uint32_t)idx, (uint32_t)(idx >> 32)) >= thresh ? v * scale : 0.f;
     }
+    __device__ __forceinline__ Dropout resolved() const {
+        Dropout d = *this;
+        if (thresh != 0u && epoch) d.seed = seed + *epoch * 0x9E3779B1u;
+        d.epoch = nullptr;
+        return d;
+    }
 };
+extern const uint32_t* g_vtx_dropout_epoch;      // core.hip
 static inline Dropout make_dropout(float p, uint64_t seed) {
     Dropout d;
+    d.epoch = g_vtx_dropout_epoch;
     d.seed = (uint32_t)(seed * 0x9E3779B97F4A7C15ull >> 32) ^ (uint32_t)seed;
     if (p <= 0.f) { d.thresh = 0u; d.scale = 1.f; }
     else {

@@ -750,6 +750,20 @@ def sgd_lookahead_step(p, g, m, slow, chunk_off, chunk_len, chunk_seg, seg_lr, s
          c_int(1 if do_lookahead else 0), c_float(alpha), stream_ptr(p))
 
 
+def sgd_lookahead_step_dev(p, g, m, slow, chunk_off, chunk_len, chunk_seg, seg_lr, seg_wd, sched, momentum, grad_scale,
+                           sumsq_buf, max_norm, alpha):
+    """sched: fp32[2] on the device = {LR multiplier, Lookahead-sync flag} of this step (graph-capturable form)"""
+    _chk(sched, "sched", torch.float32)
+    call("vtx_sgd_lookahead_step_dev", ptr(p), ptr(g), ptr(m), ptr(slow), ptr(chunk_off), ptr(chunk_len),
+         ptr(chunk_seg), c_int(chunk_off.numel()), ptr(seg_lr), ptr(seg_wd), ptr(sched), c_float(momentum),
+         c_float(grad_scale), ptr(sumsq_buf), c_float(max_norm if max_norm else 0.0), c_float(alpha), stream_ptr(p))
+
+
+def set_dropout_epoch(t):
+    """t: int32[1] device tensor (or None) mixed into every dropout seed on the device; the caller increments it per step"""
+    call("vtx_set_dropout_epoch", ptr(t))
+
+
 # ---------------------------------------------------------------------------------------
 # per-launch timing of the contraction kernels (bench.py's roofline leg)
 def profile_start(only_class=-1):

@@ -185,6 +185,7 @@ class FusedPretrainOptimizer:
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.momentum, self.clip_norm, self.k, self.alpha = momentum, clip_norm, lookahead_k, lookahead_alpha
         self.kc, self.step_idx = 0, start_step
+        self.dev = None              # device-side schedule state (enable_device_schedule)
         self.total_steps, self.warmup_steps = total_steps, warmup_steps
         self.cnn_lr, self.lr, self.weight_decay, self.no_decay = cnn_lr, lr, weight_decay, no_decay
         self.model_named = model.named_parameters
@@ -203,6 +204,9 @@ class FusedPretrainOptimizer:
         wgrad_stream.join(g.device)
         if self.clip_norm:
             self.ops.sumsq(g, self.partials, self.sumsq)
+        if self.dev is not None:
+            self._device_schedule_step(g, grad_scale)
+            return
         self.kc += 1
         look = self.kc >= self.k
         if look:
@@ -216,6 +220,58 @@ class FusedPretrainOptimizer:
         for p in self.buckets.params:
             torch.autograd.graph.increment_version(p)
         self.step_idx += 1
+
+    # -- device-side schedule (what a captured hipGraph of the step needs: virtex_amd/graph.py).  The step index, the
+    #    Lookahead counter, the LR multiplier and the dropout epoch live in device memory and are advanced by (captured)
+    #    device operations; the by-value arguments of the eager path would be frozen at capture time.
+    def enable_device_schedule(self):
+        if self.dev is not None:
+            return
+        d = self.flat_p.device
+        self.dev = {"step": torch.tensor([float(self.step_idx)], dtype=torch.float32, device=d),
+                    "kc": torch.tensor([float(self.kc)], dtype=torch.float32, device=d),
+                    "sched": torch.zeros(2, dtype=torch.float32, device=d),
+                    "epoch": torch.zeros(1, dtype=torch.int32, device=d)}
+        self.ops.set_dropout_epoch(self.dev["epoch"])
+
+    def disable_device_schedule(self):
+        if self.dev is None:
+            return
+        self.sync_host()
+        self.ops.set_dropout_epoch(None)
+        self.dev = None
+
+    def sync_host(self):
+        """After graph replays: pull the device-side counters back into the host mirrors and tell autograd / the weight
+        caches that the parameters have changed (one device synchronisation)."""
+        if self.dev is not None:
+            self.step_idx = int(round(self.dev["step"].item()))
+            self.kc = int(round(self.dev["kc"].item()))
+        self._touch()
+
+    def _device_schedule_step(self, g, grad_scale):
+        dv = self.dev
+        st, kc, sched = dv["step"], dv["kc"], dv["sched"]
+        warm = float(max(1, self.warmup_steps))
+        span = float(max(1, self.total_steps - self.warmup_steps))
+        # lr_multiplier() on the device: linear warm-up, then cos^2 decay (virtex/optim/lr_scheduler.py:174-183)
+        cosm = torch.cos(((st - float(self.warmup_steps)) / span).clamp_(min=0.0) * (math.pi / 2)).square_()
+        mult = torch.where(st < float(self.warmup_steps), st / warm, cosm)
+        kc.add_(1.0)
+        look = (kc >= float(self.k)).to(torch.float32)
+        kc.mul_(1.0 - look)
+        sched[0:1].copy_(mult)
+        sched[1:2].copy_(look)
+        self.ops.sgd_lookahead_step_dev(self.flat_p, g, self.flat_m, self.flat_slow, self.chunk_off, self.chunk_len,
+                                        self.chunk_seg, self.seg_lr, self.seg_wd, sched, self.momentum, grad_scale,
+                                        self.sumsq, self.clip_norm, self.alpha)
+        st.add_(1.0)
+        dv["epoch"].add_(1)
+        capturing = self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not capturing:                # host mirrors (a replayed graph never runs this: sync_host() catches up)
+            for p in self.buckets.params:
+                torch.autograd.graph.increment_version(p)
+            self.step_idx += 1
 
     # -- checkpointing: same torch.optim.SGD layout as PretrainOptimizer.state_dict() (momentum buffers are
     #    views of the flat buffer in each parameter's logical shape), so checkpoints move freely between
@@ -234,6 +290,8 @@ class FusedPretrainOptimizer:
         return out
 
     def state_dict(self):
+        if self.dev is not None:
+            self.sync_host()
         mult = lr_multiplier(self.step_idx, self.total_steps, self.warmup_steps)
         names = {p: n for n, p in self.model_named()}
         views = self._views(self.flat_m)
@@ -272,6 +330,8 @@ class FusedPretrainOptimizer:
         extra = sd.get("virtex_amd", {})
         self.step_idx = int(extra.get("step", self.step_idx))
         self.kc = int(extra.get("k_counter", 0))
+        if self.dev is not None:
+            self.dev["step"].fill_(float(self.step_idx)); self.dev["kc"].fill_(float(self.kc))
         self.flat_slow.copy_(self.flat_p)        # reference semantics: slow weights restart from the loaded ones
 
     def _touch(self):
