@@ -46,7 +46,8 @@ int vtx_set_tile_override(int cand);   /* tests: force a block tile; -1 = automa
 /* Measurement switches of the specialised kernels, by name: "wgrad3x3" (0 off, 1 by image size, 2 always), "stem_stream",
  * "expand1x1" (0 / 1), "splitk_blocks" (block target of the split-K weight gradients, default 512), "gen3" (generation-3
  * contraction kernels, gemm_v3.h: 0 only when forced by tile override 20 / 21, n >= 2: taken when the cost model predicts
- * at least n % of the generation-2 class rate, default 80; VIRTEX_AMD_GEN3).  Defaults come from
+ * at least n % of the generation-2 class rate, default 80; VIRTEX_AMD_GEN3), "gen3_mc" (the same for the weight gradients,
+ * gemm_v3mc.h: 0 forced only, n: taken when M N / (M + N) >= n, default 200; VIRTEX_AMD_GEN3_MC).  Defaults come from
  * VIRTEX_AMD_WGRAD3X3 / _STEM_STREAM / _EXPAND1X1 / _SPLITK_BLOCKS.  No reference counterpart. */
 int vtx_set_switch(const char* name, int value);
 /* Which contraction kernel this thread's last GEMM-shaped launch ran on: 2 = the DMA kernel (operands addressed through
@@ -178,8 +179,9 @@ int vtx_conv2d_infer(int dtype, int N, int H, int W, int C, int KO, int R, int S
  * stats updated with `momentum` and the unbiased variance, num_batches_tracked += 1.
  * pre_partials/pre_nparts/pre_shift: statistics already produced by the convolution epilogue (see
  * vtx_gemm_nt bn_parts); NULL/0/NULL = reduce here.
- * workspace: vtx_bn_workspace_floats(C) fp32 scratch (per-strip partial sums; no zeroing needed;
- * may be shared by all calls issued on one stream).
+ * workspace: vtx_bn_workspace_floats(C) fp32 scratch; may be shared by all calls issued on one stream.  Its first 64
+ * words are tickets of the one-launch compaction + finalize (strip counts above 512): the caller zero-initialises
+ * the buffer ONCE when it allocates it; every launch leaves the tickets at zero.  The rest needs no initialisation.
  * bwd: dz = dy * (ymask > 0) (ymask = the post-ReLU tensor, NULL if no ReLU follows);
  *      dx = grad wrt x; dz_out (optional) receives dz (the residual-branch gradient);
  *      dgamma/dbeta accumulated. */

@@ -1158,3 +1158,96 @@ def test_contraction_generation3_convolutions(backend, late, cand):
     finally:
         _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
         _set_dma_late(backend, 0)
+
+
+@pytest.mark.parametrize("backend,late", GEN3_PARAMS)
+@pytest.mark.parametrize("cand", [20, 21])
+def test_contraction_generation3_weight_gradients(backend, late, cand):
+    """The k-major kernels of gemm_v3mc.h (transposing fragment reads from [64 k][128 rows] units): dense weight gradients with
+    one, odd and even K-tile counts, ragged K / M / N, split-K slices through the workspace, accumulation into the gradient;
+    convolution weight gradients (3x3 stride 1 / 2, 1x1 stride 2: the pixel-major gather with its position counters)."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(300 + cand)
+    try:
+        _set_dma_late(backend, late)
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
+        for (K, M, N, split) in ((64, 264, 520, 1), (200, 264, 520, 1), (448, 304, 136, 2), (640, 256, 256, 3), (1000, 520, 264, 4)):
+            at = torch.randn(K, M, generator=g).to(dt); bt = torch.randn(K, N, generator=g).to(dt)
+            c0 = torch.randn(M, N, generator=g)
+            acc = ops.gemm_tn_acc(at.to(dev), bt.to(dev), c0.clone().to(dev), split_k=split)
+            assert _generation() == 3, (K, M, N)
+            assert rel_err(acc.cpu(), c0 + at.float().t() @ bt.float()) < 2e-5 * K ** 0.5 + 1e-5, (K, M, N, split)
+        for (k, stride, H, C, KO) in ((3, 1, 9, 64, 64), (3, 2, 10, 64, 128), (1, 2, 16, 128, 64), (3, 1, 7, 128, 256)):
+            pad = k // 2
+            x = torch.randn(3, H, H, C, generator=g).to(dt)
+            w = (torch.randn(KO, k, k, C, generator=g) / (k * k * C) ** 0.5).to(dt)
+            xr = x.float().permute(0, 3, 1, 2); wr = w.float().permute(0, 3, 1, 2).requires_grad_()
+            yr = F.conv2d(xr, wr, stride=stride, padding=pad)
+            dy = torch.randn(yr.shape, generator=g).permute(0, 2, 3, 1).contiguous().to(dt)
+            yr.backward(dy.float().permute(0, 3, 1, 2))
+            for split in (1, 2):
+                dw0 = torch.randn(KO, k, k, C, generator=g)
+                dw = ops.conv2d_wgrad(x.to(dev), dy.to(dev), dw0.clone().to(dev), stride, pad, split_k=split)
+                assert _generation() == 3
+                assert rel_err(dw.cpu() - dw0, wr.grad.permute(0, 2, 3, 1)) < 2e-3, (k, stride, H, split)
+    finally:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+        _set_dma_late(backend, 0)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("C,strips", [(64, 784), (256, 3136), (128, 600)])
+def test_batchnorm_compaction_and_finalize_in_one_launch(backend, C, strips):
+    """More than 512 statistics strips (the convolution epilogues of stages 1-2 at bs = 256: 784 / 3136 block rows) are folded
+    AND finalized by one launch (bn_fin2_kernel: the last-arriving block of a channel group finalizes; agent-scope
+    release / acquire hand-off) instead of a compaction launch and a finalize launch.  Forward: mean / rstd / output / running
+    statistics equal the two-launch path (switch bn_fin2 = 0) and the plain reduction; backward: dx / dgamma / dbeta likewise;
+    repeated launches keep working (the tickets are left at zero)."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(C + strips)
+    rows_per = 2
+    P = strips * rows_per
+    x = (0.8 * torch.randn(P, C, generator=g) + 0.2).to(dt)
+    gamma = 0.5 + torch.rand(C, generator=g); beta = 0.1 * torch.randn(C, generator=g)
+    shift = 0.2 * torch.randn(C, generator=g)
+    d = (x.float() - shift).view(strips, rows_per, C)
+    parts = torch.stack([d.sum(1), (d * d).sum(1)], 1).contiguous()                    # [strips][2][C]
+    xd, gd, bd = x.to(dev), gamma.to(dev), beta.to(dev)
+    st = ops.BnStats(parts.to(dev), strips, shift.to(dev))
+    out = {}
+    for mode in (1, 0, 1):                                                             # one launch, two launches, one launch again
+        _lib.call("vtx_set_switch", b"bn_fin2", ctypes.c_int(mode))
+        rm, rv = shift.clone().to(dev), torch.ones(C, device=dev)
+        y, mean, rstd = ops.bn_fwd(xd, gd, bd, rm, rv, None, stats=st)
+        out.setdefault(mode, []).append((y.float().cpu(), mean.cpu(), rstd.cpu(), rm.cpu(), rv.cpu()))
+    _lib.call("vtx_set_switch", b"bn_fin2", ctypes.c_int(0))
+    ref = ops.bn_fwd(xd, gd, bd, shift.clone().to(dev), torch.ones(C, device=dev), None)
+    for a in out[1]:
+        b = out[0][0]
+        assert torch.allclose(a[1], b[1], rtol=1e-5, atol=1e-6) and torch.allclose(a[2], b[2], rtol=1e-5)
+        assert torch.allclose(a[3], b[3], rtol=1e-5, atol=1e-6) and torch.allclose(a[4], b[4], rtol=1e-5)
+        assert rel_err(a[0], b[0]) < 1e-3
+        assert torch.allclose(a[1], ref[1].cpu(), atol=5e-3, rtol=1e-2) and torch.allclose(a[2], ref[2].cpu(), rtol=1e-2)
+    # backward: strips of (sum dz, sum dz * xhat)
+    mean, rstd = out[1][0][1], out[1][0][2]
+    dz = torch.randn(P, C, generator=g).to(dt)
+    xh = (x.float() - mean) * rstd
+    bparts = torch.stack([dz.float().view(strips, rows_per, C).sum(1), (dz.float() * xh).view(strips, rows_per, C).sum(1)], 1).contiguous()
+    res = {}
+    for mode in (1, 0):
+        _lib.call("vtx_set_switch", b"bn_fin2", ctypes.c_int(mode))
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx = ops.bn_bwd_fused(xd, dz.to(dev), gd, mean.to(dev), rstd.to(dev), dg, db, ops.BnStats(bparts.to(dev), strips, None))
+        res[mode] = (dx.float().cpu(), dg.cpu(), db.cpu())
+    _lib.call("vtx_set_switch", b"bn_fin2", ctypes.c_int(0))
+    assert rel_err(res[1][0], res[0][0]) < 1e-3
+    assert torch.allclose(res[1][1], res[0][1], rtol=1e-4, atol=1e-3) and torch.allclose(res[1][2], res[0][2], rtol=1e-4, atol=1e-3)
+    s1, s2 = dz.float().sum(0), (dz.float() * xh).sum(0)
+    dx_ref = gamma * rstd * (dz.float() - s1 / P - xh * s2 / P)
+    assert rel_err(res[1][0], dx_ref) < 1e-2

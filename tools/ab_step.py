@@ -58,7 +58,9 @@ def main():
         kv, sw, lib = [], [], default_lib
         for f in filter(None, flags.split(",")):
             k, val = f.split("=")
-            if k == "lib":
+            if k == "serial":                       # serial=1: every kernel on the compute stream (what the kernels cost without overlap)
+                kv.append(("__serial__", None, int(val)))
+            elif k == "lib":
                 lib = val if os.path.isabs(val) else os.path.join(os.path.dirname(_lib.DEFAULT_LIB), val)
             elif k.startswith("sw."):
                 sw.append((k[3:], int(val)))
@@ -66,8 +68,14 @@ def main():
                 mod, attr = (mods[k.split(".")[0]], k.split(".")[1]) if "." in k else (vb, k)
                 kv.append((mod, attr, type(getattr(mod, attr))(int(val))))
         variants.append((name, kv, sw, lib))
-    defaults = {(m, k): getattr(m, k) for _, kv, _, _ in variants for m, k, _ in kv}
-    sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512, "mc_eff128": 84, "bn_fin_wide": 0, "stats_tile": 0, "bn_adj": 1, "bn_grid": 8192, "tile64x256": 1, "tile_order": 0, "conv3x3_shared": 1}
+    from virtex_amd import streams as _streams
+
+    def _set_serial(on):
+        _streams.wgrad_stream.enabled = not on
+        _streams.branch_stream.enabled = not on
+        models.HEAD_STREAMS = not on
+    defaults = {(m, k): getattr(m, k) for _, kv, _, _ in variants for m, k, _ in kv if m != "__serial__"}
+    sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512, "mc_eff128": 84, "bn_fin_wide": 0, "stats_tile": 0, "bn_adj": 1, "bn_grid": 8192, "tile64x256": 1, "tile_order": 0, "conv3x3_shared": 1, "gen3": 80, "gen3_mc": 200}
     res = {n: [] for n, _, _, _ in variants}
     for r in range(a.rounds):
         for name, kv, sw, lib in variants:
@@ -80,8 +88,12 @@ def main():
                 _lib.call("vtx_set_switch", k.encode(), ctypes.c_int(val))
             for (m, k), d in defaults.items():
                 setattr(m, k, d)
+            _set_serial(False)
             for m, k, val in kv:
-                setattr(m, k, val)
+                if m == "__serial__":
+                    _set_serial(bool(val))
+                else:
+                    setattr(m, k, val)
             for i in range(a.warmup):
                 step(i)
             torch.cuda.synchronize()

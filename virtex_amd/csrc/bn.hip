@@ -157,6 +157,96 @@ __global__ void bn_compact_parts_kernel(const float* __restrict__ sums, float* _
     }
 }
 
+// Compaction AND finalize in ONE launch (round 4 experiment, OFF by default: measured 0.26 ms/step slower than the two
+// dependent 5-us launches it replaces, 38 per step, on the critical path of every BatchNorm of stages 1-2): block (x = 32-channel group, y = chunk of `per` strips) folds its chunk into compact strip y as
+// bn_compact_parts_kernel does, publishes it, and draws a ticket; the block that draws the last ticket of its channel group
+// folds the ny compact strips and runs the finalize arithmetic of bn_fwd_finalize_kernel / bn_bwd_finalize_kernel for those
+// 32 channels.  Hand-off = the agent-scope release / acquire recipe of cdna_hip_programming.md (Guideline 16): slab stores,
+// every wave vmcnt(0), block barrier, ONE lane: release fence, vmcnt(0), relaxed agent-scope fetch_add; the last arriver:
+// acquire fence, block barrier, plain loads.  Correct for any placement of the blocks on XCDs.  tickets[x] is zero when
+// the launch starts (zero-initialised workspace header) and is put back to zero by the last arriver.
+struct BnFin2Args {
+    // forward
+    const float* pre_shift; const float* gamma; const float* beta; float* mean; float* rstd; float* scale; float* shift;
+    float* running_mean; float* running_var; long long* nbt; float eps, momentum;
+    // backward
+    const float* rstd_in; float* coef; float* dgamma; float* dbeta;
+    int P;
+};
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_fin2_kernel(const float* __restrict__ sums, float* __restrict__ compact, int* __restrict__ tickets,
+                                                      int C, int nparts, int per, BnFin2Args a) {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5, NG = blockDim.x >> 5;
+    const int ny = gridDim.y;
+    const int p0 = blockIdx.y * per, p1 = p0 + per < nparts ? p0 + per : nparts;
+    __shared__ float red[2][8][32];
+    __shared__ int s_last;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C)
+        for (int p = p0 + grp; p < p1; p += NG) { s0 += sums[(size_t)p * 2 * C + c]; s1 += sums[(size_t)p * 2 * C + C + c]; }
+    red[0][grp][threadIdx.x & 31] = s0; red[1][grp][threadIdx.x & 31] = s1;
+    __syncthreads();
+    if (grp == 0 && c < C) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int g = 0; g < NG; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+        compact[(size_t)blockIdx.y * 2 * C + c] = t0;
+        compact[(size_t)blockIdx.y * 2 * C + C + c] = t1;
+    }
+    // ---- publish the compact strip, draw the ticket
+#ifndef HIPEMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#ifndef HIPEMU
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        const int t = atomicAdd(&tickets[blockIdx.x], 1);
+#endif
+        s_last = t == ny - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#ifndef HIPEMU
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    __syncthreads();
+    // ---- the last arriver of this channel group: fold the ny compact strips (every block's, through L2), finalize
+    s0 = s1 = 0.f;
+    if (c < C)
+        for (int y = grp; y < ny; y += NG) { s0 += compact[(size_t)y * 2 * C + c]; s1 += compact[(size_t)y * 2 * C + C + c]; }
+    red[0][grp][threadIdx.x & 31] = s0; red[1][grp][threadIdx.x & 31] = s1;
+    __syncthreads();
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0;              // re-armed for the next launch on this stream
+    if (grp != 0 || c >= C) return;
+    float t0 = 0.f, t1 = 0.f;
+    for (int g = 0; g < NG; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+    if constexpr (!BWD) {
+        if (c == 0 && a.nbt) *a.nbt += 1;
+        const float ms = t0 / (float)a.P;
+        float var = t1 / (float)a.P - ms * ms;
+        var = var > 0.f ? var : 0.f;
+        const float m = a.pre_shift[c] + ms;
+        const float r = rsqrtf(var + a.eps);
+        a.mean[c] = m; a.rstd[c] = r;
+        const float sc = a.gamma[c] * r;
+        a.scale[c] = sc; a.shift[c] = a.beta[c] - m * sc;
+        if (a.running_mean) {
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * m;
+            const float unbiased = a.P > 1 ? var * ((float)a.P / (float)(a.P - 1)) : var;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * unbiased;
+        }
+    } else {
+        a.coef[c] = a.gamma[c] * a.rstd_in[c];
+        a.coef[C + c] = t0 / (float)a.P;
+        a.coef[2 * C + c] = t1 / (float)a.P;
+        a.dgamma[c] += t1;
+        a.dbeta[c] += t0;
+    }
+}
+
 template <class T>
 __global__ void bn_fwd_finalize_kernel(const T* __restrict__ x, const float* __restrict__ pre_shift,
                                        const float* __restrict__ sums, const float* __restrict__ gamma,
@@ -547,7 +637,9 @@ static bool bn_shape_ok(int C, int vec) { return C > 0 && C % vec == 0 && ((C / 
 
 }  // namespace
 
-extern "C" long vtx_bn_workspace_floats(int C) { return (long)(2 * VTX_BN_MAX_PARTS + 4) * C; }
+constexpr int VTX_BN_WS_HEADER = 64;      // ints in front of the workspace: tickets of bn_fin2_kernel (the caller zero-initialises the buffer ONCE)
+extern int g_vtx_sw_bn_fin2;              // vtx_set_switch("bn_fin2"): 1 = compaction + finalize in one launch, 0 (default: faster, see core.hip) two launches
+extern "C" long vtx_bn_workspace_floats(int C) { return VTX_BN_WS_HEADER + (long)(2 * VTX_BN_MAX_PARTS + 4) * C; }
 
 // workspace layout (fp32): scale[C] | coef[3*C] | partial sums [nparts][2][C]   (need not be zeroed)
 extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const float* gamma,
@@ -562,15 +654,26 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_fwd: C=%d must be vec*2^k, P=%d > 0", C, P);
     hipStream_t st = (hipStream_t)stream;
+    int* tickets = reinterpret_cast<int*>(workspace); (void)tickets;
+    workspace += VTX_BN_WS_HEADER;
     float* scale = workspace; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(P, C, vec);
     const long nvec = (long)P * C / vec;
     const bool fused = pre_partials != nullptr && pre_nparts > 0;   // statistics came with the conv epilogue
+    bool fin_done = false;
     VTX_CHECK(!fused || pre_shift, VTX_ERR_ARG, "bn_fwd: fused statistics need the shift vector they were taken against");
     if (fused) {
         const float* parts = pre_partials;
         int np = pre_nparts;
-        if (np > 512) {             // thousands of strips: fold them first (keeps the finalize short)
+        if (np > 512 && g_vtx_sw_bn_fin2 && C <= 32 * VTX_BN_WS_HEADER) {
+            // thousands of strips: folded and finalized by ONE launch (bn_fin2_kernel: last-arriving block per channel group)
+            const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
+            BnFin2Args fa{};
+            fa.pre_shift = pre_shift; fa.gamma = gamma; fa.beta = beta; fa.mean = save_mean; fa.rstd = save_rstd; fa.scale = scale; fa.shift = scale + C;
+            fa.running_mean = running_mean; fa.running_var = running_var; fa.nbt = num_batches_tracked; fa.eps = eps; fa.momentum = momentum; fa.P = P;
+            VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, (bn_fin2_kernel<false>), dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, tickets, C, np, per, fa);
+            fin_done = true;
+        } else if (np > 512) {      // the same in two launches (A/B: vtx_set_switch("bn_fin2", 0))
             const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
             VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(g_vtx_sw_bn_fin_wide ? 1024 : 256), 0, st, parts, sums, C, np, per);
             parts = sums; np = ny;
@@ -583,7 +686,8 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     else
         VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
                            (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
-    if (dtype == VTX_BF16)
+    if (fin_done) {}
+    else if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                            save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);
     else
@@ -633,6 +737,8 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(P > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_bwd: C=%d must be vec*2^k, P=%d > 0", C, P);
     hipStream_t st = (hipStream_t)stream;
+    int* tickets = reinterpret_cast<int*>(workspace); (void)tickets;
+    workspace += VTX_BN_WS_HEADER;
     float* coef = workspace + C; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(P, C, vec);
     const long nvec = (long)P * C / vec;
@@ -674,16 +780,25 @@ extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const 
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(P > 0 && pre_nparts > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_bwd_fused: C=%d must be vec*2^k, P=%d > 0", C, P);
     hipStream_t st = (hipStream_t)stream;
+    int* tickets = reinterpret_cast<int*>(workspace); (void)tickets;
+    workspace += VTX_BN_WS_HEADER;
     float* coef = workspace + C; float* sums = workspace + 4 * C;
     const float* parts = pre_partials;
     int np = pre_nparts;
-    if (np > 512) {
+    if (np > 512 && g_vtx_sw_bn_fin2 && C <= 32 * VTX_BN_WS_HEADER) {
         const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
-        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(g_vtx_sw_bn_fin_wide ? 1024 : 256), 0, st, parts, sums, C, np, per);
-        parts = sums; np = ny;
+        BnFin2Args fa{};
+        fa.gamma = gamma; fa.rstd_in = save_rstd; fa.coef = coef; fa.dgamma = dgamma; fa.dbeta = dbeta; fa.P = P;
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, (bn_fin2_kernel<true>), dim3(vtx_cdiv(C, 32), ny), dim3(256), 0, st, parts, sums, tickets, C, np, per, fa);
+    } else {
+        if (np > 512) {
+            const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
+            VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(g_vtx_sw_bn_fin_wide ? 1024 : 256), 0, st, parts, sums, C, np, per);
+            parts = sums; np = ny;
+        }
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(np), 0, st, parts, gamma, save_rstd, coef,
+                    dgamma, dbeta, P, C, np);
     }
-    VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(np), 0, st, parts, gamma, save_rstd, coef,
-                dgamma, dbeta, P, C, np);
     const long nvec = (long)P * C / vec;
     launch_bwd_apply_fused(dtype, x, dz, save_mean, save_rstd, coef, dx, nvec, P, C, vec, st);
     VTX_LAUNCH_CHECK();
@@ -711,6 +826,8 @@ extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, c
     VTX_CHECK(NQl < (1L << 24), VTX_ERR_SHAPE, "bn_bwd_maxpool: more than 2^24 pixel quads is not supported");
     const int NQ = (int)NQl;
     hipStream_t st = (hipStream_t)stream;
+    int* tickets = reinterpret_cast<int*>(workspace); (void)tickets;
+    workspace += VTX_BN_WS_HEADER;
     float* coef = workspace + C; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(NQ, C, vec);
     const double el = dtype == VTX_BF16 ? 2.0 : 4.0;
@@ -756,6 +873,8 @@ extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, 
     VTX_CHECK(N > 0 && H > 0 && W > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_fwd_maxpool: C=%d must be vec*2^k", C);
     VTX_CHECK((long)N * H * W < (1L << 24), VTX_ERR_SHAPE, "bn_fwd_maxpool: more than 2^24 pixels is not supported");
     hipStream_t st = (hipStream_t)stream;
+    int* tickets = reinterpret_cast<int*>(workspace); (void)tickets;
+    workspace += VTX_BN_WS_HEADER;
     const int P = N * H * W, OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
     float* scale = workspace; float* sums = workspace + 4 * C;
     ReducePlan rp = plan_reduce(P, C, vec);

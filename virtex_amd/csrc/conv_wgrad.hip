@@ -16,7 +16,7 @@ static int conv_wgrad_t(const ConvGeo& g, const void* x, const void* dy, float* 
                         long ws_floats, hipStream_t st) {
     const int M = g.KO, Nd = g.R * g.S * g.C, Kd = g.N * g.OH * g.OW;
     const int bk = 4 * Elem<T>::VEC, nkt = vtx_cdiv(Kd, bk);
-    if (split_k <= 0) split_k = vtx_pick_split_k(M, Nd, Kd, bk, ws ? ws_floats : 0);
+    if (split_k <= 0) split_k = vtx_pick_split_k(M, Nd, Kd, bk, ws ? ws_floats : 0, 1);
     else { if (split_k > nkt) split_k = nkt; split_k = vtx_cdiv(nkt, vtx_cdiv(nkt, split_k)); }
     VTX_CHECK(split_k == 1 || (ws && (long)split_k * M * Nd <= ws_floats), VTX_ERR_WORKSPACE,
               "conv2d_wgrad: split_k=%d needs %ld workspace floats", split_k, (long)split_k * M * Nd);

@@ -57,6 +57,7 @@ int g_vtx_sw_wgrad3x3 = getenv("VIRTEX_AMD_WGRAD3X3") ? atoi(getenv("VIRTEX_AMD_
 int g_vtx_sw_stem_stream = getenv("VIRTEX_AMD_STEM_STREAM") ? atoi(getenv("VIRTEX_AMD_STEM_STREAM")) : 1;  // stem.hip
 int g_vtx_sw_expand1x1 = getenv("VIRTEX_AMD_EXPAND1X1") ? atoi(getenv("VIRTEX_AMD_EXPAND1X1")) : 1;        // expand1x1.hip
 int g_vtx_sw_splitk_blocks = getenv("VIRTEX_AMD_SPLITK_BLOCKS") ? atoi(getenv("VIRTEX_AMD_SPLITK_BLOCKS")) : 512;   // split-K block target of the weight gradients
+int g_vtx_sw_bn_fin2 = getenv("VIRTEX_AMD_BN_FIN2") ? atoi(getenv("VIRTEX_AMD_BN_FIN2")) : 0;   // BatchNorm strips > 512: compaction + finalize in one launch (bn_fin2_kernel).  Measured SLOWER (24.66 vs 24.40 ms/step, profiles/r04_ab_bn_fin2.txt): an agent-scope release per block costs more than the 2-us kernel boundary it removes -> off
 int g_vtx_sw_bn_fin_wide = getenv("VIRTEX_AMD_BN_FIN_WIDE") ? atoi(getenv("VIRTEX_AMD_BN_FIN_WIDE")) : 0;   // 1024-thread BatchNorm finalize / compaction blocks
 // tile rule of the convolutions with BatchNorm epilogues (launch_auto): 0 = the plain picker, 1 = 8-wave 128x128 tiles for every
 // statistics epilogue on large M (rounds 1-2), 2 = only for the forward statistics, 3 = only for the fused backward
@@ -66,6 +67,7 @@ int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
 namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 80; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, n >= 2: taken when the cost model predicts n % of the generation-2 class rate (step A/B: 80 -> 24.26, 100 -> 24.46, off 24.65 ms/step)
+namespace vtxg { int g_vtx_sw_gen3_mc = getenv("VIRTEX_AMD_GEN3_MC") ? atoi(getenv("VIRTEX_AMD_GEN3_MC")) : 200; }   // generation 3 for the weight gradients (gemm_v3mc.h): 0 forced only, n: taken from M N / (M + N) >= n (MFMA-leaning shapes)
 namespace vtxg { int g_vtx_sw_mc_eff128 = getenv("VIRTEX_AMD_MC_EFF128") ? atoi(getenv("VIRTEX_AMD_MC_EFF128")) : 84; }   // tile picker: 128x128 efficiency (%) for k-major operands
 extern "C" int vtx_set_switch(const char* name, int value) {
     VTX_CHECK(name, VTX_ERR_ARG, "vtx_set_switch: null name");
@@ -73,11 +75,13 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "stem_stream")) g_vtx_sw_stem_stream = value;
     else if (!strcmp(name, "expand1x1")) g_vtx_sw_expand1x1 = value;
     else if (!strcmp(name, "bn_fin_wide")) g_vtx_sw_bn_fin_wide = value;
+    else if (!strcmp(name, "bn_fin2")) g_vtx_sw_bn_fin2 = value;
     else if (!strcmp(name, "stats_tile")) vtxg::g_vtx_sw_stats_tile = value;
     else if (!strcmp(name, "tile_order")) vtxg::g_vtx_ablate = (vtxg::g_vtx_ablate & ~32) | (value ? 32 : 0);   // 1: plain block -> tile order (A/B)
     else if (!strcmp(name, "bn_adj")) g_vtx_sw_bn_adj = value;
     else if (!strcmp(name, "bn_grid")) g_vtx_sw_bn_grid = value > 0 ? value : 8192;
     else if (!strcmp(name, "gen3")) vtxg::g_vtx_sw_gen3 = value;
+    else if (!strcmp(name, "gen3_mc")) vtxg::g_vtx_sw_gen3_mc = value;
     else if (!strcmp(name, "conv3x3_shared")) vtxg::g_vtx_sw_conv3x3_shared = value;
     else if (!strcmp(name, "tile64x256")) vtxg::g_vtx_sw_tile64x256 = value;
     else if (!strcmp(name, "mc_eff128")) vtxg::g_vtx_sw_mc_eff128 = value > 0 ? value : 84;

@@ -13,7 +13,7 @@ using namespace vtxg;
 
 vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
-int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats);
+int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats, int gather = 0);
 int vtx_expand1x1_try(int M, int N, int K, const void* A, long lda, const void* W, long ldw, void* Y, long ldy,
                       const float* shift, float* parts, hipStream_t st);
 
@@ -91,7 +91,11 @@ void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc,
 // Split-K policy for the weight-gradient GEMMs: enough slices to give every CU ~2 blocks, never fewer than 8 K-steps per slice, bounded by the workspace
 // ([slices][M][N] fp32 partial sums).
 extern int g_vtx_sw_splitk_blocks;
-int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats) {
+int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats, int gather) {
+    if (bk == 32 && vtxg::g_vtx_contraction_generation >= 2) {          // generation 3 plans its own slices (gemm_kernel.h)
+        int s3 = 1;
+        if (vtxg::plan_gen3_mc(M, N, K, gather != 0, &s3) && (s3 == 1 || (long)s3 * M * N <= ws_floats)) return s3;
+    }
     long tiles = (long)vtx_cdiv(M, 128) * vtx_cdiv(N, N <= 64 ? 64 : 128);
     // launch_auto takes one 64x256 tile -- only on the bf16 LDS-DMA kernel (bk == 32) and without a forced tile
     if (vtxg::g_vtx_sw_tile64x256 && bk == 32 && vtxg::g_vtx_contraction_generation >= 2 && vtxg::g_vtx_tile_override < 0 &&

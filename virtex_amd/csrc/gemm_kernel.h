@@ -1729,6 +1729,43 @@ inline int pick_gen3(int M, int N, int K, int splits, bool gather, int smode) {
     return c256 <= c128 ? 1 : 2;
 }
 
+// Generation 3 for the weight gradients (k-major pairs, gemm_v3mc.h): tile (1 = 256x256, 2 = 256x128, 0 = generation 2) and
+// the split-K slice count that goes with it -- enough slices to give every CU a block, at least 4 K tiles of 64 per slice.
+// The callers' split policy (vtx_pick_split_k) asks first, so that launch_auto sees the slice count this plan assumes.
+// Measured per shape at bs = 256 (profiles/r04_gen3_mc_per_shape.txt, reductions included): text-head gradients +6...23 %,
+// 1x1 convolutions at 14x14 / 7x7 +12...19 % (256x128 blocks), 3x3 at 14x14 / 7x7 +25...34 % (256x256 blocks); the
+// HBM-bound gradients of the 56x56 / 28x28 stages (M N / (M + N) below ~200 FLOP per operand byte pair) tie or lose
+// and stay on generation 2.  Tile and slices by a cycle model fitted to the same table:
+//   256x256: 4 400 + slices' K tiles x 3 000 (gather 3 600) + 13 000 (fp32 tile through the strip); 256x128: ... x 1 800 (2 450) + 6 000;
+//   + the reduce launch: 6 000 + (slices + 2) x M N x 4 bytes at 4 TB/s.
+extern int g_vtx_sw_gen3_mc;      // vtx_set_switch("gen3_mc"): 0 = only when forced (tile override 20 / 21), n = the intensity threshold (default 200)
+inline int plan_gen3_mc(int M, int N, int K, bool gather, int* split) {
+    *split = 1;
+    if (g_vtx_tile_override >= 0 && g_vtx_tile_override != 20 && g_vtx_tile_override != 21) return 0;
+    const bool forced = g_vtx_tile_override == 20 || g_vtx_tile_override == 21;
+    if (!forced) {
+        if (!g_vtx_sw_gen3_mc || K < 2048 || M < 256 || N < 256) return 0;
+        if ((double)M * N / ((double)M + N) < (double)g_vtx_sw_gen3_mc) return 0;
+    }
+    const int nkt = vtx_cdiv(K, 64);
+    int best = 0, best_s = 1; double best_c = 1e30;
+    for (int c = 1; c <= 2; ++c) {
+        if (forced && c != g_vtx_tile_override - 19) continue;
+        const long t = (long)vtx_cdiv(M, 256) * vtx_cdiv(N, c == 1 ? 256 : 128);
+        long s = t >= 256 ? 1 : 256 / t;
+        if (s > nkt / 4) s = nkt / 4 > 0 ? nkt / 4 : 1;
+        const int per = vtx_cdiv(nkt, (int)s);
+        s = vtx_cdiv(nkt, per);
+        const double ck = c == 1 ? (gather ? 3600.0 : 3000.0) : (gather ? 2450.0 : 1800.0);
+        const double epi = c == 1 ? 13000.0 : 6000.0;
+        double cyc = (double)((t * s + 255) / 256) * (4400.0 + per * ck + epi);
+        if (s > 1) cyc += 6000.0 + (double)(s + 2) * M * N * 4.0 / 4.0e12 * 2.1e9;
+        if (cyc < best_c) { best_c = cyc; best = c; best_s = (int)s; }
+    }
+    *split = best_s;
+    return best;
+}
+
 // Returns the number of BatchNorm-statistics strips written (0 when the kernel generation that ran
 // does not produce them: the caller then falls back to the stand-alone reduction).
 template <class T, template <class, int> class ALT, template <class, int> class BLT, class EP, class FA, class FB>
@@ -1759,6 +1796,22 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
 #define VTX_V2(BM_, BN_, WM_, WN_, SA_, SB_)                                                \
     { ALT<T, SA_> a; make_a(a); BLT<T, SB_> b; make_b(b); strips = launch_v2<BM_, BN_, WM_, WN_>(a, b, ep, M, N, K, split_k, st); }
     int strips = 0;
+    if constexpr (BF && ALT<T, 1>::MC && BLT<T, 1>::MC && !EP::STATS && EP::STAGED) {
+        // generation 3, k-major pairs (the weight gradients): only with the slice count its plan assumes
+        int s3 = 1;
+        const int g3 = v2 ? plan_gen3_mc(M, N, K, !std::is_same<BLT<T, 1>, PlainMC<T, 1>>::value, &s3) : 0;
+        const bool forced = g_vtx_tile_override == 20 || g_vtx_tile_override == 21;
+        // (the caller sized its workspace epilogue / reduction for split_k slices: the 64-deep K tiles must split into exactly that many)
+        const int sk = split_k < 1 ? 1 : split_k, nkt64 = vtx_cdiv(K, 64);
+        const bool slices_ok = sk == 1 || (sk <= nkt64 && vtx_cdiv(nkt64, vtx_cdiv(nkt64, sk)) == sk);
+        if (g3 && slices_ok && (forced || s3 == sk) && buf_ok(64)) {
+            g_vtx_last_generation = 3;
+            g_vtx_generation_count[3].fetch_add(1, std::memory_order_relaxed);
+            if (g3 == 1) { ALT<T, 4> a; make_a(a); BLT<T, 4> b; make_b(b); launch_v3<256>(a, b, ep, M, N, K, split_k, st); }
+            else { ALT<T, 4> a; make_a(a); BLT<T, 2> b; make_b(b); launch_v3<128>(a, b, ep, M, N, K, split_k, st); }
+            return 0;
+        }
+    }
     if constexpr (BF && !ALT<T, 1>::MC && !BLT<T, 1>::MC) {
         // generation 3 (gemm_v3.h): 8-wave 256x256 / 256x128 blocks with the phase-interleaved K loop
         const int g3 = v2 ? pick_gen3(M, N, K, split_k, !std::is_same<ALT<T, 1>, PlainKC<T, 1>>::value, EP::SMODE) : 0;

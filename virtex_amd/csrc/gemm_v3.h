@@ -513,6 +513,8 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
     V3_STAMP(3);
 }
 
+#include "gemm_v3mc.h"
+
 // ------------------------------------------------------------------ host side
 extern unsigned long long* g_vtx_dbg;   // measurement builds: time-stamp buffer of the generation-3 kernels (vtx_set_debug_buffer), else null
 extern int g_vtx_sw_gen3;        // vtx_set_switch("gen3"): 0 = generation 3 only when forced by the tile override (20 / 21), 1 = automatic
@@ -528,8 +530,13 @@ inline int launch_v3(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
     split_k = per > 0 ? vtx_cdiv(nkt, per) : 1;
     constexpr size_t lds_bytes = BN == 256 ? 2 * 4 * V3_UNIT * 2 : 3 * 3 * V3_UNIT * 2;
     auto pick = [](auto lean) {
-        if constexpr (BN == 256) return contraction_v3_256x256_kernel<AL, BL, EP, decltype(lean)::value>;
-        else return contraction_v3_256x128_kernel<AL, BL, EP, decltype(lean)::value>;
+        if constexpr (AL::MC) {                 // k-major pairs (weight gradients): gemm_v3mc.h, plain fp32 epilogue
+            if constexpr (BN == 256) return contraction_v3mc_256x256_kernel<AL, BL, EP>;
+            else return contraction_v3mc_256x128_kernel<AL, BL, EP>;
+        } else {
+            if constexpr (BN == 256) return contraction_v3_256x256_kernel<AL, BL, EP, decltype(lean)::value>;
+            else return contraction_v3_256x128_kernel<AL, BL, EP, decltype(lean)::value>;
+        }
     };
     auto kern = pick(std::false_type{});
     if constexpr (EP::STATS && EP::STAGED) {

@@ -102,6 +102,8 @@ __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
 // the same from a byte offset inside the kernel's dynamic LDS (which starts at LDS address 0 when the kernel has no static
 // __shared__ object: the offset IS the address -- no per-read "+ base" instruction)
 __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16_at(const char* dyn_lds, uint32_t off) { return vtx_ds_read_tr16(dyn_lds + off); }
+// ... and with a compile-time byte offset on top (the instruction's 16-bit offset field: no address arithmetic per read)
+template <int IMM> __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16_imm(const char* dyn_lds, uint32_t off) { return vtx_ds_read_tr16(dyn_lds + off + IMM); }
 __device__ __forceinline__ void vtx_ds_tr_wait() {}
 template <int N> __device__ __forceinline__ void vtx_ds_tr_wait_n() {}
 #else
@@ -114,6 +116,12 @@ __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16(const void* p) {
 __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16_at(const char*, uint32_t off) {
     vtx_v4s_t r;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(off) : "memory");
+    return r;
+}
+template <int IMM> __device__ __forceinline__ vtx_v4s_t vtx_ds_read_tr16_imm(const char*, uint32_t off) {
+    static_assert(IMM >= 0 && IMM < 65536, "ds offset field is 16 bits");
+    vtx_v4s_t r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(off), "n"(IMM) : "memory");
     return r;
 }
 __device__ __forceinline__ void vtx_ds_tr_wait() {

@@ -269,7 +269,8 @@ def bn_workspace(device, C):
     need = lib.vtx_bn_workspace_floats(c_int(C))
     ws = _bn_ws.get(_ws_key(device))
     if ws is None or ws.numel() < need:
-        ws = torch.empty(max(need, lib.vtx_bn_workspace_floats(c_int(2048))), dtype=torch.float32, device=device)
+        # zero-initialised ONCE: the first 64 words are the tickets of bn_fin2_kernel (each launch leaves them at zero again)
+        ws = torch.zeros(max(need, lib.vtx_bn_workspace_floats(c_int(2048))), dtype=torch.float32, device=device)
         _bn_ws[_ws_key(device)] = ws
     return ws
 
