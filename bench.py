@@ -61,11 +61,13 @@ def parse(argv=None):
                          "this mode shows every kernel un-contended, which is what the roofline object reports")
     ap.add_argument("--roofline-live", action="store_true",
                     help="take the per-launch events inside the timed region itself (adds the event overhead to `value`)")
-    ap.add_argument("--graph", choices=("auto", "on", "off"), default="off",
-                    help="replay the whole step as ONE hipGraph (virtex_amd/graph.py).  Default off: measured SLOWER than the eager "
-                         "three-stream step on ROCm 7.2 (profiles/r04_hipgraph_configs_2_4_5.txt: 26.3 vs 24.3 ms at bs 256, 23.6 vs "
-                         "20.4 config 4, 21.4 vs 18.0 config 5 -- the replay runs the captured side-stream branches one after the "
-                         "other and adds ~2 us per node); auto = try it on single-process GPU runs, eager as the fall-back")
+    ap.add_argument("--launch", choices=("auto", "eager", "replay", "graph"), default="auto",
+                    help="how the timed steps are issued.  eager: the Python step (autograd + ctypes per launch, ~10 ms of host "
+                         "time per step).  replay: the same launches on the same three streams re-issued from a recorded list "
+                         "(virtex_amd/replay.py; validated against the eager step at construction; ~2 ms of host time) -- what "
+                         "BASELINE configs 4 / 5 need, neutral at bs 256.  graph: ONE hipGraph (virtex_amd/graph.py) -- measured "
+                         "SLOWER than eager on ROCm 7.2 (profiles/r04_hipgraph_configs_2_4_5.txt).  auto: replay on single-process "
+                         "GPU runs with the eager step as the fall-back")
     ap.add_argument("--image-size", type=int, default=224)
     ap.add_argument("--vocab-size", type=int, default=10000)
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -337,27 +339,37 @@ def main(argv=None, device=None, backend=None):
         opt.step(grad_scale=scale)
         return out["loss"].detach()        # (no autograd graph of an eager step may be alive when a hipGraph capture starts)
 
+    loss = None
     for i in range(a.warmup):
         loss = step(i)
     device_sync()
-    # One hipGraph per step (single process: the all-reduces of N > 1 stay eager).  The captured step is the SAME function;
-    # dropout epoch, LR multiplier and Lookahead phase advance on the device (virtex_amd/graph.py).
+    # Launch replay / hipGraph (single process: the all-reduces of N > 1 stay eager).  The issued step is the SAME function;
+    # dropout epoch, LR multiplier and Lookahead phase advance on the device (virtex_amd/replay.py, graph.py).
     gstep, launch_mode = None, "eager"
-    if a.graph != "off" and world == 1 and dev.type == "cuda" and not a.roofline_live:
+    want = a.launch
+    if want == "auto":
+        want = "replay" if (world == 1 and dev.type == "cuda" and not a.roofline_live) else "eager"
+    if want in ("replay", "graph") and world == 1 and not a.roofline_live:
+        del loss
         try:
-            from virtex_amd.graph import GraphedTrainStep
-            gstep = GraphedTrainStep(model, buckets, opt, batches[0], warmup=2)
+            if want == "graph":
+                from virtex_amd.graph import GraphedTrainStep
+                gstep = GraphedTrainStep(model, buckets, opt, batches[0], warmup=2)
+            else:
+                from virtex_amd.replay import StepReplay
+                gstep = StepReplay(model, buckets, opt, batches[0], warmup=1, validate=True)
             for i in range(3):
                 loss = gstep(batches[i % 2])
             device_sync()
-            launch_mode = "hipgraph"
-        except Exception as e:                  # capture is an optimisation: the eager step is the product path either way
-            if a.graph == "on":
+            launch_mode = "hipgraph" if want == "graph" else "replay"
+        except Exception as e:                  # an optimisation: the eager step is the product path either way
+            if a.launch != "auto":
                 raise
-            print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
+            print(f"bench.py: launch {want} failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
             gstep = None
             opt.disable_device_schedule()
             device_sync()
+            loss = step(0)
     run_step = (lambda i: gstep(batches[i % 2])) if gstep is not None else step
     vd.synchronize()
     device_sync()
@@ -368,6 +380,7 @@ def main(argv=None, device=None, backend=None):
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = run_step(i)
+    host_issue = time.perf_counter() - t0          # the host has enqueued every step (the GPU is still working when it is ahead)
     device_sync()
     vd.synchronize()
     device_sync()
@@ -460,7 +473,8 @@ def main(argv=None, device=None, backend=None):
             "config": {"workload": f"bicaptioning_{cnn}_{key} {a.dtype}, bs={a.batch}/GPU, {a.image_size}x{a.image_size} synthetic images + "
                                    "30-tok captions, full step (fwd+bwd+clip+SGD+Lookahead), dropout "
                                    f"{a.dropout}", "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "launch": launch_mode},
+                       "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "launch": launch_mode,
+                       "host_enqueue_ms_per_step": round(host_issue / a.steps * 1e3, 3)},
         }
         if comm_exposed is not None:
             rec["data_parallel"] = {"comm_exposed_ms_per_rank": comm_exposed, "payload": buckets.payload,

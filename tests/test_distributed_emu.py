@@ -39,6 +39,15 @@ vd.broadcast_parameters(model)
 buckets = vd.GradientBuckets(model, bucket_mb=2.0, payload=os.environ["VTX_PAYLOAD"])
 assert buckets.buckets[-1][1] - buckets.buckets[-1][0] <= 2.0 * (1 << 20) / 4 / 2 + 1      # the tail bucket (closes last, exposed) is small
 batch = synth.synthetic_batch(seed=40 + rank, **bk)
+# order of host-side events of the backward pass: every bucket launch, every convolution weight-gradient enqueue
+from virtex_amd import ops as _ops
+order = []
+_launch0, _wgrad0 = buckets._launch, _ops.conv2d_wgrad
+def _launch(b):
+    order.append(["bucket", b]); return _launch0(b)
+def _wgrad(x, dy, dw, *a, **k):
+    order.append(["wgrad", list(dw.shape)]); return _wgrad0(x, dy, dw, *a, **k)
+buckets._launch = _launch; _ops.conv2d_wgrad = _wgrad
 buckets.zero(); buckets.begin()
 model({k: v.to(dev) for k, v in batch.items()})["loss"].backward()
 scale = buckets.finish()
@@ -46,7 +55,7 @@ early = buckets.last_early
 out = {n: (p.grad * scale).flatten()[:: max(1, p.numel() // 64)][:64].tolist() + [float((p.grad * scale).double().norm())]
        for n, p in model.named_parameters()}
 with open(os.environ["VTX_OUT"] + f".{rank}", "w") as f:      # a file, not the pipe: the parent reads the ranks one after the other
-    json.dump({"rank": rank, "nbuckets": len(buckets.buckets), "early": early, "grads": out}, f)
+    json.dump({"rank": rank, "nbuckets": len(buckets.buckets), "early": early, "grads": out, "order": order}, f)
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -77,6 +86,15 @@ def test_two_ranks_real_modules_average_matches_oracle(tmp_path, payload):
     outs.sort(key=lambda o: o["rank"])
     assert outs[0]["nbuckets"] > 2
     assert outs[0]["early"] >= 150           # the backbone's 161 tensors were announced from inside its backward
+    # Overlap by construction: every bucket except the small tail one has been handed to the process group BEFORE the host
+    # enqueues the stem's weight gradient (the last kernel of the backward pass) -- i.e. while the early stages' backward is
+    # still being enqueued, not at the end; the tail bucket (which holds the stem) necessarily follows it.
+    for o in outs:
+        seq = o["order"]
+        stem = max(i for i, e in enumerate(seq) if e[0] == "wgrad" and e[1][1] == 7)          # the 7x7 stem filter (packed 7 x 8 x 4)
+        launched_before = {e[1] for e in seq[:stem] if e[0] == "bucket"}
+        assert launched_before == set(range(o["nbuckets"] - 1)), (sorted(launched_before), o["nbuckets"])
+        assert [e for e in seq[stem:] if e[0] == "bucket"] == [["bucket", o["nbuckets"] - 1]]
     # oracle: the same seeded state, each rank's batch, gradients averaged
     grads = []
     for r in range(2):

@@ -3,10 +3,10 @@
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_optimizer.py tests/test_model_parity.py -q -m gpu -x -k "device_side or dropout_epoch or bf16_gpu" 2>&1 | tail -15 > gpurun_out/r04_s6_tests.txt
 Q="--no-cpu-baseline --no-fidelity --no-roofline --steps 30 --warmup 8"
-for g in on off; do
-  timeout 600 python bench.py $Q --graph $g > gpurun_out/r04_s6_cfg2_graph_$g.json 2> gpurun_out/r04_s6_cfg2_graph_$g.err
-  timeout 600 python bench.py $Q --graph $g --textual transdec_postnorm::L4_H1024_A16_F4096 --batch 128 > gpurun_out/r04_s6_cfg4_graph_$g.json 2> gpurun_out/r04_s6_cfg4_graph_$g.err
-  timeout 600 python bench.py $Q --graph $g --visual torchvision::resnet101 --textual transdec_postnorm::L1_H2048_A32_F8192 --batch 64 > gpurun_out/r04_s6_cfg5_graph_$g.json 2> gpurun_out/r04_s6_cfg5_graph_$g.err
+for g in graph eager; do
+  timeout 600 python bench.py $Q --launch $g > gpurun_out/r04_s6_cfg2_graph_$g.json 2> gpurun_out/r04_s6_cfg2_graph_$g.err
+  timeout 600 python bench.py $Q --launch $g --textual transdec_postnorm::L4_H1024_A16_F4096 --batch 128 > gpurun_out/r04_s6_cfg4_graph_$g.json 2> gpurun_out/r04_s6_cfg4_graph_$g.err
+  timeout 600 python bench.py $Q --launch $g --visual torchvision::resnet101 --textual transdec_postnorm::L1_H2048_A32_F8192 --batch 64 > gpurun_out/r04_s6_cfg5_graph_$g.json 2> gpurun_out/r04_s6_cfg5_graph_$g.err
 done
 cat gpurun_out/r04_s6_tests.txt
 for f in gpurun_out/r04_s6_cfg*_graph_*.json; do echo $f; python -c "

@@ -20,4 +20,16 @@ python tools/rocpd_stats.py $(find gpurun_out/prof_ks -name "*.db" | head -1) 60
 [ -n "$SKIP_PMC" ] || python tools/pmc_traffic.py gpurun_out/pmc_fetch.txt gpurun_out/pmc_write.txt --json gpurun_out/traffic_table.json > gpurun_out/pmc_traffic.txt 2>&1
 find gpurun_out -name "*.db" -delete
 grep -h '^{' gpurun_out/prof_ks.log | tail -1 > gpurun_out/bench_serial.json
+# BASELINE configs 4 and 5 (host-bound at these batch sizes): bench line with the roofline leg + kernel trace each
+C4="--textual transdec_postnorm::L4_H1024_A16_F4096 --batch 128"
+C5="--visual torchvision::resnet101 --textual transdec_postnorm::L1_H2048_A32_F8192 --batch 64"
+python bench.py --no-cpu-baseline --no-fidelity $C4 > gpurun_out/bench_config4.json 2> gpurun_out/bench_config4.err
+python bench.py --no-cpu-baseline --no-fidelity $C5 > gpurun_out/bench_config5.json 2> gpurun_out/bench_config5.err
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_c4 -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --serial-streams --steps 9 --warmup 3 $C4 > $R/gpurun_out/prof_c4.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_c5 -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --serial-streams --steps 9 --warmup 3 $C5 > $R/gpurun_out/prof_c5.log 2>&1
+cd $R
+python tools/rocpd_stats.py $(find gpurun_out/prof_c4 -name "*.db" | head -1) 40 > gpurun_out/kernel_stats_serial_config4.txt
+python tools/rocpd_stats.py $(find gpurun_out/prof_c5 -name "*.db" | head -1) 40 > gpurun_out/kernel_stats_serial_config5.txt
+find gpurun_out -name "*.db" -delete; rm -rf gpurun_out/prof_c4 gpurun_out/prof_c5 gpurun_out/prof_kt gpurun_out/prof_ks gpurun_out/prof_fetch gpurun_out/prof_write
 cat gpurun_out/gpu_tests.txt

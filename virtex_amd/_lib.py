@@ -56,12 +56,22 @@ def is_emulator() -> bool:
     return backend() == "hipemu"
 
 
+_recorder = None     # virtex_amd.replay.Recorder while a step is being recorded (launch replay), else None
+
+
+def set_recorder(rec):
+    global _recorder
+    _recorder = rec
+
+
 def call(name: str, *args):
     """Invoke a C-ABI entry point; raise VtxError(vtx_last_error()) on non-zero status."""
     fn = getattr(lib(), name)
     rc = fn(*args)
     if rc != 0:
         raise VtxError(f"{name} failed ({rc}): {lib().vtx_last_error().decode()}")
+    if _recorder is not None:            # the same call, re-issued by virtex_amd.replay (arguments are ctypes objects: kept as they are)
+        _recorder.add("kernel", lambda f=fn, a=args: f(*a), args)
 
 
 # torch.cuda.current_stream() builds a Stream object through three Python layers (4.4 us per call, 2.5 ms of the 12 ms the
@@ -90,6 +100,8 @@ def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     if t is None:
         return c_void_p(0)
+    if _recorder is not None:
+        _recorder.keep.append(t)         # the recorded launch holds this address: the tensor must outlive the recording
     return c_void_p(t.data_ptr())
 
 

@@ -161,9 +161,9 @@ __global__ void bn_compact_parts_kernel(const float* __restrict__ sums, float* _
 // dependent 5-us launches it replaces, 38 per step, on the critical path of every BatchNorm of stages 1-2): block (x = 32-channel group, y = chunk of `per` strips) folds its chunk into compact strip y as
 // bn_compact_parts_kernel does, publishes it, and draws a ticket; the block that draws the last ticket of its channel group
 // folds the ny compact strips and runs the finalize arithmetic of bn_fwd_finalize_kernel / bn_bwd_finalize_kernel for those
-// 32 channels.  Hand-off = the agent-scope release / acquire recipe of cdna_hip_programming.md (Guideline 16): slab stores,
-// every wave vmcnt(0), block barrier, ONE lane: release fence, vmcnt(0), relaxed agent-scope fetch_add; the last arriver:
-// acquire fence, block barrier, plain loads.  Correct for any placement of the blocks on XCDs.  tickets[x] is zero when
+// 32 channels.  Hand-off = the write-through form of cdna_hip_programming.md (section 5, in-launch split-K reduction): sc1
+// slab stores (relaxed agent-scope atomic stores), every wave vmcnt(0), block barrier, ONE lane: relaxed agent-scope
+// fetch_add; the last arriver reads the slabs with sc1 loads.  Correct for any placement of the blocks on XCDs.  tickets[x] is zero when
 // the launch starts (zero-initialised workspace header) and is put back to zero by the last arriver.
 struct BnFin2Args {
     // forward
@@ -189,18 +189,23 @@ __global__ __launch_bounds__(256) void bn_fin2_kernel(const float* __restrict__ 
     if (grp == 0 && c < C) {
         float t0 = 0.f, t1 = 0.f;
         for (int g = 0; g < NG; ++g) { t0 += red[0][g][threadIdx.x & 31]; t1 += red[1][g][threadIdx.x & 31]; }
+        // write-through (sc1) stores: relaxed agent-scope atomic stores of 4 bytes -- visible to every XCD without a release
+        // fence (the fence form, buffer_wbl2 in every block, measured 0.26 ms/step slower than two launches)
+#ifndef HIPEMU
+        __hip_atomic_store(&compact[(size_t)blockIdx.y * 2 * C + c], t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&compact[(size_t)blockIdx.y * 2 * C + C + c], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         compact[(size_t)blockIdx.y * 2 * C + c] = t0;
         compact[(size_t)blockIdx.y * 2 * C + C + c] = t1;
+#endif
     }
-    // ---- publish the compact strip, draw the ticket
+    // ---- publish the compact strip (every wave: its stores have left), draw the ticket
 #ifndef HIPEMU
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     __syncthreads();
     if (threadIdx.x == 0) {
 #ifndef HIPEMU
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int t = __hip_atomic_fetch_add(&tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
         const int t = atomicAdd(&tickets[blockIdx.x], 1);
@@ -209,14 +214,17 @@ __global__ __launch_bounds__(256) void bn_fin2_kernel(const float* __restrict__ 
     }
     __syncthreads();
     if (!s_last) return;
-#ifndef HIPEMU
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-    __syncthreads();
-    // ---- the last arriver of this channel group: fold the ny compact strips (every block's, through L2), finalize
+    // ---- the last arriver of this channel group: fold the ny compact strips (sc1 loads: straight from the coherent level), finalize
     s0 = s1 = 0.f;
     if (c < C)
-        for (int y = grp; y < ny; y += NG) { s0 += compact[(size_t)y * 2 * C + c]; s1 += compact[(size_t)y * 2 * C + C + c]; }
+        for (int y = grp; y < ny; y += NG) {
+#ifndef HIPEMU
+            s0 += __hip_atomic_load(&compact[(size_t)y * 2 * C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __hip_atomic_load(&compact[(size_t)y * 2 * C + C + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            s0 += compact[(size_t)y * 2 * C + c]; s1 += compact[(size_t)y * 2 * C + C + c];
+#endif
+        }
     red[0][grp][threadIdx.x & 31] = s0; red[1][grp][threadIdx.x & 31] = s1;
     __syncthreads();
     if (threadIdx.x == 0) tickets[blockIdx.x] = 0;              // re-armed for the next launch on this stream

@@ -57,7 +57,7 @@ int g_vtx_sw_wgrad3x3 = getenv("VIRTEX_AMD_WGRAD3X3") ? atoi(getenv("VIRTEX_AMD_
 int g_vtx_sw_stem_stream = getenv("VIRTEX_AMD_STEM_STREAM") ? atoi(getenv("VIRTEX_AMD_STEM_STREAM")) : 1;  // stem.hip
 int g_vtx_sw_expand1x1 = getenv("VIRTEX_AMD_EXPAND1X1") ? atoi(getenv("VIRTEX_AMD_EXPAND1X1")) : 1;        // expand1x1.hip
 int g_vtx_sw_splitk_blocks = getenv("VIRTEX_AMD_SPLITK_BLOCKS") ? atoi(getenv("VIRTEX_AMD_SPLITK_BLOCKS")) : 512;   // split-K block target of the weight gradients
-int g_vtx_sw_bn_fin2 = getenv("VIRTEX_AMD_BN_FIN2") ? atoi(getenv("VIRTEX_AMD_BN_FIN2")) : 0;   // BatchNorm strips > 512: compaction + finalize in one launch (bn_fin2_kernel).  Measured SLOWER (24.66 vs 24.40 ms/step, profiles/r04_ab_bn_fin2.txt): an agent-scope release per block costs more than the 2-us kernel boundary it removes -> off
+int g_vtx_sw_bn_fin2 = getenv("VIRTEX_AMD_BN_FIN2") ? atoi(getenv("VIRTEX_AMD_BN_FIN2")) : 0;   // BatchNorm strips > 512: compaction + finalize in one launch (bn_fin2_kernel).  Measured: with a release fence per block 24.66 vs 24.40 ms/step (profiles/r04_ab_bn_fin2.txt), with write-through stores 24.34 vs 24.31 (r04_ab_bn_fin2_write_through.txt): a dependent 5-us launch costs what it runs, the boundary itself ~2 us -> off (two launches keep the summation order the tests were calibrated on)
 int g_vtx_sw_bn_fin_wide = getenv("VIRTEX_AMD_BN_FIN_WIDE") ? atoi(getenv("VIRTEX_AMD_BN_FIN_WIDE")) : 0;   // 1024-thread BatchNorm finalize / compaction blocks
 // tile rule of the convolutions with BatchNorm epilogues (launch_auto): 0 = the plain picker, 1 = 8-wave 128x128 tiles for every
 // statistics epilogue on large M (rounds 1-2), 2 = only for the forward statistics, 3 = only for the fused backward

@@ -17,6 +17,7 @@ import functools
 from typing import Any, Dict
 
 import torch
+from .replay import traced_backward
 from torch import nn
 
 import os
@@ -30,6 +31,26 @@ from .modules.visual_backbones import VisualBackbone
 # Training path: tied projection + cross-entropy with the logits living only in MFMA accumulators (csrc/tied_ce.hip).
 # "0" selects the round-1 path (fp32 logits written by the GEMM, read twice by the loss kernels) for A/B runs.
 FUSED_TIED_CE = os.environ.get("VIRTEX_AMD_FUSED_CE", "1") != "0"
+
+
+class _FanoutFn(torch.autograd.Function):
+    """y1, y2 = x, x -- with the SUM of the two gradients computed by the library (vtx_add) instead of by the autograd engine,
+    and the stream dependency of that sum made explicit (the second consumer's backward runs on the branch stream).  Same
+    arithmetic as the engine's accumulation; it exists so that every launch of the step is visible to virtex_amd.replay."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    @traced_backward
+    def backward(ctx, d1, d2):
+        if d1 is None or d2 is None:
+            return d1 if d2 is None else d2
+        from . import ops
+        from .streams import branch_stream
+        branch_stream.join(d2.device)
+        return ops.add(d1.contiguous(), d2.contiguous())
 
 
 class _FusedTiedCrossEntropyFn(torch.autograd.Function):
@@ -52,6 +73,7 @@ class _FusedTiedCrossEntropyFn(torch.autograd.Function):
         return lc[0].clone()
 
     @staticmethod
+    @traced_backward
     def backward(ctx, gout):
         h2, targets, lse, lc = ctx.saved_tensors
         B, T, H, V, padding_idx, dt = ctx.cfg
@@ -85,6 +107,7 @@ class _TiedCrossEntropyFn(torch.autograd.Function):
         return lc[0].clone()
 
     @staticmethod
+    @traced_backward
     def backward(ctx, gout):
         h2, weight, targets, logits, lse, lc = ctx.saved_tensors
         B, T, H, V, padding_idx, dt = ctx.cfg
@@ -194,6 +217,9 @@ class CaptioningModel(nn.Module):
                     and self.backward_textual.visual_projection is self.textual.visual_projection):
                 # both heads read the same projected grid: evaluate the shared projection once
                 memory = self.textual.project_visual_features(visual_features)
+            memory_b = memory
+            if memory is not None and self.training and torch.is_grad_enabled() and memory.requires_grad:
+                memory, memory_b = _FanoutFn.apply(memory)          # the fan-in of the two heads' gradients stays in the library
             backward_loss = None
             if self.training:
                 if self.caption_backward and HEAD_STREAMS:
@@ -205,11 +231,11 @@ class CaptioningModel(nn.Module):
                     # attached both chains run 11.85 -> 14.8 ms side by side in either order; the one-after-the-other
                     # picture in rocprofv3 kernel traces is an artefact of the tracer).
                     br = branch_stream(visual_features.device, visual_features, batch["noitpac_tokens"], caption_lengths,
-                                       *([memory] if memory is not None else []))
+                                       *([memory_b] if memory_b is not None else []))
                     if HEAD_ORDER_BRANCH_FIRST:
                         with br:
                             backward_loss = self._head_loss(self.backward_textual, visual_features,
-                                                            batch["noitpac_tokens"], caption_lengths, memory)
+                                                            batch["noitpac_tokens"], caption_lengths, memory_b)
                     else:
                         br.mark()
                 loss = self._head_loss(self.textual, visual_features, caption_tokens, caption_lengths, memory)
@@ -224,11 +250,11 @@ class CaptioningModel(nn.Module):
                     if backward_loss is None:
                         with br:
                             backward_loss = self._head_loss(self.backward_textual, visual_features,
-                                                            backward_caption_tokens, caption_lengths, memory)
+                                                            backward_caption_tokens, caption_lengths, memory_b)
                     br.wait(backward_loss)
                 elif self.training:
                     backward_loss = self._head_loss(self.backward_textual, visual_features,
-                                                    backward_caption_tokens, caption_lengths, memory)
+                                                    backward_caption_tokens, caption_lengths, memory_b)
                 else:
                     backward_loss = _logits_loss(
                         self.backward_textual(visual_features, backward_caption_tokens, caption_lengths),

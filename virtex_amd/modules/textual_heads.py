@@ -18,6 +18,7 @@ MFMA GEMMs with fused bias/GELU/dropout epilogues, one fused attention kernel pe
 import itertools
 
 import torch
+from ..replay import traced_backward
 from torch import nn
 
 from .. import gradsink, ops
@@ -66,6 +67,7 @@ class _EmbeddingFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @traced_backward
     def backward(ctx, dout):
         tokens, words, positions, gamma, mean, rstd = ctx.saved_tensors
         padding_idx, p, seed = ctx.cfg
@@ -239,6 +241,7 @@ class _VisualProjectionFn(torch.autograd.Function):
         return mem
 
     @staticmethod
+    @traced_backward
     def backward(ctx, dmem):
         weight, bias = ctx.owner
         dt = ctx.dt
@@ -328,6 +331,7 @@ class _DecoderFn(torch.autograd.Function):
         return x.view(B, T, H)
 
     @staticmethod
+    @traced_backward
     def backward(ctx, dhid):
         head, p = ctx.head, ctx.p
         B, T, S, H, A = ctx.dims
@@ -483,6 +487,7 @@ class _OutputProjectionFn(torch.autograd.Function):
         return logits.view(B, T, -1)
 
     @staticmethod
+    @traced_backward
     def backward(ctx, dlogits):
         hidden, weight = ctx.saved_tensors
         B, T, H = hidden.shape

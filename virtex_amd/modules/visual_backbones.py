@@ -17,6 +17,7 @@ import os
 
 
 import torch
+from ..replay import traced_backward
 from torch import nn
 
 from .. import gradsink, ops
@@ -455,6 +456,7 @@ class _ResNetFn(torch.autograd.Function):
         return cur.permute(0, 3, 1, 2)  # logical NCHW, physical NHWC
 
     @staticmethod
+    @traced_backward
     def backward(ctx, dfeat):
         module, rec = ctx.module, ctx.rec
         dt = module.compute_dtype

@@ -1,0 +1,272 @@
+"""Launch replay: the training step re-issued from a recorded launch list instead of re-running its Python.
+
+The step of `scripts/pretrain_virtex.py:145-163` is ~1 100 kernel launches on three HIP streams; producing them costs the host
+~10 ms of Python per step (tools/host_profile.py: autograd, argument marshalling, allocator calls) -- hidden behind the GPU at 256
+images per step, the LIMIT at 64-128 (BASELINE configs 4 and 5).  A hipGraph of the step removes that cost but replays
+SLOWER on ROCm 7.2 (profiles/r04_hipgraph_configs_2_4_5.txt: the captured side-stream branches run one after the other).
+`StepReplay` keeps the eager launches -- same kernels, same three streams, same events -- and removes only the Python:
+
+  record   one eager step runs with every C-ABI call (`_lib.call`: function pointer + ctypes arguments), every stream / event
+           operation (event record / wait, stream switch, wait_stream) and every ATen operator that launches work (fills,
+           copies, the few adds) appended to ONE ordered list; every tensor that took part stays alive, so device addresses in
+           the recorded arguments stay valid;
+  replay   the list is re-issued in order: ~1 400 prebuilt calls, no autograd, no allocation, no shape logic.
+
+What makes a replay a faithful NEXT step rather than a repetition (the same three things a hipGraph needs, virtex_amd/graph.py):
+dropout masks advance through the device epoch mixed into the seeds by the kernels, the LR multiplier and the Lookahead phase
+are computed on the device (`FusedPretrainOptimizer.enable_device_schedule`), BatchNorm's counters live on the device.
+Work the autograd ENGINE launches by itself cannot be recorded; the model routes the one such operation of the step (the sum
+of the two heads' gradients of the shared visual projection) through a Function of its own.  Construction VALIDATES the
+recording: from identical state and batch the replayed step must reproduce the eager step's loss, gradients and updated
+parameters bit for bit (dropout off during the check), else the caller keeps the eager step.
+
+Single process only (the data-parallel all-reduces are torch.distributed calls issued from autograd hooks).
+"""
+import threading
+from typing import Callable, Dict, List, Optional
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+from . import _lib
+
+_VIEW_NAMES = {"view", "_unsafe_view", "reshape", "permute", "transpose", "t", "slice", "select", "detach", "alias", "expand",
+               "as_strided", "unsqueeze", "squeeze", "split", "split_with_sizes", "unbind", "chunk", "narrow", "view_as",
+               "unfold", "diagonal", "movedim", "swapaxes", "flatten", "unflatten", "lift_fresh", "_reshape_alias", "real"}
+_NO_WORK = {"empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "_local_scalar_dense", "is_same_size",
+            "sym_size", "sym_stride", "sym_numel", "stride", "size", "numel", "dim", "is_contiguous", "record_stream",
+            "_has_compatible_shallow_copy_type", "is_pinned", "set_", "resize_"}
+
+
+class Recorder:
+    """The ordered launch list of one step.  Appended to from the main thread and from autograd's worker thread (the backward
+    pass runs there; the two never run at the same time)."""
+
+    def __init__(self):
+        self.ops: List[Callable[[], None]] = []
+        self.keep = []                   # tensors / ctypes objects whose memory the recorded arguments point into
+        self.lock = threading.Lock()
+        self.counts = {"kernel": 0, "aten": 0, "stream": 0}
+
+    def add(self, kind, thunk, *keep):
+        with self.lock:
+            self.ops.append(thunk)
+            self.keep.extend(keep)
+            self.counts[kind] += 1
+
+
+_active: Optional[Recorder] = None
+
+
+def active() -> Optional[Recorder]:
+    return _active
+
+
+class _RecordAten(TorchDispatchMode):
+    """Every ATen operator that launches device work, as a thunk that repeats it INTO the tensors the recording produced."""
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        out = func(*args, **kwargs)
+        rec = _active
+        if rec is None:
+            return out
+        name = func._schema.name.split("::")[-1]
+        if name in _VIEW_NAMES or name in _NO_WORK:
+            return out
+        flat_in = [a for a in list(args) + list(kwargs.values()) if isinstance(a, torch.Tensor)]
+        outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if isinstance(o, torch.Tensor)]
+        if not any(t.is_cuda for t in flat_in + outs) and flat_in + outs and not _lib.is_emulator():
+            return out                                   # host-side tensor arithmetic: no device work to repeat
+        if func._schema.is_mutable:                      # in-place / out= : repeat as it was
+            rec.add("aten", lambda f=func, a=args, k=kwargs: f(*a, **k), args, kwargs, out)
+        elif any(r.alias_info is not None for r in func._schema.returns):
+            return out                                   # a view the table above does not know
+        elif outs:                                       # functional: recompute, store into the recorded result
+            if len(outs) == 1:
+                rec.add("aten", lambda f=func, a=args, k=kwargs, o=outs[0]: o.copy_(f(*a, **k)), args, kwargs, out)
+            else:
+                def thunk(f=func, a=args, k=kwargs, os_=outs):
+                    r = f(*a, **k)
+                    r = [x for x in (r if isinstance(r, (tuple, list)) else (r,)) if isinstance(x, torch.Tensor)]
+                    for o, x in zip(os_, r):
+                        o.copy_(x)
+                rec.add("aten", thunk, args, kwargs, out)
+        return out
+
+
+def traced_backward(fn):
+    """Decorator for the backward of the library's autograd Functions: autograd calls them on its own thread, where the
+    recording dispatch mode of the main thread is not active."""
+    def wrapper(ctx, *grads):
+        if _active is not None:
+            with _RecordAten():
+                return fn(ctx, *grads)
+        return fn(ctx, *grads)
+    wrapper.__name__ = getattr(fn, "__name__", "backward")
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
+class _Patches:
+    """Stream / event operations of torch.cuda recorded at the level every caller goes through."""
+
+    def __init__(self, rec: Recorder):
+        self.rec = rec
+        self.saved = []
+        self.tl = threading.local()
+
+    def _wrap(self, owner, name, bound: bool):
+        orig = getattr(owner, name)
+        rec = self.rec
+
+        tl = self.tl
+
+        if bound:                        # (wait_stream is record_event + wait_event inside: only the outermost call is recorded)
+            def wrapped(self_, *a, **k):
+                depth = getattr(tl, "depth", 0)
+                tl.depth = depth + 1
+                try:
+                    r = orig(self_, *a, **k)
+                finally:
+                    tl.depth = depth
+                if depth == 0:
+                    rec.add("stream", lambda s=self_, a=a, k=k: orig(s, *a, **k), self_, a, k)
+                return r
+        else:
+            def wrapped(*a, **k):
+                depth = getattr(tl, "depth", 0)
+                tl.depth = depth + 1
+                try:
+                    r = orig(*a, **k)
+                finally:
+                    tl.depth = depth
+                if depth == 0:
+                    rec.add("stream", lambda a=a, k=k: orig(*a, **k), a, k)
+                return r
+        self.saved.append((owner, name, orig))
+        setattr(owner, name, wrapped)
+
+    def __enter__(self):
+        if torch.cuda.is_available():
+            self._wrap(torch.cuda.Event, "record", True)
+            self._wrap(torch.cuda.Event, "wait", True)
+            self._wrap(torch.cuda.Stream, "wait_event", True)
+            self._wrap(torch.cuda.Stream, "wait_stream", True)
+            if hasattr(torch._C, "_cuda_setStream"):
+                self._wrap(torch._C, "_cuda_setStream", False)
+                from . import streams                         # (streams.py holds its own reference to the raw setter)
+                if getattr(streams, "_set_cur", None) is not None:
+                    self.saved.append((streams, "_set_cur", streams._set_cur))
+                    streams._set_cur = torch._C._cuda_setStream
+        return self
+
+    def __exit__(self, *exc):
+        for owner, name, orig in reversed(self.saved):
+            setattr(owner, name, orig)
+        return False
+
+
+def record(step_fn: Callable[[], torch.Tensor]):
+    """Run `step_fn` once, recording it.  Returns (recorder, the step's result)."""
+    global _active
+    rec = Recorder()
+    with _Patches(rec):
+        _active = rec
+        _lib.set_recorder(rec)
+        try:
+            with _RecordAten():
+                out = step_fn()
+        finally:
+            _active = None
+            _lib.set_recorder(None)
+    return rec, out
+
+
+class StepReplay:
+    """step = StepReplay(model, buckets, optimizer, example_batch); loss = step(batch)
+
+    `validate`: compare one replayed step with one eager step from identical state (parameters, optimizer state, BatchNorm
+    buffers, device counters) on the example batch, dropout off -- raises RuntimeError when anything differs."""
+
+    def __init__(self, model: torch.nn.Module, buckets, optimizer, example_batch: Dict[str, torch.Tensor], warmup: int = 2,
+                 validate: bool = True):
+        if getattr(buckets, "enabled", False):
+            raise ValueError("StepReplay is single-process: the gradient exchange of N > 1 stays on the eager path")
+        self.model, self.buckets, self.opt = model, buckets, optimizer
+        self.static = {k: v.clone() for k, v in example_batch.items()}
+        optimizer.enable_device_schedule()
+        for _ in range(max(1, warmup)):
+            self._eager()
+        self._sync()
+        if validate:
+            self._validate()
+        self.rec, self.loss = record(self._eager)
+        self._sync()
+        self.replays = 0
+
+    # ---- the step
+    def _eager(self) -> torch.Tensor:
+        self.buckets.zero(); self.buckets.begin()
+        out = self.model(self.static)
+        out["loss"].backward()
+        self.opt.step(grad_scale=self.buckets.finish())
+        return out["loss"].detach()
+
+    def _replay(self):
+        for op in self.rec.ops:
+            op()
+
+    def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+        if batch is not None:
+            for k, v in self.static.items():
+                v.copy_(batch[k], non_blocking=True)
+        self._replay()
+        self.replays += 1
+        return self.loss
+
+    def sync(self):
+        """Refresh the host-side mirrors after replays (optimizer step index, parameter version counters)."""
+        self.opt.sync_host()
+
+    def _sync(self):
+        dev = next(self.model.parameters()).device
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    # ---- validation: eager step vs replayed step from the same state
+    def _state(self):
+        ts = [self.opt.flat_p, self.opt.flat_m, self.opt.flat_slow, self.opt.dev["step"], self.opt.dev["kc"], self.opt.dev["epoch"]]
+        ts += [b for b in self.model.buffers()]
+        return ts
+
+    def _validate(self):
+        saved = [t.clone() for t in self._state()]
+        rec, loss_rec = record(self._eager)                  # step A: eager (recorded)
+        self._sync()
+        after_a = [t.clone() for t in self._state()]
+        grads_a = self.buckets.flat.clone()
+        loss_a = loss_rec.clone()
+        for t, s in zip(self._state(), saved):
+            t.copy_(s)
+        for op in rec.ops:                                   # step B: the recording replayed from the same state
+            op()
+        self._sync()
+
+        def close(a, b):                                     # (the embedding's fp32 atomics reorder sums: 1e-7 relative)
+            if a.dtype.is_floating_point:
+                scale = max(a.abs().max().item(), 1e-30)
+                return (a.double() - b.double()).abs().max().item() <= 2e-5 * scale
+            return torch.equal(a, b)
+        bad = []
+        if not close(loss_a, loss_rec):
+            bad.append(f"loss {loss_a.item()} vs {loss_rec.item()}")
+        if not close(grads_a, self.buckets.flat):
+            d = (grads_a - self.buckets.flat).abs().max().item()
+            bad.append(f"gradients differ (max abs {d:.3e} of {grads_a.abs().max().item():.3e})")
+        for i, (a, b) in enumerate(zip(after_a, self._state())):
+            if not close(a, b):
+                bad.append(f"state tensor {i} differs")
+        self.validated = {"ops": len(rec.ops), **rec.counts}
+        if bad:
+            raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step: " + "; ".join(bad[:4]))
