@@ -89,7 +89,8 @@ def test_bench_through_rccl_with_one_rank(payload):
     The result must equal the plain single-process run bit for bit in fp32 payload mode (a 1-rank SUM is the identity)."""
     import json
     args = ["--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8", "--image-size", "64", "--vocab-size", "1000",
-            "--textual", "transdec_postnorm::L1_H128_A2_F256", "--no-cpu-baseline", "--roofline-steps", "1", "--dropout", "0.0"]
+            "--textual", "transdec_postnorm::L1_H128_A2_F256", "--no-cpu-baseline", "--roofline-steps", "1", "--dropout", "0.0",
+            "--launch", "eager"]        # (launch replay is single-process: both runs issue the eager step, the same number of times)
     def run(extra_env):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
