@@ -103,7 +103,22 @@ def load_traffic_table():
         print("bench.py: ERROR -- profiles/traffic_table.json was measured on different kernel sources (sha256 mismatch): "
               "roofline.traffic = null until tools/round_end.sh regenerates it", file=sys.stderr)
         return {}, None
-    return t.get("per_launch_bytes", {}), f"profiles/traffic_table.json ({t.get('source')}; {t.get('rule')})"
+    table = dict(t.get("per_launch_bytes", {}))
+    table["__per_kernel__"] = t.get("per_kernel", {})
+    return table, f"profiles/traffic_table.json ({t.get('source')}; {t.get('rule')})"
+
+
+def lookup_traffic(table, name, n_classes, launches_per_step):
+    """HBM bytes per launch of the kernel the focused pass timed.  A launch family of ONE instantiation: the family's entry.
+    A family of several (bn_bwd_apply: the flat kernel at two unrolls, the pooled one): the focused pass timed the largest
+    single instantiation, identified in the table by its launches per step.  -> (bytes or None, kernel name or None)"""
+    per_kernel = table.get("__per_kernel__", {}).get(name)
+    if n_classes > 1 and per_kernel and launches_per_step is not None:
+        hits = [(k, v) for k, v in per_kernel.items() if abs(v["launches_per_step"] - launches_per_step) < 0.5]
+        if len(hits) == 1:
+            return hits[0][1]["bytes"], hits[0][0]
+        return None, None                         # ambiguous: better no figure than one for a different mix of launches
+    return table.get(name), None
 
 
 def _kernel_name(bracket):
@@ -164,7 +179,7 @@ def merge_classes(recs):
     return out
 
 
-def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1):
+def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1, focused_steps=None):
     """Roofline of the step's dominant kernel, measured LIVE: HIP events attached to every launch of the step function
     the timed region runs (`recs` = ops.profile_stop() of `survey_steps` fully timed steps).  The dominant kernel is the
     one with the largest summed time; achieved = its algorithmic FLOPs (or bytes) / its summed launch time; the binding
@@ -183,11 +198,12 @@ def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1):
     f_mfma, f_hbm = tf / peak_tf, tbs / PEAK_HBM_TBS
     bound = "mfma" if f_mfma >= f_hbm else "hbm"
     table, table_source = load_traffic_table() if default_workload else ({}, None)
-    traffic = table.get(dom["name"])
+    per_step = dom["launches"] / focused_steps if (focused is not None and focused_steps) else None
+    traffic, instantiation = lookup_traffic(table, dom["name"], len(dom["cls"]) if focused is not None else 1, per_step)
     if default_workload and table_source and traffic is None:
         print(f"bench.py: ERROR -- profiles/traffic_table.json has no entry for the dominant kernel {dom['name']!r}; "
               "reporting traffic = null", file=sys.stderr)
-    out = {"bound": bound, "kernel": dom["name"],
+    out = {"bound": bound, "kernel": instantiation or dom["name"],
            "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": peak_tf if bound == "mfma" else PEAK_HBM_TBS * 1e3,
            "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(max(f_mfma, f_hbm), 4),
            "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -474,7 +490,10 @@ def main(argv=None, device=None, backend=None):
                                    "30-tok captions, full step (fwd+bwd+clip+SGD+Lookahead), dropout "
                                    f"{a.dropout}", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "launch": launch_mode,
-                       "host_enqueue_ms_per_step": round(host_issue / a.steps * 1e3, 3)},
+                       "host_enqueue_ms_per_step": round(host_issue / a.steps * 1e3, 3),
+                       "host_enqueue_note": "wall time of the issuing loop / steps; a host faster than the GPU spends the difference "
+                                            "blocked on the full HIP queue, so a value near ms_per_step means 'host not the limit' "
+                                            "(un-blocked cost: profiles/r04_launch_replay_configs_2_4_5.txt)"},
         }
         if comm_exposed is not None:
             rec["data_parallel"] = {"comm_exposed_ms_per_rank": comm_exposed, "payload": buckets.payload,
@@ -493,7 +512,8 @@ def main(argv=None, device=None, backend=None):
                 if rec["roofline"]:
                     rec["roofline"]["measured"] = "inside the timed region"
             else:
-                rec["roofline"] = step_roofline(survey, a.dtype, default_workload, focused[0] if focused else None)
+                rec["roofline"] = step_roofline(survey, a.dtype, default_workload, focused[0] if focused else None,
+                                                focused_steps=a.roofline_steps)
                 if rec["roofline"]:
                     rec["roofline"]["measured"] = (f"{a.roofline_steps} further steps right after the timed region, side streams off, "
                                                    "begin/end HIP events on this kernel class only (class chosen from one fully timed step)")

@@ -86,7 +86,17 @@ def test_traffic_table_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch, cap
     assert table == {} and src is None and "different kernel sources" in capsys.readouterr().err
     p.write_text(json.dumps({"csrc_sha256": csrc_hash(), "per_launch_bytes": {"k": 1.0}, "source": "s", "rule": "r"}))
     table, src = bench.load_traffic_table()
-    assert table == {"k": 1.0} and "traffic_table.json" in src
+    assert table["k"] == 1.0 and "traffic_table.json" in src
+    # a launch family of several instantiations: the focused pass of bench.py times ONE of them, found by launches per step
+    p.write_text(json.dumps({"csrc_sha256": csrc_hash(), "per_launch_bytes": {"fam": 300.0, "solo": 7.0}, "source": "s", "rule": "r",
+                             "per_kernel": {"fam": {"kern<2>": {"launches_per_step": 47.0, "bytes": 229.0},
+                                                    "kern<4>": {"launches_per_step": 4.0, "bytes": 1233.0}}}}))
+    table, src = bench.load_traffic_table()
+    assert bench.lookup_traffic(table, "fam", 2, 47.0) == (229.0, "kern<2>")
+    assert bench.lookup_traffic(table, "fam", 2, 4.2) == (1233.0, "kern<4>")
+    assert bench.lookup_traffic(table, "fam", 2, 20.0) == (None, None)          # no instantiation launches that often: no figure
+    assert bench.lookup_traffic(table, "fam", 1, None) == (300.0, None)          # the whole family was timed
+    assert bench.lookup_traffic(table, "solo", 1, 3.0) == (7.0, None)
     # the class names bench.py derives from the library's profile classes: generation 2 by tile, generation 3 by kernel
     assert bench._kernel_name("[BM = 256, BN = 128, WM = 4, WN = 2, BK = 32, STAGES = 3, AL = vtxg::PlainKC<unsigned short, 2>, "
                               "BL = vtxg::PlainKC<unsigned short, 1>, EP = vtxg::EpiStore<unsigned short, 2>]") == \

@@ -70,16 +70,22 @@ for total, n, f, w, k in sorted(rows, reverse=True):
 if json_out:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from virtex_amd.build import csrc_hash
-    agg = {}
+    agg, per_kernel = {}, {}
+    steps = max([n for total, n, f, w, k in rows if short(k).startswith("sgd_lookahead_kernel")] or [1])     # one optimizer launch per step
     for total, n, f, w, k in rows:
         c = class_name(k)
         a = agg.setdefault(c, [0.0, 0])
         a[0] += total; a[1] += n
+        per_kernel.setdefault(c, {})[k] = {"launches_per_step": round(n / steps, 2), "bytes": round(total / n, 1)}
     table = {"csrc_sha256": csrc_hash(),
              "rule": "bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024, separate rocprofv3 --pmc passes of `python bench.py` (MI355X_MICROARCH.md, HBM)",
              "source": os.path.basename(args[0]) + " + " + os.path.basename(args[1]),
              "per_launch_bytes": {c: round(t / n, 1) for c, (t, n) in sorted(agg.items()) if n > 0},
-             "launches_profiled": {c: n for c, (t, n) in sorted(agg.items())}}
+             "launches_profiled": {c: n for c, (t, n) in sorted(agg.items())},
+             # a launch family of several instantiations (bn_bwd_apply = the flat kernel at two unrolls + the pooled one): bench.py's
+             # focused pass times ONE of them and looks its bytes up here by launches per step
+             "steps_profiled": steps,
+             "per_kernel": {c: v for c, v in sorted(per_kernel.items()) if len(v) > 1}}
     with open(json_out, "w") as fh:
         json.dump(table, fh, indent=1, sort_keys=True)
         fh.write("\n")
