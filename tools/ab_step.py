@@ -7,6 +7,7 @@ switches of virtex_amd.modules.visual_backbones / models, interleaved round afte
 FLAG is an attribute of visual_backbones (FUSE_STEM_FWD, RELU_BITS, STEM_STATS, ...) or `models.X` / `textual.X`.
 Prints per variant: every round's ms/step, the minimum and the median."""
 import argparse
+import contextlib
 import os
 import sys
 import time
@@ -58,7 +59,9 @@ def main():
         kv, sw, lib = [], [], default_lib
         for f in filter(None, flags.split(",")):
             k, val = f.split("=")
-            if k == "serial":                       # serial=1: every kernel on the compute stream (what the kernels cost without overlap)
+            if k in ("wgrad_cus", "branch_cus", "compute_cus"):   # CU-masked streams: wgrad [0, n), branch [0, n), compute [256 - n, 256)
+                kv.append(("__" + k + "__", None, int(val)))
+            elif k == "serial":                       # serial=1: every kernel on the compute stream (what the kernels cost without overlap)
                 kv.append(("__serial__", None, int(val)))
             elif k == "lib":
                 lib = val if os.path.isabs(val) else os.path.join(os.path.dirname(_lib.DEFAULT_LIB), val)
@@ -74,7 +77,24 @@ def main():
         _streams.wgrad_stream.enabled = not on
         _streams.branch_stream.enabled = not on
         models.HEAD_STREAMS = not on
-    defaults = {(m, k): getattr(m, k) for _, kv, _, _ in variants for m, k, _ in kv if m != "__serial__"}
+    plain = {"wgrad": None, "branch": None}
+    masked = {}
+
+    def _set_masks(w, b):
+        """swap the side streams of the device for CU-masked ones (0 = the ordinary streams)"""
+        torch.cuda.synchronize()
+        if plain["wgrad"] is None:
+            plain["wgrad"] = _streams.wgrad_stream.side(dev)
+            plain["branch"] = _streams.branch_stream.side(dev)
+        for kind, n, table in (("wgrad", w, _streams._side_streams), ("branch", b, _streams._branch_streams)):
+            if n:
+                if (kind, n) not in masked:
+                    masked[(kind, n)] = _streams.masked_stream(dev, 0, n)
+                table[dev] = masked[(kind, n)]
+            else:
+                table[dev] = plain[kind]
+    compute_streams = {}
+    defaults = {(m, k): getattr(m, k) for _, kv, _, _ in variants for m, k, _ in kv if not (isinstance(m, str) and m.startswith("__"))}
     sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512, "mc_eff128": 84, "bn_fin_wide": 0, "stats_tile": 0, "bn_adj": 1, "bn_grid": 8192, "tile64x256": 1, "tile_order": 0, "conv3x3_shared": 1, "gen3": 80, "gen3_mc": 200}
     res = {n: [] for n, _, _, _ in variants}
     for r in range(a.rounds):
@@ -89,19 +109,27 @@ def main():
             for (m, k), d in defaults.items():
                 setattr(m, k, d)
             _set_serial(False)
+            masks = {"wgrad": 0, "branch": 0, "compute": 0}
             for m, k, val in kv:
                 if m == "__serial__":
                     _set_serial(bool(val))
+                elif isinstance(m, str):
+                    masks[m.strip("_").split("_")[0]] = val
                 else:
                     setattr(m, k, val)
-            for i in range(a.warmup):
-                step(i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(a.steps):
-                step(i)
-            torch.cuda.synchronize()
-            res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
+            _set_masks(masks["wgrad"], masks["branch"])
+            cs = None
+            if masks["compute"]:
+                cs = compute_streams.setdefault(masks["compute"], _streams.masked_stream(dev, 256 - masks["compute"], 256))
+            with torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext():
+                for i in range(a.warmup):
+                    step(i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(a.steps):
+                    step(i)
+                torch.cuda.synchronize()
+                res[name].append((time.perf_counter() - t0) / a.steps * 1e3)
     for name, _, _, _ in variants:
         v = sorted(res[name])
         print(f"{name:28s} " + " ".join(f"{x:7.3f}" for x in res[name]) + f"   min {v[0]:7.3f}  median {v[len(v) // 2]:7.3f} ms/step", flush=True)

@@ -60,6 +60,33 @@ def _restore_stream(prev):
         prev.__exit__(None, None, None)
 
 
+_hip = None
+_masked = []        # (handle, ExternalStream): masked streams live for the life of the process
+
+
+def masked_stream(device, lo, hi):
+    """A HIP stream whose kernels may only occupy compute units [lo, hi) of the device's 256 (hipExtStreamCreateWithCUMask),
+    wrapped for torch.  Measurement aid (tools/ab_step.py `wgrad_cus=` / `compute_cus=`, tools/cu_mask_probe.py): partitions the
+    chip between the compute stream and a side stream instead of letting their blocks share compute units.  Measured in round 4
+    and NOT used: the mask is honoured (a GEMM scales with the CUs it is given, 128 CUs still copy at 5.2 of 5.6 TB/s), but the
+    step runs 43-80 ms instead of 24 ms with any masked stream in it (profiles/r04_cu_masked_streams.txt)."""
+    import ctypes
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+    words = (ctypes.c_uint32 * 8)()
+    for b in range(lo, hi):
+        words[b // 32] |= 1 << (b % 32)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        err = _hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(8), words)
+    if err != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask: error {err}")
+    st = torch.cuda.ExternalStream(h.value, device=device)
+    _masked.append((h, st))
+    return st
+
+
 class wgrad_stream:
     """Context manager: run weight-gradient GEMMs (off the critical path of backward: nothing downstream
     reads them until the optimizer) on a side HIP stream, concurrently with the input-gradient chain.
