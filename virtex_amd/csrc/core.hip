@@ -61,7 +61,7 @@ int g_vtx_sw_bn_fin2 = getenv("VIRTEX_AMD_BN_FIN2") ? atoi(getenv("VIRTEX_AMD_BN
 int g_vtx_sw_bn_fin_wide = getenv("VIRTEX_AMD_BN_FIN_WIDE") ? atoi(getenv("VIRTEX_AMD_BN_FIN_WIDE")) : 0;   // 1024-thread BatchNorm finalize / compaction blocks
 // tile rule of the convolutions with BatchNorm epilogues (launch_auto): 0 = the plain picker, 1 = 8-wave 128x128 tiles for every
 // statistics epilogue on large M (rounds 1-2), 2 = only for the forward statistics, 3 = only for the fused backward
-namespace vtxg { int g_vtx_sw_stats_tile = getenv("VIRTEX_AMD_STATS_TILE") ? atoi(getenv("VIRTEX_AMD_STATS_TILE")) : 0; }
+namespace vtxg { int g_vtx_sw_stats_tile = getenv("VIRTEX_AMD_STATS_TILE") ? atoi(getenv("VIRTEX_AMD_STATS_TILE")) : 4; }
 int g_vtx_sw_bn_adj = getenv("VIRTEX_AMD_BN_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_ADJ")) : 1;      // flat BatchNorm apply kernels: adjacent vectors per trip
 int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN_GRID")) : 8192;  // ... and their grid cap
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h

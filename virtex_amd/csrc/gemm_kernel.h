@@ -1784,6 +1784,17 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
         const int rule = g_vtx_sw_stats_tile;
         const bool stats_tile = rule == 1 || (rule == 2 && EP::SMODE == STATS_FWD) || (rule == 3 && EP::SMODE == STATS_BWD);
         if (stats_tile && v2 && c == 1 && g_vtx_tile_override < 0 && M >= 100000) c = 6;
+        // Round 4, after the lean epilogues: the 1x1 input gradients with the fused BatchNorm backward are faster on FOUR-wave
+        // 128x128 tiles (48 KiB of stages: three blocks per CU) at every image size the generation-3 picker leaves to this
+        // kernel -- residual joins (mask bits + identity gradient, tools/bench_join_tiles.py) 301 -> 252 us (K 64, N 256 @56),
+        // 173 -> 145 (128, 512 @28), 112 -> 94 (256, 1024 @14), 62 -> 55 (512, 2048 @7); mask recomputed from x 125 -> 87
+        // (128 -> 512 @28), 86 -> 75 (512 -> 128 @28) (profiles/r04_join_tiles.txt).  vtx_set_switch("stats_tile", 4); 0 = off.
+        // (4 + bit 0: the forward statistics class too; 4 + bit 1: every A loader, not only plain rows -- sweeps)
+        if (rule >= 4 && v2 && c == 1 && g_vtx_tile_override < 0) {
+            const bool plain = std::is_same<ALT<T, 1>, PlainKC<T, 1>>::value;
+            const bool bwd = EP::SMODE == STATS_BWD, fwd = EP::SMODE == STATS_FWD && ((rule - 4) & 1);
+            if ((bwd || fwd) && (plain || ((rule - 4) & 2))) c = 2;
+        }
     }
     if constexpr (BF && ALT<T, 1>::MC) {
         // Weight gradients of layers with at most 64 output channels and 129...256 rows of taps x channels (the stem: 64 x 224
