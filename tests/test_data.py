@@ -47,6 +47,35 @@ def test_collate_equals_live_reference():
         assert torch.equal(ref[k], ours[k]), k
 
 
+def test_fixed_length_collation_leaves_the_loss_and_the_gradients_alone():
+    """collate_captions(pad_to=T) gives every batch one shape (what launch replay needs); the extra padding columns are masked
+    in attention, zeroed by the embedding and ignored by the loss: same loss, same gradients as the reference collation
+    (the ORACLE model on CPU, fp32 -- the property is the reference's, not a kernel's)."""
+    from oracle import bicaptioning as port
+    g = torch.Generator().manual_seed(5)
+    items = []
+    for i, L in enumerate((3, 6, 4)):
+        toks = torch.randint(4, 300, (L,), generator=g).tolist()
+        items.append(vdata.caption_instance(i, torch.randn(3, 64, 64, generator=g), toks, max_caption_length=12))
+    short = vdata.collate_captions(items)
+    fixed = vdata.collate_captions(items, pad_to=12)
+    assert short["caption_tokens"].shape == (3, 8) and fixed["caption_tokens"].shape == (3, 12)
+    assert torch.equal(fixed["caption_tokens"][:, :8], short["caption_tokens"]) and (fixed["caption_tokens"][:, 8:] == 0).all()
+    assert torch.equal(fixed["caption_lengths"], short["caption_lengths"])
+    torch.manual_seed(0)
+    model = port.build_model(textual="transdec_postnorm::L1_H128_A2_F256", vocab_size=304, max_caption_length=12, dropout=0.0).train()
+    grads = []
+    for b in (short, fixed):
+        model.zero_grad(set_to_none=True)
+        out = model(b)
+        out["loss"].backward()
+        grads.append((out["loss"].item(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 * abs(grads[0][0])
+    for n, ga in grads[0][1].items():
+        gb = grads[1][1][n]
+        assert torch.allclose(ga, gb, rtol=1e-4, atol=1e-7), n
+
+
 def test_cycle_moves_batches_and_restarts():
     items = _items(6)
     loader = torch.utils.data.DataLoader(items, batch_size=4, collate_fn=vdata.collate_captions)

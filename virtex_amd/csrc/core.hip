@@ -67,6 +67,7 @@ int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
 namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 80; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, n >= 2: taken when the cost model predicts n % of the generation-2 class rate (step A/B: 80 -> 24.26, 100 -> 24.46, off 24.65 ms/step)
+namespace vtxg { int g_vtx_sw_gen3_s2 = 0; }   // generation 3 for the stride-2 input-gradient classes (loses per shape: off)
 namespace vtxg { int g_vtx_sw_gen3_mc = getenv("VIRTEX_AMD_GEN3_MC") ? atoi(getenv("VIRTEX_AMD_GEN3_MC")) : 200; }   // generation 3 for the weight gradients (gemm_v3mc.h): 0 forced only, n: taken from M N / (M + N) >= n (MFMA-leaning shapes)
 namespace vtxg { int g_vtx_sw_mc_eff128 = getenv("VIRTEX_AMD_MC_EFF128") ? atoi(getenv("VIRTEX_AMD_MC_EFF128")) : 84; }   // tile picker: 128x128 efficiency (%) for k-major operands
 extern "C" int vtx_set_switch(const char* name, int value) {
@@ -82,6 +83,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "bn_grid")) g_vtx_sw_bn_grid = value > 0 ? value : 8192;
     else if (!strcmp(name, "gen3")) vtxg::g_vtx_sw_gen3 = value;
     else if (!strcmp(name, "gen3_mc")) vtxg::g_vtx_sw_gen3_mc = value;
+    else if (!strcmp(name, "gen3_s2")) vtxg::g_vtx_sw_gen3_s2 = value;
     else if (!strcmp(name, "conv3x3_shared")) vtxg::g_vtx_sw_conv3x3_shared = value;
     else if (!strcmp(name, "tile64x256")) vtxg::g_vtx_sw_tile64x256 = value;
     else if (!strcmp(name, "mc_eff128")) vtxg::g_vtx_sw_mc_eff128 = value > 0 ? value : 84;

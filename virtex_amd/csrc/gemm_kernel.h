@@ -1711,6 +1711,7 @@ inline int pick_tile(int M, int N, int splits, bool allow256, bool mc = false) {
 //   256x128               4 400      1 819 (gather loaders 2 450)   4 000 /  7 100 / 13 400
 // and taken when its predicted rate beats what generation 2 reaches on the class (850 TFLOP/s plain matrices, 950 gathers).
 extern int g_vtx_sw_gen3;
+extern int g_vtx_sw_gen3_s2;      // vtx_set_switch("gen3_s2"): 1 = the picker may take generation 3 for stride-2 input gradients (A/B; default 0)
 inline int pick_gen3(int M, int N, int K, int splits, bool gather, int smode) {
     if (g_vtx_tile_override == 20) return 1;
     if (g_vtx_tile_override == 21) return 2;
@@ -1825,7 +1826,11 @@ inline int launch_auto(FA make_a, FB make_b, const EP& ep, int M, int N, int K, 
     }
     if constexpr (BF && !ALT<T, 1>::MC && !BLT<T, 1>::MC) {
         // generation 3 (gemm_v3.h): 8-wave 256x256 / 256x128 blocks with the phase-interleaved K loop
-        const int g3 = v2 ? pick_gen3(M, N, K, split_k, !std::is_same<ALT<T, 1>, PlainKC<T, 1>>::value, EP::SMODE) : 0;
+        // (the parity classes of the stride-2 input gradients lose on generation 3 at every shape of the step -- 107 vs 142-148 us
+        //  256->256 k3 @28, 142 vs 182-188 512->1024 k1 @28, 98 vs 116-119 1024->2048 k1 @14: profiles/r04_gen3_per_shape_lean_epilogue.txt
+        //  -- while the cycle model, fitted to the stride-1 gathers, predicts a tie: they stay on generation 2 unless forced)
+        const bool s2 = std::is_same<ALT<T, 1>, ConvDgradS2A<T, 1>>::value && g_vtx_tile_override < 0 && !g_vtx_sw_gen3_s2;
+        const int g3 = v2 && !s2 ? pick_gen3(M, N, K, split_k, !std::is_same<ALT<T, 1>, PlainKC<T, 1>>::value, EP::SMODE) : 0;
         if (g3 && buf_ok(64)) {
             g_vtx_last_generation = 3;
             g_vtx_generation_count[3].fetch_add(1, std::memory_order_relaxed);

@@ -32,6 +32,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
         xr[i] = *reinterpret_cast<const uint4*>(x + base + cc);
         yr[i] = *reinterpret_cast<const uint4*>(yp + base + cc);
     }
+    // gamma / beta too: loaded where they are used (behind the two wave reductions) they were one more memory latency in a
+    // kernel that IS a chain of latencies (one round of 7 680 one-row waves)
+    float4 gq[NV][VEC / 4], bq[NV][VEC / 4];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC, cc = col < H ? col : 0;
+#pragma unroll
+        for (int j = 0; j < VEC / 4; ++j) {
+            gq[i][j] = *reinterpret_cast<const float4*>(gamma + cc + 4 * j);
+            bq[i][j] = *reinterpret_cast<const float4*>(beta + cc + 4 * j);
+        }
+    }
     vtx_loads_issued();
     Vec16<T> z[NV];
     float s = 0.f;
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
             float ga[VEC], be[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; j += 4) {
-                const float4 g4 = *reinterpret_cast<const float4*>(gamma + col + j), b4 = *reinterpret_cast<const float4*>(beta + col + j);
+                const float4 g4 = gq[i][j / 4], b4 = bq[i][j / 4];
                 ga[j] = g4.x; ga[j + 1] = g4.y; ga[j + 2] = g4.z; ga[j + 3] = g4.w;
                 be[j] = b4.x; be[j + 1] = b4.y; be[j + 2] = b4.z; be[j + 3] = b4.w;
             }
@@ -103,17 +115,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
 #pragma unroll
         for (int j = 0; j < VEC; ++j) ag[i][j] = ab[i][j] = 0.f;
 
-    for (int row = blockIdx.x * 4 + wv; row < rows; row += gridDim.x * 4) {
-        const size_t base = (size_t)row * H;
-        const float mean = mean_in[row], rstd = rstd_in[row];
-        uint4 xr[NV], yr[NV], gr[NV];
-        const T* yp = y ? y : x;
+    // gamma is the same for every row: once per wave, in front of the loop (it was re-requested per row, behind the row's loads)
+    float gam[NV][VEC];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int col = (i * 64 + lane) * VEC, cc = col < H ? col : 0;
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + cc + j);
+            gam[i][j] = g4.x; gam[i][j + 1] = g4.y; gam[i][j + 2] = g4.z; gam[i][j + 3] = g4.w;
+        }
+    }
+    // A wave walks its rows with the NEXT row's vectors (and statistics) requested before the current row is worked on:
+    // a row is load -> two wave reductions -> store, and without the prefetch a wave's rows were that chain back to back
+    // (2.7 TB/s on 63 MB: profiles/r04_bench_default.json).
+    const T* yp = y ? y : x;
+    const int row0 = blockIdx.x * 4 + wv, rstep = gridDim.x * 4;
+    uint4 nx[NV], ny[NV], ng[NV];
+    float nmean = 0.f, nrstd = 0.f;
+    if (row0 < rows) {
+        const size_t b0 = (size_t)row0 * H;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = (i * 64 + lane) * VEC, cc = col < H ? col : 0;
-            xr[i] = *reinterpret_cast<const uint4*>(x + base + cc);
-            yr[i] = *reinterpret_cast<const uint4*>(yp + base + cc);
-            gr[i] = *reinterpret_cast<const uint4*>(dout + base + cc);
+            nx[i] = *reinterpret_cast<const uint4*>(x + b0 + cc);
+            ny[i] = *reinterpret_cast<const uint4*>(yp + b0 + cc);
+            ng[i] = *reinterpret_cast<const uint4*>(dout + b0 + cc);
+        }
+        nmean = mean_in[row0]; nrstd = rstd_in[row0];
+    }
+    for (int row = row0; row < rows; row += rstep) {
+        const size_t base = (size_t)row * H;
+        const float mean = nmean, rstd = nrstd;
+        uint4 xr[NV], yr[NV], gr[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { xr[i] = nx[i]; yr[i] = ny[i]; gr[i] = ng[i]; }
+        const int nrow = row + rstep;
+        if (nrow < rows) {                                   // (wave-uniform)
+            const size_t nb = (size_t)nrow * H;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int col = (i * 64 + lane) * VEC, cc = col < H ? col : 0;
+                nx[i] = *reinterpret_cast<const uint4*>(x + nb + cc);
+                ny[i] = *reinterpret_cast<const uint4*>(yp + nb + cc);
+                ng[i] = *reinterpret_cast<const uint4*>(dout + nb + cc);
+            }
+            nmean = mean_in[nrow]; nrstd = rstd_in[nrow];
         }
         vtx_loads_issued();
         Vec16<T> xh[NV], g[NV];
@@ -130,18 +177,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
                     for (int j = 0; j < VEC; ++j) xh[i].v[j] += drop.apply(t[j], base + col + j);
                 }
                 vtx_unpack_raw16<T>(gr[i], g[i].v);
-                float ga[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; j += 4) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(gamma + col + j);
-                    ga[j] = g4.x; ga[j + 1] = g4.y; ga[j + 2] = g4.z; ga[j + 3] = g4.w;
-                }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const float h = (xh[i].v[j] - mean) * rstd;
                     const float d = g[i].v[j];
                     ag[i][j] += d * h; ab[i][j] += d;
-                    const float gg = d * ga[j];
+                    const float gg = d * gam[i][j];
                     xh[i].v[j] = h; g[i].v[j] = gg;
                     s1 += gg; s2 += gg * h;
                 }
@@ -217,7 +258,7 @@ __global__ void ln_bwd_finalize_kernel(const float* __restrict__ partials, float
     }
 }
 
-constexpr int VTX_LN_MAX_PARTS = 512;
+constexpr int VTX_LN_MAX_PARTS = 512;       // blocks (= dgamma / dbeta partial rows) of the backward kernel; 1 024 measured: the kernel 28.7 -> 27 us, its finalize 7 -> 13 us
 
 template <class T>
 int ln_fwd_t(const void* x, const void* y, const float* gamma, const float* beta, void* out,

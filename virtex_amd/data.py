@@ -12,10 +12,13 @@ from typing import Dict, Iterable, Iterator, List
 import torch
 
 
-def collate_captions(instances: List[Dict[str, torch.Tensor]], padding_idx: int = 0) -> Dict[str, torch.Tensor]:
+def collate_captions(instances: List[Dict[str, torch.Tensor]], padding_idx: int = 0, pad_to: int = 0) -> Dict[str, torch.Tensor]:
     """Right-pad ``caption_tokens`` / ``noitpac_tokens`` with ``padding_idx`` to the longest caption of the batch and
-    stack everything else -- key for key what the reference's collate_fn returns."""
-    longest = max(int(d["caption_tokens"].numel()) for d in instances)
+    stack everything else -- key for key what the reference's collate_fn returns.  ``pad_to`` > 0 pads to at least that
+    length instead (the maximum caption length): every batch then has ONE shape, which launch replay and hipGraphs need
+    (virtex_amd.replay.StepReplay); the loss and every gradient are those of the shorter batch -- padded positions are masked
+    in attention, zeroed by the embedding and ignored by the loss (tests/test_data.py)."""
+    longest = max(max(int(d["caption_tokens"].numel()) for d in instances), int(pad_to))
     n = len(instances)
     caption_tokens = torch.full((n, longest), padding_idx, dtype=torch.long)
     noitpac_tokens = torch.full((n, longest), padding_idx, dtype=torch.long)

@@ -51,8 +51,11 @@ def layernorm_residual_bwd(x, y, gamma, mean, rstd, dout, dgamma, dbeta, p_drop=
     dz = torch.empty_like(x)
     dy = torch.empty_like(x) if (y is not None and p_drop > 0.0) else None
     ws = _ln_ws.get(_ws_key(x.device))
-    if ws is None or ws.numel() < 1024 * H:
-        ws = torch.empty(1024 * max(H, 2048), dtype=torch.float32, device=x.device)
+    lib = _lib.lib()
+    lib.vtx_layernorm_workspace_floats.restype = _lib.ctypes.c_long
+    need = int(lib.vtx_layernorm_workspace_floats(c_int(H)))          # per-block dgamma / dbeta partials (the library's block cap x 2 x H)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, int(lib.vtx_layernorm_workspace_floats(c_int(2048)))), dtype=torch.float32, device=x.device)
         _ln_ws[_ws_key(x.device)] = ws
     call("vtx_layernorm_residual_bwd", c_int(dtype_code(x.dtype)), ptr(x), ptr(y), ptr(gamma),
          ptr(mean), ptr(rstd), ptr(dout), ptr(dz), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(rows),

@@ -220,6 +220,11 @@ class StepReplay:
     def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
         if batch is not None:
             for k, v in self.static.items():
+                if batch[k].shape != v.shape:
+                    # a recording is a list of launches on FIXED shapes: collate to the recorded caption length
+                    # (virtex_amd.data.collate_captions(..., pad_to=...)) or take the eager step for odd batches
+                    raise ValueError(f"StepReplay: batch[{k!r}] has shape {tuple(batch[k].shape)}, the recording was made on "
+                                     f"{tuple(v.shape)}")
                 v.copy_(batch[k], non_blocking=True)
         self._replay()
         self.replays += 1
