@@ -90,3 +90,26 @@ def test_replay_draws_new_dropout_masks(backend):
         assert len({round(l, 6) for l in losses}) == 4, losses
     finally:
         opt.disable_device_schedule()
+
+
+@pytest.mark.gpu
+def test_every_recorded_op_is_replayed_on_the_stream_it_was_recorded_on():
+    """The autograd engine switches streams with a C++ guard (no Python setter runs): the recorder has to notice and record the
+    switch itself, else `event.record()` and ATen operators of a backward node land on the stream the LAST recorded switch left.
+    Walk the list the way the replay does and compare with the stream every op saw when it was recorded."""
+    import re
+    dev = select("gpu")
+    model, buckets, opt = _setup(dev, 0.1, torch.bfloat16)
+    try:
+        replay = StepReplay(model, buckets, opt, _batch(3, dev), warmup=1, validate=True)
+        rec = replay.rec
+        assert rec.counts["engine_switch"] >= 1              # the branch head's backward runs on the branch stream
+        cur = rec.start[0]
+        for i, (label, at) in enumerate(zip(rec.labels, rec.at_stream)):
+            m = re.match(r"stream:engine switch to stream#(\d+)", label) or re.match(r"stream:_cuda_setStream .*'stream_id': (\d+)", label)
+            if m:
+                cur = int(m.group(1))
+                continue
+            assert at == cur, (i, label, at, cur)
+    finally:
+        opt.disable_device_schedule()

@@ -71,7 +71,7 @@ def call(name: str, *args):
     if rc != 0:
         raise VtxError(f"{name} failed ({rc}): {lib().vtx_last_error().decode()}")
     if _recorder is not None:            # the same call, re-issued by virtex_amd.replay (arguments are ctypes objects: kept as they are)
-        _recorder.add("kernel", lambda f=fn, a=args: f(*a), args)
+        _recorder.add("kernel", lambda f=fn, a=args: f(*a), args, label=name)
 
 
 # torch.cuda.current_stream() builds a Stream object through three Python layers (4.4 us per call, 2.5 ms of the 12 ms the

@@ -53,6 +53,26 @@ class _FanoutFn(torch.autograd.Function):
         return ops.add(d1.contiguous(), d2.contiguous())
 
 
+class _LossSumFn(torch.autograd.Function):
+    """loss = forward-captioning loss (compute stream) + backward-captioning loss (branch stream).  The gradient of the sum is
+    produced on the compute stream and consumed by the branch head's backward on the branch stream: the autograd engine orders
+    the two streams by itself, in C++ -- invisible to virtex_amd.replay, whose recording would lose that edge.  Here the branch
+    stream waits for the compute stream explicitly (a recorded stream operation; harmless next to the engine's own)."""
+
+    @staticmethod
+    def forward(ctx, a, b, branch):
+        ctx.branch = branch
+        return a + b
+
+    @staticmethod
+    @traced_backward
+    def backward(ctx, g):
+        if ctx.branch is not None and g.is_cuda:
+            ctx.branch.wait_stream(torch.cuda.current_stream(g.device))
+            g.record_stream(ctx.branch)
+        return g, g, None
+
+
 class _FusedTiedCrossEntropyFn(torch.autograd.Function):
     """mean_{tok[b,t+1] != pad} CE(hidden[b,t] @ words^T + bias, tok[b,t+1]) without (B,T,V) logits in HBM
     (reference: captioning.py:111-114 on textual_heads.py:277 logits)."""
@@ -259,7 +279,10 @@ class CaptioningModel(nn.Module):
                     backward_loss = _logits_loss(
                         self.backward_textual(visual_features, backward_caption_tokens, caption_lengths),
                         backward_caption_tokens, self.padding_idx)
-                output_dict["loss"] = output_dict["loss"] + backward_loss
+                if self.training and br is not None and br.active:
+                    output_dict["loss"] = _LossSumFn.apply(output_dict["loss"], backward_loss, branch_stream.side(backward_loss.device))
+                else:
+                    output_dict["loss"] = output_dict["loss"] + backward_loss
                 output_dict["loss_components"].update(captioning_backward=backward_loss.clone().detach())
             if not self.training:
                 output_dict["predictions"] = torch.argmax(output_logits, dim=-1)

@@ -24,12 +24,21 @@ from torch import nn
 from .. import gradsink, ops
 from ..streams import wgrad_stream
 
-_seed_counter = itertools.count(1)
+_seed_counter = [0]
 
 
 def next_dropout_seed() -> int:
     """Host-side counter mixed with torch's seed: deterministic given torch.manual_seed."""
-    return (torch.initial_seed() * 1000003 + next(_seed_counter) * 7919) & 0x7FFFFFFFFFFFFFFF
+    _seed_counter[0] += 1
+    return (torch.initial_seed() * 1000003 + _seed_counter[0] * 7919) & 0x7FFFFFFFFFFFFFFF
+
+
+def dropout_seed_state(value=None) -> int:
+    """Read (and, with an argument, set) the host counter the dropout seeds are drawn from: two runs started from the same value
+    draw the same seeds (virtex_amd.replay validates a recording against an eager step that way)."""
+    if value is not None:
+        _seed_counter[0] = int(value)
+    return _seed_counter[0]
 
 
 class WordAndPositionalEmbedding(nn.Module):

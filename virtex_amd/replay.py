@@ -15,10 +15,17 @@ SLOWER on ROCm 7.2 (profiles/r04_hipgraph_configs_2_4_5.txt: the captured side-s
 What makes a replay a faithful NEXT step rather than a repetition (the same three things a hipGraph needs, virtex_amd/graph.py):
 dropout masks advance through the device epoch mixed into the seeds by the kernels, the LR multiplier and the Lookahead phase
 are computed on the device (`FusedPretrainOptimizer.enable_device_schedule`), BatchNorm's counters live on the device.
-Work the autograd ENGINE launches by itself cannot be recorded; the model routes the one such operation of the step (the sum
-of the two heads' gradients of the shared visual projection) through a Function of its own.  Construction VALIDATES the
-recording: from identical state and batch the replayed step must reproduce the eager step's loss, gradients and updated
-parameters bit for bit (dropout off during the check), else the caller keeps the eager step.
+Work the autograd ENGINE does by itself cannot be recorded as such, so none is left to it: (1) the one launch it made (the sum
+of the two heads' gradients of the shared visual projection) is a Function of the model; (2) the one cross-stream edge it ordered
+in C++ (the gradient of `loss_a + loss_b`, produced on the compute stream, consumed by the branch head on the branch stream) is an
+explicit `wait_stream` in `models._LossSumFn`; (3) its stream guards -- every backward node runs on the stream of its forward,
+switched without any Python setter -- are noticed by the recorder as an unexplained change of the current stream and recorded as
+switches of their own (kernel launches carry their stream in their arguments, but `event.record()` and ATen operators go to
+whatever stream is current when they are re-issued).  Construction VALIDATES the recording: made on the example batch X, it is
+replayed on a second batch Y (rows rolled, images negated) from the state and dropout seeds an eager step on Y started from, and
+must reproduce that step's loss, gradients and updated state; a recorded launch that runs before its producer reads what the
+recording left in its buffers -- X-values -- and fails the comparison.  `tests/test_replay.py` also walks the list the way the
+replay does and checks every op against the stream it saw when it was recorded.
 
 Single process only (the data-parallel all-reduces are torch.distributed calls issued from autograd hooks).
 """
@@ -38,19 +45,49 @@ _NO_WORK = {"empty", "empty_like", "empty_strided", "new_empty", "new_empty_stri
             "_has_compatible_shallow_copy_type", "is_pinned", "set_", "resize_"}
 
 
+def _current_stream_key():
+    """(stream_id, device_index, device_type) of the calling thread's current stream; None without a GPU."""
+    get = getattr(torch._C, "_cuda_getCurrentStream", None)
+    if get is None or not torch.cuda.is_available():
+        return None
+    return tuple(get(torch.cuda.current_device()))
+
+
+def _set_stream_key(key):
+    torch._C._cuda_setStream(stream_id=key[0], device_index=key[1], device_type=key[2])
+
+
 class Recorder:
     """The ordered launch list of one step.  Appended to from the main thread and from autograd's worker thread (the backward
     pass runs there; the two never run at the same time)."""
 
     def __init__(self):
         self.ops: List[Callable[[], None]] = []
+        self.labels: List[str] = []      # what each op is (C entry point / stream operation / ATen operator): tools/replay_dump.py
+        self.at_stream: List[Optional[int]] = []   # id of the calling thread's current stream when the op was recorded (tests)
         self.keep = []                   # tensors / ctypes objects whose memory the recorded arguments point into
         self.lock = threading.Lock()
-        self.counts = {"kernel": 0, "aten": 0, "stream": 0}
+        self.counts = {"kernel": 0, "aten": 0, "stream": 0, "engine_switch": 0}
+        self.cur = _current_stream_key()         # the stream the replay will be on at this point of the list
+        self.start = self.cur
 
-    def add(self, kind, thunk, *keep):
+    def add(self, kind, thunk, *keep, label="", sets_stream=False):
         with self.lock:
+            # The autograd engine puts every node on the stream its forward ran on with a C++ stream guard: no Python setter
+            # is called, so the recording never sees the switch.  Kernel launches carry their stream handle in their recorded
+            # arguments, but `event.record()` and ATen operators go to whatever stream is CURRENT when they are re-issued:
+            # an unexplained change of the calling thread's current stream becomes a recorded switch of its own.
+            now = _current_stream_key()
+            if now is not None:
+                if not sets_stream and now != self.cur:
+                    self.ops.append(lambda k=now: _set_stream_key(k))
+                    self.labels.append(f"stream:engine switch to stream#{now[0]}")
+                    self.at_stream.append(now[0])
+                    self.counts["engine_switch"] += 1
+                self.cur = now
             self.ops.append(thunk)
+            self.at_stream.append(now[0] if now is not None else None)
+            self.labels.append(f"{kind}:{label}")
             self.keep.extend(keep)
             self.counts[kind] += 1
 
@@ -79,20 +116,35 @@ class _RecordAten(TorchDispatchMode):
         if not any(t.is_cuda for t in flat_in + outs) and flat_in + outs and not _lib.is_emulator():
             return out                                   # host-side tensor arithmetic: no device work to repeat
         if func._schema.is_mutable:                      # in-place / out= : repeat as it was
-            rec.add("aten", lambda f=func, a=args, k=kwargs: f(*a, **k), args, kwargs, out)
+            rec.add("aten", lambda f=func, a=args, k=kwargs: f(*a, **k), args, kwargs, out, label=name)
         elif any(r.alias_info is not None for r in func._schema.returns):
             return out                                   # a view the table above does not know
         elif outs:                                       # functional: recompute, store into the recorded result
             if len(outs) == 1:
-                rec.add("aten", lambda f=func, a=args, k=kwargs, o=outs[0]: o.copy_(f(*a, **k)), args, kwargs, out)
+                rec.add("aten", lambda f=func, a=args, k=kwargs, o=outs[0]: o.copy_(f(*a, **k)), args, kwargs, out, label=name)
             else:
                 def thunk(f=func, a=args, k=kwargs, os_=outs):
                     r = f(*a, **k)
                     r = [x for x in (r if isinstance(r, (tuple, list)) else (r,)) if isinstance(x, torch.Tensor)]
                     for o, x in zip(os_, r):
                         o.copy_(x)
-                rec.add("aten", thunk, args, kwargs, out)
+                rec.add("aten", thunk, args, kwargs, out, label=name)
         return out
+
+
+def _describe(obj, args):
+    """stream / event identities for the labels of recorded stream operations"""
+    def one(o):
+        if isinstance(o, torch.cuda.Stream):
+            return f"stream#{o.stream_id}"
+        if isinstance(o, torch.cuda.Event):
+            return f"event@{id(o) & 0xffff:04x}"
+        return type(o).__name__
+    try:
+        cur = torch.cuda.current_stream().stream_id
+    except Exception:
+        cur = "?"
+    return f"{one(obj)}({', '.join(one(a) for a in args)}) [current stream#{cur}]"
 
 
 def traced_backward(fn):
@@ -131,7 +183,8 @@ class _Patches:
                 finally:
                     tl.depth = depth
                 if depth == 0:
-                    rec.add("stream", lambda s=self_, a=a, k=k: orig(s, *a, **k), self_, a, k)
+                    rec.add("stream", lambda s=self_, a=a, k=k: orig(s, *a, **k), self_, a, k,
+                            label=f"{type(self_).__name__}.{name} {_describe(self_, a)}")
                 return r
         else:
             def wrapped(*a, **k):
@@ -142,7 +195,7 @@ class _Patches:
                 finally:
                     tl.depth = depth
                 if depth == 0:
-                    rec.add("stream", lambda a=a, k=k: orig(*a, **k), a, k)
+                    rec.add("stream", lambda a=a, k=k: orig(*a, **k), a, k, label=f"{name} {k or a}", sets_stream=name == "_cuda_setStream")
                 return r
         self.saved.append((owner, name, orig))
         setattr(owner, name, wrapped)
@@ -183,6 +236,16 @@ def record(step_fn: Callable[[], torch.Tensor]):
     return rec, out
 
 
+def _run(rec: Recorder):
+    """Re-issue a recording; the calling thread ends on the stream it was on (the list may end on another one)."""
+    try:
+        for op in rec.ops:
+            op()
+    finally:
+        if rec.start is not None and _current_stream_key() != rec.start:
+            _set_stream_key(rec.start)
+
+
 class StepReplay:
     """step = StepReplay(model, buckets, optimizer, example_batch); loss = step(batch)
 
@@ -214,8 +277,7 @@ class StepReplay:
         return out["loss"].detach()
 
     def _replay(self):
-        for op in self.rec.ops:
-            op()
+        _run(self.rec)
 
     def __call__(self, batch: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
         if batch is not None:
@@ -246,17 +308,32 @@ class StepReplay:
         return ts
 
     def _validate(self):
+        """Recording on batch X, comparison on batch Y: a recorded launch that runs too early (a stream dependency the
+        recording lost) reads what the recording left in its buffers -- X-values -- and that shows only when the reference
+        values come from a different batch."""
+        from .modules.textual_heads import dropout_seed_state
         saved = [t.clone() for t in self._state()]
-        rec, loss_rec = record(self._eager)                  # step A: eager (recorded)
+        batch_x = {k: v.clone() for k, v in self.static.items()}
+        seeds = dropout_seed_state()
+        rec, loss_rec = record(self._eager)                  # the recording (batch X); its tensors are the replay's buffers
+        self._sync()
+
+        def restore():
+            for t, s0 in zip(self._state(), saved):
+                t.copy_(s0)
+        restore()
+        for k, v in self.static.items():                     # batch Y: the images / captions of X assigned to other rows, images negated
+            y = torch.roll(batch_x[k], 1, 0) if v.dim() > 0 and v.shape[0] > 1 else batch_x[k]
+            v.copy_(-y if (k == "image" and y.dtype.is_floating_point) else y)
+        dropout_seed_state(seeds)                            # the eager reference draws the seeds the recording holds
+        loss_a = self._eager().clone()                       # step A: eager on Y
         self._sync()
         after_a = [t.clone() for t in self._state()]
         grads_a = self.buckets.flat.clone()
-        loss_a = loss_rec.clone()
-        for t, s in zip(self._state(), saved):
-            t.copy_(s)
-        for op in rec.ops:                                   # step B: the recording replayed from the same state
-            op()
+        restore()
+        _run(rec)                                            # step B: the recording replayed on Y from the same state
         self._sync()
+        restored_batch = batch_x
 
         def close(a, b):                                     # (the embedding's fp32 atomics reorder sums: 1e-7 relative)
             if a.dtype.is_floating_point:
@@ -273,5 +350,8 @@ class StepReplay:
             if not close(a, b):
                 bad.append(f"state tensor {i} differs")
         self.validated = {"ops": len(rec.ops), **rec.counts}
+        for k, v in self.static.items():
+            v.copy_(restored_batch[k])
+        restore()
         if bad:
             raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step: " + "; ".join(bad[:4]))
