@@ -16,6 +16,7 @@
 #include "vtx_common.h"
 #include "pool_windows.h"
 
+extern int g_vtx_sw_bn_red_adj;      // vtx_set_switch("bn_red_adj"): stand-alone BatchNorm reductions walk the tensor in interleaved trips
 extern int g_vtx_sw_bn_adj, g_vtx_sw_bn_grid;   // vtx_set_switch("bn_adj" / "bn_grid"): form and grid cap of the flat apply kernels
 extern int g_vtx_sw_bn_fin_wide;     // vtx_set_switch("bn_fin_wide"): 1024-thread finalize / compaction blocks (default off)
 
@@ -48,14 +49,21 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     // UNR rows per trip, all loads issued before any use: one 16-byte load per wave in flight cannot cover
     // the HBM latency with <= 512 blocks on 256 CUs (measured 2.9 TB/s before)
     constexpr int UNR = 4;
-    for (int pb = p0 + ty; pb < p1; pb += UNR * TY) {
+    // Which rows a block sums.  rows_per_block > 0: one contiguous chunk per block (rounds 1-3).  rows_per_block == 0 (round 4,
+    // vtx_set_switch("bn_red_adj", 1)): trips of UNR * TY rows INTERLEAVED over the blocks -- at any moment the blocks of the grid
+    // read neighbouring addresses instead of gridDim.x places 0.4-1.6 MB apart, the access shape that took the flat apply kernels
+    // from 4.4 to 5.7 TB/s (tools/probes/stream_probe.hip).  A thread's channel vector does not depend on the row, so only the
+    // order of the fp32 additions changes.  Measured NEUTRAL here (the reductions read, they do not write: default off).
+    const bool adj = rows_per_block == 0;
+    const int pbeg = adj ? blockIdx.x * UNR * TY : p0, pend = adj ? P : p1, pstep = adj ? gridDim.x * UNR * TY : UNR * TY;
+    for (int pb = pbeg + ty; pb < pend; pb += pstep) {
         Vec16<T> xv[UNR], g[UNR], m[UNR];
         bool ok[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int p = pb + u * TY;
-            ok[u] = p < p1;
-            const size_t off = (size_t)(ok[u] ? p : p0) * C + c0;
+            ok[u] = p < pend;
+            const size_t off = (size_t)(ok[u] ? p : pbeg) * C + c0;
             xv[u].load(x + off);
             if (BWD) {
                 g[u].load(dy + off);
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
 // vectors in flight per thread of the apply kernels: 0 = by size, or 1, 2, 4 (A/B switch VIRTEX_AMD_BN_UNROLL)
 int g_bn_apply_unroll = getenv("VIRTEX_AMD_BN_UNROLL") ? atoi(getenv("VIRTEX_AMD_BN_UNROLL")) : 0;
 constexpr int VTX_BN_MAX_PARTS = 512;
-struct ReducePlan { int TX, gy, gx, rows; };
+struct ReducePlan { int TX, gy, gx, rows, krows; };   // krows: what bn_reduce_kernel gets (0 = interleaved trips)
 static ReducePlan plan_reduce(int P, int C, int vec) {
     ReducePlan r;
     const int cv = C / vec;
@@ -608,6 +616,7 @@ static ReducePlan plan_reduce(int P, int C, int vec) {
     if (gx < 1) gx = 1;
     r.rows = vtx_cdiv(P, gx);
     r.gx = vtx_cdiv(P, r.rows);
+    r.krows = g_vtx_sw_bn_red_adj ? 0 : r.rows;      // interleaved trips (see bn_reduce_kernel); same grid, same partial layout
     return r;
 }
 // grid of the flat apply kernels: at most 4096 blocks, and gridDim.x * 256 a multiple of cv (see bn_apply_kernel)
@@ -690,10 +699,10 @@ extern "C" int vtx_bn_fwd(int dtype, const void* x, const void* residual, const 
     }
     else if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_fwd_reduce", 0, 2.0 * P * C, (bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+                           (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.krows);
     else
         VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
-                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.krows);
     if (fin_done) {}
     else if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
@@ -752,10 +761,10 @@ extern "C" int vtx_bn_bwd(int dtype, const void* x, const void* dy, const void* 
     const long nvec = (long)P * C / vec;
     if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_bwd_reduce", 0, 2.0 * P * C * (ymask ? 3 : 2), (bn_reduce_kernel<bf16_t, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
-                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
+                           (const bf16_t*)dy, (const bf16_t*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.krows);
     else
         VTX_KLAUNCH("bn_bwd_reduce", 0, 4.0 * P * C * (ymask ? 3 : 2), (bn_reduce_kernel<float, true>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
-                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.rows);
+                           (const float*)dy, (const float*)ymask, save_mean, save_rstd, gamma, relu_beta, sums, P, C, rp.TX, rp.krows);
     VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, sums, gamma, save_rstd, coef,
                 dgamma, dbeta, P, C, rp.gx);
     if (!ymask && !relu_beta && !dz_out) {
@@ -891,10 +900,10 @@ extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, 
     if (fused) { sums = const_cast<float*>(pre_partials); rp.gx = pre_nparts; }
     else if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_fwd_reduce", 0, 2.0 * P * C, (bn_reduce_kernel<bf16_t, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const bf16_t*)x,
-                    (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+                    (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.krows);
     else
         VTX_KLAUNCH("bn_fwd_reduce", 0, 4.0 * P * C, (bn_reduce_kernel<float, false>), dim3(rp.gx, rp.gy), dim3(256), 0, st, (const float*)x,
-                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.rows);
+                    (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, sums, P, C, rp.TX, rp.krows);
     if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_finalize", 0, 8.0 * rp.gx * C, (bn_fwd_finalize_kernel<bf16_t>), dim3(vtx_cdiv(C, FIN_CH)), fin_block(rp.gx), 0, st, (const bf16_t*)x, fused ? pre_shift : (const float*)nullptr, sums, gamma, beta,
                     save_mean, save_rstd, scale, scale + C, running_mean, running_var, num_batches_tracked, P, C, eps, momentum, rp.gx);

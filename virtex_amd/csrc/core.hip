@@ -62,6 +62,7 @@ int g_vtx_sw_bn_fin_wide = getenv("VIRTEX_AMD_BN_FIN_WIDE") ? atoi(getenv("VIRTE
 // tile rule of the convolutions with BatchNorm epilogues (launch_auto): 0 = the plain picker, 1 = 8-wave 128x128 tiles for every
 // statistics epilogue on large M (rounds 1-2), 2 = only for the forward statistics, 3 = only for the fused backward
 namespace vtxg { int g_vtx_sw_stats_tile = getenv("VIRTEX_AMD_STATS_TILE") ? atoi(getenv("VIRTEX_AMD_STATS_TILE")) : 4; }
+int g_vtx_sw_bn_red_adj = getenv("VIRTEX_AMD_BN_RED_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_RED_ADJ")) : 0;   // stand-alone BatchNorm reductions in interleaved trips: measured neutral (step 23.96 vs 23.94, kernel time 25.78 vs 25.71 ms: profiles/r04_ab_bn_red_adj.txt) -> off, the summation order of rounds 1-3 stays
 int g_vtx_sw_bn_adj = getenv("VIRTEX_AMD_BN_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_ADJ")) : 1;      // flat BatchNorm apply kernels: adjacent vectors per trip
 int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN_GRID")) : 8192;  // ... and their grid cap
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
@@ -80,6 +81,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "stats_tile")) vtxg::g_vtx_sw_stats_tile = value;
     else if (!strcmp(name, "tile_order")) vtxg::g_vtx_ablate = (vtxg::g_vtx_ablate & ~32) | (value ? 32 : 0);   // 1: plain block -> tile order (A/B)
     else if (!strcmp(name, "bn_adj")) g_vtx_sw_bn_adj = value;
+    else if (!strcmp(name, "bn_red_adj")) g_vtx_sw_bn_red_adj = value;
     else if (!strcmp(name, "bn_grid")) g_vtx_sw_bn_grid = value > 0 ? value : 8192;
     else if (!strcmp(name, "gen3")) vtxg::g_vtx_sw_gen3 = value;
     else if (!strcmp(name, "gen3_mc")) vtxg::g_vtx_sw_gen3_mc = value;
