@@ -69,7 +69,7 @@ namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
 namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 80; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, n >= 2: taken when the cost model predicts n % of the generation-2 class rate (step A/B: 80 -> 24.26, 100 -> 24.46, off 24.65 ms/step)
 namespace vtxg { int g_vtx_sw_gen3_s2 = 0; }   // generation 3 for the stride-2 input-gradient classes (loses per shape: off)
-namespace vtxg { int g_vtx_sw_gen3_mc = getenv("VIRTEX_AMD_GEN3_MC") ? atoi(getenv("VIRTEX_AMD_GEN3_MC")) : 200; }   // generation 3 for the weight gradients (gemm_v3mc.h): 0 forced only, n: taken from M N / (M + N) >= n (MFMA-leaning shapes)
+namespace vtxg { int g_vtx_sw_gen3_mc = getenv("VIRTEX_AMD_GEN3_MC") ? atoi(getenv("VIRTEX_AMD_GEN3_MC")) : 800; }   // generation 3 for the weight gradients (gemm_v3mc.h): 0 forced only, n: taken from M N / (M + N) >= n (MFMA-leaning shapes); step A/B (profiles/r04_ab_gen3_mc_threshold.txt): off 23.78, 200 23.71, 400 23.68, 800 23.64, 1500 23.78 ms
 namespace vtxg { int g_vtx_sw_mc_eff128 = getenv("VIRTEX_AMD_MC_EFF128") ? atoi(getenv("VIRTEX_AMD_MC_EFF128")) : 84; }   // tile picker: 128x128 efficiency (%) for k-major operands
 extern "C" int vtx_set_switch(const char* name, int value) {
     VTX_CHECK(name, VTX_ERR_ARG, "vtx_set_switch: null name");

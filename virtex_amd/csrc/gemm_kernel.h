@@ -1739,7 +1739,7 @@ inline int pick_gen3(int M, int N, int K, int splits, bool gather, int smode) {
 // and stay on generation 2.  Tile and slices by a cycle model fitted to the same table:
 //   256x256: 4 400 + slices' K tiles x 3 000 (gather 3 600) + 13 000 (fp32 tile through the strip); 256x128: ... x 1 800 (2 450) + 6 000;
 //   + the reduce launch: 6 000 + (slices + 2) x M N x 4 bytes at 4 TB/s.
-extern int g_vtx_sw_gen3_mc;      // vtx_set_switch("gen3_mc"): 0 = only when forced (tile override 20 / 21), n = the intensity threshold (default 200)
+extern int g_vtx_sw_gen3_mc;      // vtx_set_switch("gen3_mc"): 0 = only when forced (tile override 20 / 21), n = the intensity threshold (default 800)
 inline int plan_gen3_mc(int M, int N, int K, bool gather, int* split) {
     *split = 1;
     if (g_vtx_tile_override >= 0 && g_vtx_tile_override != 20 && g_vtx_tile_override != 21) return 0;
