@@ -307,6 +307,26 @@ inline hipemu_v4s hipemu_ds_read_tr16_b64(const void* p) {
 }
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu_ds_read_tr16_b64((const void*)(uintptr_t)(p))
 
+// v_permlane16_swap_b32 / v_permlane32_swap_b32 (gfx950; semantics measured on MI355X, tools/probes/permlane_probe.hip):
+//   permlane16_swap(a, b): r[0] = rows {a0, b0, a2, b2}, r[1] = rows {a1, b1, a3, b3}   (rows of 16 lanes: a.row1 <-> b.row0, a.row3 <-> b.row2)
+//   permlane32_swap(a, b): r[0] = {a.lanes 0-31, b.lanes 0-31}, r[1] = {a.lanes 32-63, b.lanes 32-63}   (a.upper <-> b.lower)
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+inline hipemu_u32x2 hipemu_permlane_swap(unsigned a, unsigned b, int half) {
+    unsigned mine[2] = {a, b};
+    char* base = (char*)hipemu::wave_exchange(mine, 8);
+    const int lane = hipemu::tls.cur->lane;
+    const bool upper = (lane & half) != 0;              // odd row (half = 16) / upper half of the wave (half = 32)
+    unsigned pa, pb;
+    memcpy(&pa, base + 64 * (lane ^ half), 4);
+    memcpy(&pb, base + 64 * (lane ^ half) + 4, 4);
+    hipemu_u32x2 r;
+    r[0] = upper ? pb : a;                              // r[0]: a where it stays, the partner's b in the swapped positions
+    r[1] = upper ? b : pa;
+    return r;
+}
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) hipemu_permlane_swap((unsigned)(a), (unsigned)(b), 16)
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) hipemu_permlane_swap((unsigned)(a), (unsigned)(b), 32)
+
 // ---- atomics (blocks run on several OS threads) ---------------------------------------
 inline float atomicAdd(float* p, float v) {
     unsigned* ip = (unsigned*)p; unsigned old = __atomic_load_n(ip, __ATOMIC_RELAXED), nw;

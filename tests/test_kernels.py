@@ -1064,6 +1064,37 @@ GEN3_PARAMS = [pytest.param("emu", 0, marks=pytest.mark.emu), pytest.param("emu"
                pytest.param("gpu", 0, marks=pytest.mark.gpu)]
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cand", [20, 21])
+def test_generation3_register_transposed_epilogue_equals_the_strips(backend, cand):
+    """vtx_set_switch("epi_regs", 1): the plain epilogue of interior tiles without LDS -- the four 16x16 tiles of a wave row
+    transposed across the four lane rows with v_permlane16_swap / v_permlane32_swap (semantics probed on the part:
+    tools/probes/permlane_probe.hip; measured slower than the strips, so it is off by default) -- must store exactly what the
+    strip epilogue stores: bf16 with bias + GELU + residual, fp32, and split-K partial tiles."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    g = torch.Generator().manual_seed(7 + cand)
+    M, N, K = 512 + 40, 512, 128                                   # interior tiles (lean path) and a ragged last row of tiles
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); b = torch.randn(N, K, generator=g).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev); res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    outs = {}
+    try:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(cand))
+        for regs in (0, 1):
+            _lib.call("vtx_set_switch", b"epi_regs", ctypes.c_int(regs))
+            o1 = ops.gemm_nt(a, b, bias, res, act=ops.ACT_GELU)
+            assert _generation() == 3
+            o2 = ops.gemm_nt(a, b, bias, out_f32=True)
+            outs[regs] = (o1.float().cpu(), o2.cpu())
+    finally:
+        _lib.call("vtx_set_switch", b"epi_regs", ctypes.c_int(0))
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = F.gelu(a.float().cpu() @ b.float().cpu().t() + bias.cpu()) + res.float().cpu()
+    assert rel_err(outs[1][0], ref) < 1e-2
+
+
 @pytest.mark.parametrize("backend,late", GEN3_PARAMS)
 @pytest.mark.parametrize("cand", [20, 21])
 def test_contraction_generation3_gemm(backend, late, cand):

@@ -79,6 +79,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "bn_fin_wide")) g_vtx_sw_bn_fin_wide = value;
     else if (!strcmp(name, "bn_fin2")) g_vtx_sw_bn_fin2 = value;
     else if (!strcmp(name, "stats_tile")) vtxg::g_vtx_sw_stats_tile = value;
+    else if (!strcmp(name, "epi_regs")) vtxg::g_vtx_ablate = (vtxg::g_vtx_ablate & ~256) | (value ? 256 : 0);   // 1: generation-3 plain epilogue by register transposition (v_permlane swaps) instead of LDS strips: measured slower, off
     else if (!strcmp(name, "tile_order")) vtxg::g_vtx_ablate = (vtxg::g_vtx_ablate & ~32) | (value ? 32 : 0);   // 1: plain block -> tile order (A/B)
     else if (!strcmp(name, "bn_adj")) g_vtx_sw_bn_adj = value;
     else if (!strcmp(name, "bn_red_adj")) g_vtx_sw_bn_red_adj = value;

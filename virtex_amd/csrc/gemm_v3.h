@@ -208,16 +208,96 @@ __device__ __forceinline__ void v3_lean_store(const EpiStore<T, STATS_NONE>& ep,
     }
 }
 
+// The same epilogue without LDS (round 4, second half): the four 16x16 tiles of a wave row are TRANSPOSED ACROSS THE FOUR LANE ROWS
+// of the wave in registers -- gfx950's v_permlane16_swap / v_permlane32_swap, two stages -- so that lane (r, g) ends up with all
+// 16 columns of tile g for matrix row r: 32 contiguous bytes of bf16 (64 of fp32) per lane, 128 (256) per matrix row and wave,
+// stored straight from registers.  Per 16-row step: 4 W swaps (W = dwords per 4-column group) and 2 (4) 16-byte stores instead of
+// 4 strip writes, a wave barrier, 2 (4) strip reads and their LDS latency.  Element (j, g) = tile j, column group g:
+//   stage 1  permlane16_swap(T0, T1) -> rows {E00 E10 E02 E12}, {E01 E11 E03 E13};  (T2, T3) alike
+//   stage 2  permlane32_swap(T0', T2') -> {E00 E10 E20 E30} = E[g][0], {E02 E12 E22 E32} = E[g][2];  (T1', T3') -> E[g][1], E[g][3]
+// (semantics probed on the part: tools/probes/permlane_probe.hip; the CPU emulator implements the same maps).
+// MEASURED SLOWER than the strips and off by default (vtx_set_switch("epi_regs", 1)): ffn1 forward 59.1 -> 65.6 us, vocabulary
+// projection 152 -> 161, step 23.59 -> 23.70 ms (profiles/r04_epilogue_register_transpose.txt).  With lane & 15 = matrix row a
+// store instruction touches 16 rows and half of each 128-byte line (the other half follows with the next instruction); a strip
+// drain writes 8 rows of whole lines per instruction.  What bounds this epilogue is the write path, not the LDS round trip.
+template <int ACT, int WTM, int WTN, class T>
+__device__ __forceinline__ void v3_lean_store_regs(const EpiStore<T, STATS_NONE>& ep, f32x4_t (&acc)[WTM / 16][WTN / 16], int mw, int nw,
+                                                   int lane) {
+    static_assert(WTN == 64, "four 16-column tiles per wave row: one per lane row after the transposition");
+    constexpr int MT = WTM / 16;
+    constexpr int W = sizeof(T) == 2 ? 2 : 4;                  // dwords per (tile, 4-column group)
+    constexpr int NCH = 4 * W / 4;                             // 16-byte chunks per lane and step
+    constexpr int EPV = 16 / (int)sizeof(T);
+    const int g = lane >> 4, r = lane & 15;
+    float4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + nw + j * 16 + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float alpha = ep.alpha;
+    const bool has_res = ep.residual != nullptr;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const long row = mw + i * 16 + r;
+        uint4 res[NCH];
+        if (has_res) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) res[q] = *reinterpret_cast<const uint4*>(ep.residual + row * ep.ldr + nw + 16 * g + q * EPV);
+        }
+        uint32_t t[4][W];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4_t v = acc[i][j] * alpha;
+            v[0] += bv[j].x; v[1] += bv[j].y; v[2] += bv[j].z; v[3] += bv[j].w;
+            if constexpr (ACT == ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if constexpr (ACT == ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if constexpr (sizeof(T) == 2) { t[j][0] = f2bf2(v[0], v[1]); t[j][1] = f2bf2(v[2], v[3]); }
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[j][e] = __float_as_uint(v[e]);
+            }
+        }
+        uint32_t u[4][W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            const auto s01 = __builtin_amdgcn_permlane16_swap(t[0][w], t[1][w], false, false);
+            const auto s23 = __builtin_amdgcn_permlane16_swap(t[2][w], t[3][w], false, false);
+            const auto a = __builtin_amdgcn_permlane32_swap(s01[0], s23[0], false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(s01[1], s23[1], false, false);
+            u[0][w] = a[0]; u[2][w] = a[1]; u[1][w] = b[0]; u[3][w] = b[1];
+        }
+        T* const dst = ep.out + row * ep.ldc + nw + 16 * g + ep.split_off;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            uint4 w4;
+            if constexpr (sizeof(T) == 2) w4 = make_uint4(u[2 * q][0], u[2 * q][1], u[2 * q + 1][0], u[2 * q + 1][1]);
+            else w4 = make_uint4(u[q][0], u[q][1], u[q][2], u[q][3]);
+            if (has_res) w4 = add16<T>(w4, res[q]);
+            if (ep.nt) st16_nt(dst + q * EPV, u32x4_t{w4.x, w4.y, w4.z, w4.w});
+            else *reinterpret_cast<uint4*>(dst + q * EPV) = w4;
+        }
+    }
+}
+
 // true when the block took the lean path
 template <int BM, int BN, int WM, int WN, class EP>
 __device__ __forceinline__ bool v3_lean_epilogue(const EP& ep, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16], bf16_t* lds, int m0, int n0,
-                                                 int lane, int wave) {
+                                                 int lane, int wave, bool strips) {
     if constexpr (V3Lean<EP>::OK) {
         const bool lean = m0 + BM <= ep.M && n0 + BN <= ep.N && !ep.preact && ep.drop.thresh == 0u && !ep.map_on &&
                           (ep.act == ACT_NONE || ep.act == ACT_GELU || ep.act == ACT_RELU) && (ep.N & 3) == 0;
         if (!lean) return false;
         constexpr int WTM = BM / WM, WTN = BN / WN;
         const int mw = m0 + (wave / WN) * WTM, nw = n0 + (wave % WN) * WTN;
+        if (!strips) {                                         // registers only: no stage memory is touched, no block barrier needed
+            if (ep.act == ACT_NONE) v3_lean_store_regs<ACT_NONE, WTM, WTN>(ep, acc, mw, nw, lane);
+            else if (ep.act == ACT_GELU) v3_lean_store_regs<ACT_GELU, WTM, WTN>(ep, acc, mw, nw, lane);
+            else v3_lean_store_regs<ACT_RELU, WTM, WTN>(ep, acc, mw, nw, lane);
+            return true;
+        }
         __syncthreads();                                       // every wave is done with the stage memory
         if (ep.act == ACT_NONE) v3_lean_store<ACT_NONE, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
         else if (ep.act == ACT_GELU) v3_lean_store<ACT_GELU, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
@@ -389,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
 #undef V3_READ_B
 #undef V3_MMA
     if (V3_ABL(128)) return;
-    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave))
+    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave, (abl & 256) == 0))
         tile_epilogue<BM, BN, WM, WN, 2 * BUF * 2, EP, LEAN>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
     V3_STAMP(3);
 }
@@ -508,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
 #undef V3_MMA
 #undef V3_TILE
     if (V3_ABL(128)) return;
-    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave))
+    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave, (abl & 256) == 0))
         tile_epilogue<BM, BN, WM, WN, 3 * BUF * 2, EP, LEAN>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
     V3_STAMP(3);
 }

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3mc_256x256_kernel(AL al,
 #undef V3M_READ_A
 #undef V3M_READ_B
 #undef V3M_MMA
-    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave))
+    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave, (abl & 256) == 0))
         tile_epilogue<BM, BN, WM, WN, 2 * BUF * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
     V3_STAMP(3);
 }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3mc_256x128_kernel(AL al,
 #undef V3M_MMA
 #undef V3M_TILE
 #undef V3M_COMPUTE_BEGIN
-    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave))
+    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave, (abl & 256) == 0))
         tile_epilogue<BM, BN, WM, WN, 3 * BUF * 2>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
     V3_STAMP(3);
 }
