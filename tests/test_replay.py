@@ -85,7 +85,7 @@ def test_replay_draws_new_dropout_masks(backend):
     buckets = vd.GradientBuckets(model, bucket_mb=1.0)
     opt = FusedPretrainOptimizer(model, buckets, cnn_lr=0.0, lr=0.0, weight_decay=0.0, total_steps=50, warmup_steps=6, start_step=2)
     try:
-        replay = StepReplay(model, buckets, opt, _batch(7, dev), warmup=1, validate=True)
+        replay = StepReplay(model, buckets, opt, _batch(7, dev), warmup=1, validate=backend != "emu")   # (validation: the test above)
         losses = [replay(None).item() for _ in range(4)]
         assert len({round(l, 6) for l in losses}) == 4, losses
     finally:

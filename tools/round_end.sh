@@ -5,19 +5,23 @@ set -x
 R=$GRAFT_REPO_ROOT
 cd $R
 python -m pytest tests -q -m gpu 2>&1 | tail -3 > gpurun_out/gpu_tests.txt
-python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --steps 9 --warmup 3 > $R/gpurun_out/prof_kt.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ks -- python $R/bench.py --no-cpu-baseline --no-fidelity --serial-streams --steps 9 --warmup 3 > $R/gpurun_out/prof_ks.log 2>&1
+# PMC passes FIRST: the default bench line below then reports roofline.traffic from a table measured on these very sources
 [ -n "$SKIP_PMC" ] || rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 > $R/gpurun_out/prof_fetch.log 2>&1
 [ -n "$SKIP_PMC" ] || rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_write -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 > $R/gpurun_out/prof_write.log 2>&1
 cd $R
-python tools/rocpd_stats.py $(find gpurun_out/prof_kt -name "*.db" | head -1) 60 > gpurun_out/kernel_stats.txt
-python tools/rocpd_stats.py $(find gpurun_out/prof_ks -name "*.db" | head -1) 60 > gpurun_out/kernel_stats_serial.txt
 [ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_fetch -name "*.db" | head -1) "" > gpurun_out/pmc_fetch.txt 2>&1
 [ -n "$SKIP_PMC" ] || python tools/pmc_dump.py $(find gpurun_out/prof_write -name "*.db" | head -1) "" > gpurun_out/pmc_write.txt 2>&1
 # the table bench.py's roofline.traffic reads, stamped with the hash of the kernel sources (copy both into profiles/)
 [ -n "$SKIP_PMC" ] || python tools/pmc_traffic.py gpurun_out/pmc_fetch.txt gpurun_out/pmc_write.txt --json gpurun_out/traffic_table.json > gpurun_out/pmc_traffic.txt 2>&1
+[ -n "$SKIP_PMC" ] || cp gpurun_out/traffic_table.json profiles/traffic_table.json
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --steps 9 --warmup 3 > $R/gpurun_out/prof_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ks -- python $R/bench.py --no-cpu-baseline --no-fidelity --serial-streams --steps 9 --warmup 3 > $R/gpurun_out/prof_ks.log 2>&1
+cd $R
+python tools/rocpd_stats.py $(find gpurun_out/prof_kt -name "*.db" | head -1) 60 > gpurun_out/kernel_stats.txt
+python tools/rocpd_stats.py $(find gpurun_out/prof_ks -name "*.db" | head -1) 60 > gpurun_out/kernel_stats_serial.txt
 find gpurun_out -name "*.db" -delete
 grep -h '^{' gpurun_out/prof_ks.log | tail -1 > gpurun_out/bench_serial.json
 # BASELINE configs 4 and 5 (host-bound at these batch sizes): bench line with the roofline leg + kernel trace each
