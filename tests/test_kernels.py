@@ -1064,6 +1064,41 @@ GEN3_PARAMS = [pytest.param("emu", 0, marks=pytest.mark.emu), pytest.param("emu"
                pytest.param("gpu", 0, marks=pytest.mark.gpu)]
 
 
+@pytest.mark.parametrize("backend,late", GEN3_PARAMS)
+def test_generation3_persistent_blocks(backend, late):
+    """vtx_set_switch("gen3_pers", n): n blocks of the 256x256 kernel walk all tiles; the first K tile of a block's NEXT tile is
+    staged in front of the current tile's strip epilogue (strips moved to units the staging leaves alone).  Few blocks, many tiles:
+    interior tiles followed by interior tiles (staged path), by ragged edge tiles (general epilogue, nothing staged) and the
+    other way round; one K tile, odd and even tile counts; every plain epilogue flavour.  Bit-identical to one block per tile."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(321)
+    try:
+        _set_dma_late(backend, late)
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(20))
+        for (M, N, K) in ((256 * 5 + 40, 256 * 3, 64), (256 * 6, 256 * 2 + 8, 192), (256 * 9, 256 * 2, 320)):
+            a = torch.randn(M, K, generator=g).to(dt).to(dev); b = torch.randn(N, K, generator=g).to(dt).to(dev)
+            bias = torch.randn(N, generator=g).to(dev); res = torch.randn(M, N, generator=g).to(dt).to(dev)
+            outs = []
+            for pers in (0, 8):
+                _lib.call("vtx_set_switch", b"gen3_pers", ctypes.c_int(pers))
+                o1 = ops.gemm_nt(a, b, bias, res, act=ops.ACT_GELU)
+                assert _generation() == 3
+                o2 = ops.gemm_nt(a, b, bias, out_f32=True)
+                o3 = ops.gemm_nt(a, b)
+                outs.append((o1.float().cpu(), o2.cpu(), o3.float().cpu()))
+            for x, y in zip(*outs):
+                assert torch.equal(x, y), (M, N, K)
+            ref = F.gelu(a.float().cpu() @ b.float().cpu().t() + bias.cpu()) + res.float().cpu()
+            assert rel_err(outs[1][0], ref) < 1e-2, (M, N, K)
+    finally:
+        _lib.call("vtx_set_switch", b"gen3_pers", ctypes.c_int(0))
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+        _set_dma_late(backend, 0)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("cand", [20, 21])
 def test_generation3_register_transposed_epilogue_equals_the_strips(backend, cand):

@@ -68,6 +68,7 @@ int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
 namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 80; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, n >= 2: taken when the cost model predicts n % of the generation-2 class rate (step A/B: 80 -> 24.26, 100 -> 24.46, off 24.65 ms/step)
+namespace vtxg { int g_vtx_sw_gen3_pers = getenv("VIRTEX_AMD_GEN3_PERS") ? atoi(getenv("VIRTEX_AMD_GEN3_PERS")) : 0; }   // persistent 256x256 generation-3 blocks (gemm_v3.h): n blocks walk all tiles, the next tile's first K tile staged in front of the epilogue.  Measured neutral (text GEMMs 1 144.5 vs 1 147.7 us summed, step 24.40 vs 24.34 ms: profiles/r04_gen3_persistent.txt) -- gfx9 has ONE vmcnt for DMA loads and stores, so the next tile's first wait sits behind the epilogue's stores: off
 namespace vtxg { int g_vtx_sw_gen3_s2 = 0; }   // generation 3 for the stride-2 input-gradient classes (loses per shape: off)
 namespace vtxg { int g_vtx_sw_gen3_mc = getenv("VIRTEX_AMD_GEN3_MC") ? atoi(getenv("VIRTEX_AMD_GEN3_MC")) : 800; }   // generation 3 for the weight gradients (gemm_v3mc.h): 0 forced only, n: taken from M N / (M + N) >= n (MFMA-leaning shapes); step A/B (profiles/r04_ab_gen3_mc_threshold.txt): off 23.78, 200 23.71, 400 23.68, 800 23.64, 1500 23.78 ms
 namespace vtxg { int g_vtx_sw_mc_eff128 = getenv("VIRTEX_AMD_MC_EFF128") ? atoi(getenv("VIRTEX_AMD_MC_EFF128")) : 70; }   // tile picker: 128x128 efficiency (%) for k-major operands (round 3: 84; with generation 3 taking the large text gradients 70 measures 23.66 / 23.88 against 23.73 / 24.04 ms per step on two boxes: profiles/r04_ab_mc_eff128.txt)
@@ -87,6 +88,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     else if (!strcmp(name, "gen3")) vtxg::g_vtx_sw_gen3 = value;
     else if (!strcmp(name, "gen3_mc")) vtxg::g_vtx_sw_gen3_mc = value;
     else if (!strcmp(name, "gen3_s2")) vtxg::g_vtx_sw_gen3_s2 = value;
+    else if (!strcmp(name, "gen3_pers")) vtxg::g_vtx_sw_gen3_pers = value < 0 ? 0 : (value & ~7);
     else if (!strcmp(name, "conv3x3_shared")) vtxg::g_vtx_sw_conv3x3_shared = value;
     else if (!strcmp(name, "tile64x256")) vtxg::g_vtx_sw_tile64x256 = value;
     else if (!strcmp(name, "mc_eff128")) vtxg::g_vtx_sw_mc_eff128 = value > 0 ? value : 70;

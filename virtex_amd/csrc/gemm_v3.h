@@ -112,6 +112,14 @@ __device__ __forceinline__ void v3_block_tile(int abl, int& tile, int& slice) {
     }
 }
 
+// the same map for the L-th VIRTUAL block of a persistent launch (T tiles, no split-K): physical block p works off the virtual
+// blocks p, p + G, p + 2G, ... with G a multiple of 8, so every virtual block of a physical block lies in the tile range of ITS XCD
+__device__ __forceinline__ int v3_vb_tile(int abl, int L, int T) {
+    if (abl & 32) return L;
+    const int q = T >> 3, r = T & 7, xcd = L & 7, idx = L >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // A/B builds (python -m virtex_amd.build --variant X --define ...): VTX3_NO_LGKM0 leaves the fragment waits to hipcc's own
 // lgkmcnt ladder inside the MFMA cluster, VTX3_NO_PRIO drops the priority flips, VTX3_NO_STAGGER runs the two wave groups in
 // lockstep (what the stagger is worth)
@@ -282,13 +290,22 @@ __device__ __forceinline__ void v3_lean_store_regs(const EpiStore<T, STATS_NONE>
     }
 }
 
+// does the tile at (m0, n0) take the lean path?  (block-uniform)
+template <int BM, int BN, class EP> __device__ __forceinline__ bool v3_lean_ok(const EP& ep, int m0, int n0) {
+    if constexpr (V3Lean<EP>::OK) {
+        return m0 + BM <= ep.M && n0 + BN <= ep.N && !ep.preact && ep.drop.thresh == 0u && !ep.map_on &&
+               (ep.act == ACT_NONE || ep.act == ACT_GELU || ep.act == ACT_RELU) && (ep.N & 3) == 0;
+    } else {
+        return false;
+    }
+}
+
 // true when the block took the lean path
 template <int BM, int BN, int WM, int WN, class EP>
 __device__ __forceinline__ bool v3_lean_epilogue(const EP& ep, f32x4_t (&acc)[BM / WM / 16][BN / WN / 16], bf16_t* lds, int m0, int n0,
                                                  int lane, int wave, bool strips) {
     if constexpr (V3Lean<EP>::OK) {
-        const bool lean = m0 + BM <= ep.M && n0 + BN <= ep.N && !ep.preact && ep.drop.thresh == 0u && !ep.map_on &&
-                          (ep.act == ACT_NONE || ep.act == ACT_GELU || ep.act == ACT_RELU) && (ep.N & 3) == 0;
+        const bool lean = v3_lean_ok<BM, BN>(ep, m0, n0);
         if (!lean) return false;
         constexpr int WTM = BM / WM, WTN = BN / WN;
         const int mw = m0 + (wave / WN) * WTM, nw = n0 + (wave % WN) * WTN;
@@ -298,7 +315,10 @@ __device__ __forceinline__ bool v3_lean_epilogue(const EP& ep, f32x4_t (&acc)[BM
             else v3_lean_store_regs<ACT_RELU, WTM, WTN>(ep, acc, mw, nw, lane);
             return true;
         }
-        __syncthreads();                                       // every wave is done with the stage memory
+        // every wave is done with the stage memory (a raw barrier: __syncthreads() would also drain vmcnt, i.e. wait for the
+        // NEXT tile's staged units of a persistent block to land before the first strip is written)
+        VTX3_WAIT_LGKM(0);
+        __builtin_amdgcn_s_barrier();
         if (ep.act == ACT_NONE) v3_lean_store<ACT_NONE, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
         else if (ep.act == ACT_GELU) v3_lean_store<ACT_GELU, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
         else v3_lean_store<ACT_RELU, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
@@ -317,9 +337,9 @@ __device__ __forceinline__ bool v3_lean_epilogue(const EP& ep, f32x4_t (&acc)[BM
 //   1: O.A1 <- t+1   2: E.B0 <- t+2   3: E.A0 <- t+2   4: E.B1 <- t+2   [vmcnt(6): O complete]
 //   5: E.A1 <- t+2   6: O.B0 <- t+3   7: O.A0 <- t+3   8: O.B1 <- t+3   [vmcnt(6): E complete]
 // WAR: E.B0 last read in phase 1 behind lgkmcnt(8) -> phase 2; E.A0 phase 1 -> 3; E.B1 phase 2 -> 4; E.A1 phase 3 -> 5; O alike.
-template <class AL, class BL, class EP, bool LEAN = false>
+template <class AL, class BL, class EP, bool LEAN = false, bool PERS = false>
 __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
-                                                                        int abl, unsigned long long* dbg) {
+                                                                        int abl, unsigned long long* dbg, int vb_tiles) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, MT = 8, NT = 4;
     constexpr int BUF = 4 * V3_UNIT;
     typedef UnitStager<128, 64, AL> SA;
@@ -329,10 +349,20 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     V3_STAMP(0);
+    // PERS (launch_v3: more tiles than CUs, no split-K, plain epilogue): one block per CU walks the virtual blocks L, L + G, ...;
+    // the first K tile (and one unit of the second) of the NEXT tile are staged in front of the current tile's epilogue, whose
+    // strips live in units the staging leaves alone -- the DMA latency, the stager set-up and the dispatch of a new block (what
+    // the stamps call the prologue: 4 400 cycles, plus the launch of the block itself) disappear behind the epilogue's stores.
+    // MEASURED NEUTRAL and off by default (vtx_set_switch("gen3_pers", 256)): the counted `s_waitcnt vmcnt` of the next tile's
+    // first phases counts the epilogue's STORES too (one in-order counter for loads and stores on gfx9), so the K loop restarts
+    // when the stores have drained -- which is what the epilogue costs (all 256 CUs flush 128 KiB each at the same moment).
+    // Hiding that drain needs waves that never wait on vmcnt in the K loop: DMA issued by a producer wave.
     int tile, slice;
-    v3_block_tile(abl, tile, slice);
+    int L = blockIdx.x;
+    if constexpr (PERS) { tile = v3_vb_tile(abl, L, vb_tiles); slice = 0; }
+    else v3_block_tile(abl, tile, slice);
     set_slice(ep, slice);
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nkt = (K + 63) >> 6;
     const int kt0 = slice * kt_per_split;
     const int kt1 = kt0 + kt_per_split < nkt ? kt0 + kt_per_split : nkt;
@@ -340,7 +370,9 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
     SA sa; SB sb;
     sa.init(al, m0, wave, lane);
     sb.init(bl, n0, wave, lane);
+    bool staged = false;                 // the units of the current tile's prologue that do not collide with the strips are in flight
     f32x4_t acc[MT][NT];
+    for (;;) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -385,14 +417,18 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
 
     if (kt0 < kt1 && !V3_ABL(64)) {
         // prologue: the whole first tile, three units of the second
-        sb.template issue<0>(bl, kt0 * 64, true, E + B0, wave);
-        sa.template issue<0>(al, kt0 * 64, true, E + A0, wave);
-        sb.template issue<1>(bl, kt0 * 64, true, E + B1, wave);
-        sa.template issue<1>(al, kt0 * 64, true, E + A1, wave);
-        {
+        if (!staged) {
+            sb.template issue<0>(bl, kt0 * 64, true, E + B0, wave);
+            sa.template issue<0>(al, kt0 * 64, true, E + A0, wave);
+            sb.template issue<1>(bl, kt0 * 64, true, E + B1, wave);
+            sa.template issue<1>(al, kt0 * 64, true, E + A1, wave);
             const bool v1 = kt0 + 1 < kt1;
             sb.template issue<0>(bl, (kt0 + 1) * 64, v1, O + B0, wave);
             sa.template issue<0>(al, (kt0 + 1) * 64, v1, O + A0, wave);
+            sb.template issue<1>(bl, (kt0 + 1) * 64, v1, O + B1, wave);
+        } else {                                              // E and O.A0 went out in front of the previous tile's epilogue
+            const bool v1 = kt0 + 1 < kt1;
+            sb.template issue<0>(bl, (kt0 + 1) * 64, v1, O + B0, wave);
             sb.template issue<1>(bl, (kt0 + 1) * 64, v1, O + B1, wave);
         }
         VTX3_WAIT_VM(6);
@@ -469,9 +505,38 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
 #undef V3_READ_B
 #undef V3_MMA
     if (V3_ABL(128)) return;
-    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds, m0, n0, lane, wave, (abl & 256) == 0))
+    // ---- the next virtual block: its first K tile goes out NOW when this tile's epilogue is the strip epilogue (which then
+    // uses units 5, 6 and the head of 7: O.A1, O.B0, O.B1 -- the staging below fills units 0-4: E and O.A0)
+    int Ln = 0, tile_n = 0, m0n = 0, n0n = 0;
+    bool more = false;
+    staged = false;
+    if constexpr (PERS) {
+        Ln = L + gridDim.x;
+        more = Ln < vb_tiles;
+        if (more) {
+            tile_n = v3_vb_tile(abl, Ln, vb_tiles);
+            m0n = (tile_n / tiles_n) * BM; n0n = (tile_n % tiles_n) * BN;
+            if (v3_lean_ok<BM, BN>(ep, m0, n0) && (abl & 256) == 0 && kt0 < kt1) {
+                sa.init(al, m0n, wave, lane);                  // (every wave is past its last fragment read: the loop's last barrier)
+                sb.init(bl, n0n, wave, lane);
+                sb.template issue<0>(bl, kt0 * 64, true, lds + 2 * V3_UNIT, wave);
+                sa.template issue<0>(al, kt0 * 64, true, lds + 0 * V3_UNIT, wave);
+                sb.template issue<1>(bl, kt0 * 64, true, lds + 3 * V3_UNIT, wave);
+                sa.template issue<1>(al, kt0 * 64, true, lds + 1 * V3_UNIT, wave);
+                sa.template issue<0>(al, (kt0 + 1) * 64, kt0 + 1 < kt1, lds + BUF + 0 * V3_UNIT, wave);
+                staged = true;
+            }
+        }
+    }
+    if (!v3_lean_epilogue<BM, BN, WM, WN>(ep, acc, lds + (staged ? 5 * V3_UNIT : 0), m0, n0, lane, wave, (abl & 256) == 0))
         tile_epilogue<BM, BN, WM, WN, 2 * BUF * 2, EP, LEAN>(ep, acc, pre, lds, m0, n0, tile / tiles_n, tile % tiles_n, tid, lane, wave);
     V3_STAMP(3);
+    if (!more) break;
+    VTX3_WAIT_LGKM(0);                                         // every wave is done with the epilogue's LDS (strips: units 6 / 7 are staged
+    __builtin_amdgcn_s_barrier();                              // next; general epilogue: all of it) -- no vmcnt drain: the stores and the staged units stay in flight
+    if (!staged) { sa.init(al, m0n, wave, lane); sb.init(bl, n0n, wave, lane); }
+    L = Ln; tile = tile_n; m0 = m0n; n0 = n0n;
+    }
 }
 
 // ------------------------------------------------------------------ 256 x 128: waves 4 (M) x 2 (N), wave tile 64 x 64
@@ -482,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x256_kernel(AL al, B
 // unit was last read two phases earlier) and `vmcnt(6)` in phase 2 leaves exactly that tile in flight: tile t+1 is complete.
 template <class AL, class BL, class EP, bool LEAN = false>
 __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
-                                                                        int abl, unsigned long long* dbg) {
+                                                                        int abl, unsigned long long* dbg, int /*vb_tiles: 256x256 only*/) {
     constexpr int BM = 256, BN = 128, WM = 4, WN = 2, MT = 4, NT = 4;
     constexpr int BUF = 3 * V3_UNIT;
     typedef UnitStager<64, 32, AL> SA;
@@ -597,6 +662,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3_256x128_kernel(AL al, B
 
 // ------------------------------------------------------------------ host side
 extern unsigned long long* g_vtx_dbg;   // measurement builds: time-stamp buffer of the generation-3 kernels (vtx_set_debug_buffer), else null
+extern int g_vtx_sw_gen3_pers;   // vtx_set_switch("gen3_pers"): 0 = off, n = blocks of the persistent 256x256 form (taken from more than n tiles; 256 = one per CU)
 extern int g_vtx_sw_gen3;        // vtx_set_switch("gen3"): 0 = generation 3 only when forced by the tile override (20 / 21), 1 = automatic
 
 template <int BN, class AL, class BL, class EP>
@@ -622,13 +688,22 @@ inline int launch_v3(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
     if constexpr (EP::STATS && EP::STAGED) {
         if (lean_host_ok(ep_in, M, N, BM, BN)) kern = pick(std::true_type{});
     }
+    // persistent form (256x256, row-major operands, plain epilogue, no split-K, more tiles than CUs): one block per CU
+    bool pers = false;
+    if constexpr (!AL::MC && BN == 256 && V3Lean<EP>::OK && sizeof(typename EP::Out) == 2) {   // (fp32 strips: 68 KiB, no room beside the staged units)
+        pers = g_vtx_sw_gen3_pers && split_k == 1 && tiles_m * tiles_n > g_vtx_sw_gen3_pers;
+        if (pers) kern = contraction_v3_256x256_kernel<AL, BL, EP, false, true>;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)pick(std::false_type{}), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if constexpr (EP::STATS && EP::STAGED) hipFuncSetAttribute((const void*)pick(std::true_type{}), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if constexpr (!AL::MC && BN == 256 && V3Lean<EP>::OK && sizeof(typename EP::Out) == 2)
+            hipFuncSetAttribute((const void*)contraction_v3_256x256_kernel<AL, BL, EP, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         attr_set = true;
     }
-    dim3 grid(tiles_m * tiles_n, split_k), block(512);
+    const int vb_tiles = tiles_m * tiles_n;
+    dim3 grid(pers ? g_vtx_sw_gen3_pers : vb_tiles, split_k), block(512);
     g_vtx_last_colgroups = tiles_n * WN;
     EP ep = ep_in;
     if constexpr (EP::STAGED) ep.nt = vtx_nt_policy((double)M * N * sizeof(typename EP::Out));
@@ -639,10 +714,10 @@ inline int launch_v3(const AL& al, const BL& bl, const EP& ep_in, int M, int N, 
         if (prof) {
             hipEvent_t e0, e1;
             vtx_prof_events(cls, 2.0 * M * N * K, 2.0 * (algo_elems(al) + algo_elems(bl)) + epi_bytes(ep, (double)M * N, split_k), &e0, &e1);
-            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds_bytes, st, e0, e1, 0, al, bl, ep, K, tiles_n, per, g_vtx_ablate, g_vtx_dbg);
+            hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds_bytes, st, e0, e1, 0, al, bl, ep, K, tiles_n, per, g_vtx_ablate, g_vtx_dbg, vb_tiles);
             return tiles_m;
         }
     }
-    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate, g_vtx_dbg);
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, st, al, bl, ep, K, tiles_n, per, g_vtx_ablate, g_vtx_dbg, vb_tiles);
     return tiles_m;
 }

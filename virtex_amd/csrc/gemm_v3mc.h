@@ -66,7 +66,7 @@ constexpr int V3_UB = V3_UNIT * 2;            // bytes of a unit
 // ------------------------------------------------------------------ 256 x 256 (see contraction_v3_256x256_kernel)
 template <class AL, class BL, class EP>
 __global__ __launch_bounds__(512, 2) void contraction_v3mc_256x256_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
-                                                                          int abl, unsigned long long* dbg) {
+                                                                          int abl, unsigned long long* dbg, int /*vb_tiles: unused*/) {
     constexpr int BM = 256, BN = 256, WM = 2, WN = 4, MT = 8, NT = 4;
     constexpr int BUF = 4 * V3_UNIT;
     typedef UnitStagerMC<128, 64, AL> SA;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void contraction_v3mc_256x256_kernel(AL al,
 // ------------------------------------------------------------------ 256 x 128 (see contraction_v3_256x128_kernel)
 template <class AL, class BL, class EP>
 __global__ __launch_bounds__(512, 2) void contraction_v3mc_256x128_kernel(AL al, BL bl, EP ep, int K, int tiles_n, int kt_per_split,
-                                                                          int abl, unsigned long long* dbg) {
+                                                                          int abl, unsigned long long* dbg, int /*vb_tiles: unused*/) {
     constexpr int BM = 256, BN = 128, WM = 4, WN = 2, MT = 4, NT = 4;
     constexpr int BUF = 3 * V3_UNIT;
     typedef UnitStagerMC<64, 32, AL> SA;
