@@ -32,7 +32,7 @@ def class_name(kernel):
     normalised; other kernels by launch family"""
     k = kernel[5:] if kernel.startswith("void ") else kernel
     if k.startswith("contraction_") or k.startswith("conv3x3_shared_kernel"):
-        k = re.sub(r", (true|false)>$", ">", k)
+        k = re.sub(r"(, (true|false))+>$", ">", k)            # trailing compile-time flags (LEAN, persistent form)
         return re.sub(r"\s*>\s*$", ">", k).replace(" >", ">")
     for prefix, fam in FAMILIES:
         if k.startswith(prefix):
