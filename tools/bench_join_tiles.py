@@ -8,7 +8,7 @@ from virtex_amd import ops, _lib
 
 B, dt = 256, torch.bfloat16
 lib = _lib.lib()
-names = {-1: "auto", 0: "256x256", 1: "256x128", 2: "128x128", 6: "128x128w8"}
+names = {-1: "auto", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x128", 5: "64x64", 6: "128x128w8"}
 
 
 def timeit(fn, iters=10, warm=3):
