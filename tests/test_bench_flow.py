@@ -12,7 +12,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RUNNER = os.path.join(ROOT, "tests", "bench_flow_runner.py")
 ARGS = ["--steps", "2", "--warmup", "1", "--batch", "2", "--image-size", "64", "--vocab-size", "304", "--dtype", "bf16",
-        "--textual", "transdec_postnorm::L1_H128_A2_F256", "--no-cpu-baseline", "--roofline-steps", "1"]
+        "--textual", "transdec_postnorm::L1_H128_A2_F256", "--no-cpu-baseline", "--roofline-steps", "1",
+        "--launch", "eager"]      # (launch replay has its own tests: on the emulator its warm-up / validation / recording steps cost minutes)
 REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline"}
 
