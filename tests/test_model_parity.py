@@ -702,3 +702,37 @@ def test_relu_mask_bits_leave_the_step_unchanged(backend):
         if "embedding" in n:            # fed by fp32 atomics: not bit-reproducible run to run
             continue
         assert torch.equal(runs[True][1][n], runs[False][1][n]), n
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_padding_to_a_fixed_caption_length_changes_nothing_on_the_kernels(backend):
+    """data.collate_captions(pad_to=T) -- the one batch shape launch replay needs -- on the HIP path: extra padding columns must
+    be masked by the attention kernels (key padding), zeroed by the embedding kernel and ignored by the fused projection + loss:
+    same loss, same gradients as the batch padded to its longest caption (fp32; text side to summation order, the backbone
+    through the toy's conditioning)."""
+    dev = select(backend)
+    _, model, batch = _build_pair("r50_l2_h128_b3_small", dev, torch.float32)
+    lengths = batch["caption_lengths"].clone()
+    T = batch["caption_tokens"].shape[1]
+    lengths[:] = torch.tensor([max(3, T - 3 - i) for i in range(lengths.numel())])           # ragged, all shorter than T
+    tok = batch["caption_tokens"].clone()
+    for i, L in enumerate(lengths.tolist()):
+        tok[i, L - 1] = 2; tok[i, L:] = 0
+    rev = torch.zeros_like(tok)
+    for i, L in enumerate(lengths.tolist()):
+        rev[i, :L] = tok[i, :L].flip(0)
+    longest = int(lengths.max())
+    short = dict(batch, caption_tokens=tok[:, :longest].contiguous(), noitpac_tokens=rev[:, :longest].contiguous(), caption_lengths=lengths)
+    fixed = dict(batch, caption_tokens=tok, noitpac_tokens=rev, caption_lengths=lengths)
+    assert longest < T
+    runs = []
+    for b in (short, fixed):
+        model.zero_grad(set_to_none=True)
+        out = _run(model, b, dev)
+        runs.append((out["loss"].item(), {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters()}))
+    assert abs(runs[0][0] - runs[1][0]) <= 2e-6 * abs(runs[0][0]), (runs[0][0], runs[1][0])
+    for n, g in runs[0][1].items():
+        if "cnn" not in n:
+            assert rel_err(runs[1][1][n], g) < 2e-5, n
+    worst = max(rel_err(runs[1][1][n], g) for n, g in runs[0][1].items() if "cnn" in n and g.norm() > 0)
+    assert worst < 2e-2
