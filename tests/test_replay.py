@@ -61,6 +61,10 @@ def test_replayed_steps_equal_eager_steps(backend):
             la = _eager_step(ma, ba, oa, batch)
             lb = replay(batch).clone()
             assert abs(la.item() - lb.item()) <= 1e-5 * abs(la.item()), (it, la.item(), lb.item())
+        odd = _batch(300, dev)
+        odd = dict(odd, caption_tokens=odd["caption_tokens"][:, :-1].contiguous(), noitpac_tokens=odd["noitpac_tokens"][:, :-1].contiguous())
+        with pytest.raises(ValueError):                                                   # a recording is a list of launches on fixed shapes
+            replay(odd)
         replay.sync()
         oa.sync_host()
         assert ob.step_idx == oa.step_idx and ob.kc == oa.kc
