@@ -829,6 +829,75 @@ def test_tied_projection_cross_entropy_without_logits(backend, dtype, R, V, H):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cand", [20, 21])
+def test_feed_forward_epilogue_on_generation3(backend, cand):
+    """bias -> pre-activation copy -> GELU -> dropout (the first GEMM of the decoder's feed-forward layer in training) on the lean
+    strip path of the generation-3 kernels: output AND pre-activation equal generation 2 bit for bit (same arithmetic, same
+    dropout hash of the element index), interior tiles and a ragged edge."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    g = torch.Generator().manual_seed(40 + cand)
+    M, N, K = 256 * 2 + 24, 256 * 2 + 8, 128
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev); b = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    res = {}
+    try:
+        for c in (2, cand):
+            _lib.lib().vtx_set_tile_override(ctypes.c_int(c))
+            out, pre = ops.gemm_nt(a, b, bias=bias, act=ops.ACT_GELU, want_preact=True, p_drop=0.25, seed=1234)
+            assert _generation() == (3 if c >= 20 else 2)
+            res[c] = (out.float().cpu(), pre.float().cpu())
+    finally:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+    assert torch.equal(res[cand][1], res[2][1]) and torch.equal(res[cand][0], res[2][0])
+    ref_pre = a.float().cpu() @ b.float().cpu().t() + bias.cpu()
+    assert rel_err(res[cand][1], ref_pre) < 1e-2
+    kept = res[cand][0] != 0
+    assert 0.70 < kept.float().mean().item() < 0.80                       # p = 0.25
+    assert rel_err(res[cand][0][kept], (F.gelu(ref_pre) / 0.75)[kept]) < 2e-2
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("cand", [20, 21])
+def test_tied_projection_cross_entropy_on_generation3(backend, cand):
+    """The same two entry points on the generation-3 kernels (forced: 256x256 / 256x128 blocks), interior tiles AND a ragged last
+    column / row of tiles: the row log-sum-exp epilogue with its bias values and targets hoisted, and the cross-entropy
+    gradient epilogue (g * (softmax - onehot)) on the lean strip path -- equal to the generation-2 result element for element
+    (same arithmetic), and to torch within bf16."""
+    import ctypes
+    from virtex_amd import _lib
+    dev = select(backend)
+    dtype = torch.bfloat16
+    R, V, H = 256 * 2 + 24, 256 * 3 + 40, 128
+    g = torch.Generator().manual_seed(cand)
+    h = torch.randn(R, H, generator=g).to(dtype); w = (0.3 * torch.randn(V, H, generator=g)).to(dtype)
+    bias = 0.2 * torch.randn(V, generator=g)
+    tgt = torch.randint(1, V, (R,), generator=g)
+    tgt[::7] = 0
+    logits = (h.float() @ w.float().t() + bias).requires_grad_()
+    ref = F.cross_entropy(logits, tgt, ignore_index=0)
+    ref.backward()
+    gout = torch.tensor([1.7])
+    res = {}
+    try:
+        for c in (2, cand):                                   # 2: generation-2 128x128 tiles
+            _lib.lib().vtx_set_tile_override(ctypes.c_int(c))
+            lc, lse = ops.tied_ce_fwd(h.to(dev), w.to(dev), bias.to(dev), tgt.to(dev), 0)
+            assert _generation() == (3 if c >= 20 else 2)
+            d = ops.tied_ce_bwd(h.to(dev), w.to(dev), bias.to(dev), tgt.to(dev), lse, lc, gout.to(dev), 0)
+            assert _generation() == (3 if c >= 20 else 2)
+            res[c] = (lc.cpu().clone(), lse.cpu().clone(), d.float().cpu().clone())
+    finally:
+        _lib.lib().vtx_set_tile_override(ctypes.c_int(-1))
+    assert abs(res[cand][0][0].item() - ref.item()) < 2e-4 * abs(ref.item())
+    assert torch.allclose(res[cand][1], torch.logsumexp(logits.detach(), 1), rtol=2e-4, atol=2e-4)
+    assert rel_err(res[cand][2], 1.7 * logits.grad) < 1e-2
+    assert torch.allclose(res[cand][1], res[2][1], rtol=1e-6, atol=1e-6)      # (column groups differ: the fold order of the partials does)
+    assert torch.equal(res[cand][2] != 0, res[2][2] != 0) and rel_err(res[cand][2], res[2][2]) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,H,W,C", [(2, 12, 12, 64), (3, 9, 11, 16)])
 def test_stem_tail_maxpool_backward_inside_batchnorm_backward(backend, dtype, N, H, W, C):

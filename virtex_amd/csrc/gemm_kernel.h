@@ -890,26 +890,46 @@ template <class T, int S> __device__ __forceinline__ void set_slice(EpiStore<T, 
 }
 
 // mw / nw: first row / column of the wave tile; group: index of this column range (tile_n * waves-per-row + wn)
+// (round 4: the bias values and the column bounds of a lane do not depend on the row step -- they were re-loaded, one 4-byte
+//  global load per element behind possibly-aliasing stores, in every one of the MT steps; the targets of all steps are requested
+//  up front too)
 template <int MT, int NT, class EP>
 __device__ __forceinline__ void rowlse_epilogue(const EP& ep, f32x4_t (&acc)[MT][NT], int mw, int nw, int lane, int group) {
+    float bz[NT][4];
+    bool okc[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = nw + j * 16 + 4 * (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            okc[j][q] = n + q < ep.N;
+            bz[j][q] = (okc[j][q] && ep.bias) ? ep.bias[n + q] : 0.f;
+        }
+    }
+    long long tg[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = mw + i * 16 + (lane & 15);
+        tg[i] = m < ep.M ? ep.targets[m] : -1;
+    }
+    vtx_loads_issued();
+    const float alpha = ep.alpha;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int m = mw + i * 16 + (lane & 15);
         const bool mok = m < ep.M;
-        const long long t = mok ? ep.targets[m] : -1;
+        const int tc = (int)tg[i] - nw - 4 * (lane >> 4);          // the target's column relative to this lane's first column
         float v[NT][4];
         float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = nw + j * 16 + 4 * (lane >> 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bool nok = n + q < ep.N;
-                const float x = acc[i][j][q] * ep.alpha + ((nok && ep.bias) ? ep.bias[n + q] : 0.f);
+                const float x = acc[i][j][q] * alpha + bz[j][q];
                 v[j][q] = x;
-                if (nok) {
+                if (okc[j][q]) {
                     mx = fmaxf(mx, x);
-                    if (mok && t == (long long)(n + q)) ep.tgt_logit[m] = x;
+                    if (mok && tc == j * 16 + q) ep.tgt_logit[m] = x;
                 }
             }
         }
@@ -918,10 +938,9 @@ __device__ __forceinline__ void rowlse_epilogue(const EP& ep, f32x4_t (&acc)[MT]
         float sm = 0.f;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-            const int n = nw + j * 16 + 4 * (lane >> 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (n + q < ep.N) sm += __expf(v[j][q] - mx);
+                if (okc[j][q]) sm += __expf(v[j][q] - mx);
         }
         sm += __shfl_xor(sm, 16, 64);
         sm += __shfl_xor(sm, 32, 64);

@@ -163,7 +163,9 @@ __device__ __forceinline__ int v3_vb_tile(int abl, int L, int T) {
 template <class EP> struct V3Lean { static constexpr bool OK = false; };
 template <class T> struct V3Lean<EpiStore<T, STATS_NONE>> { static constexpr bool OK = true; };
 
-template <int ACT, int WTM, int WTN, class T>
+// PD: the pre-activation copy and the dropout of the feed-forward layer's first GEMM (transdec: gelu -> dropout, with the
+// pre-activation kept for the backward pass) -- the pre-activation values take a second strip of the same step.
+template <int ACT, int WTM, int WTN, class T, bool PD = false>
 __device__ __forceinline__ void v3_lean_store(const EpiStore<T, STATS_NONE>& ep, f32x4_t (&acc)[WTM / 16][WTN / 16], bf16_t* lds,
                                               int mw, int nw, int lane, int wave) {
     constexpr int MT = WTM / 16, NT = WTN / 16;
@@ -178,9 +180,18 @@ __device__ __forceinline__ void v3_lean_store(const EpiStore<T, STATS_NONE>& ep,
     for (int j = 0; j < NT; ++j) bv[j] = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + nw + j * 16 + 4 * (lane >> 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float alpha = ep.alpha;
     const bool has_res = ep.residual != nullptr;
+    // ACT_SOFTMAX_GRAD (the tied projection recomputed in the cross-entropy backward): target, scale and log-sum-exp of the lane's
+    // row in every 16-row step, all requested here -- the general epilogue this mode used to take costs 37 000 cycles per tile
+    typename EpiStore<T, STATS_NONE>::RowData rd[ACT == ACT_SOFTMAX_GRAD ? MT : 1];
+    if constexpr (ACT == ACT_SOFTMAX_GRAD) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) rd[i] = ep.row_data(mw + i * 16 + (lane & 15));
+        vtx_loads_issued();
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-        char* const strip = strip0 + (i & 1) * (16 * ROWB);
+        char* const strip = strip0 + (PD ? 1 : (i & 1)) * (16 * ROWB);
+        char* const pstrip = strip0;                           // PD: pre-activation values of the step
         uint4 res[NCH];
         if (has_res) {                                         // requested before the step's trip through the strip
 #pragma unroll
@@ -193,12 +204,26 @@ __device__ __forceinline__ void v3_lean_store(const EpiStore<T, STATS_NONE>& ep,
         for (int j = 0; j < NT; ++j) {
             f32x4_t v = acc[i][j] * alpha;
             v[0] += bv[j].x; v[1] += bv[j].y; v[2] += bv[j].z; v[3] += bv[j].w;
+            if constexpr (PD) {
+                if (ep.preact) st4v<T>(reinterpret_cast<T*>(pstrip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
+            }
             if constexpr (ACT == ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
             } else if constexpr (ACT == ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if constexpr (ACT == ACT_SOFTMAX_GRAD) {
+                const int n = nw + j * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rd[i].g * (__expf(v[e] - rd[i].l) - ((long long)(n + e) == rd[i].t ? 1.f : 0.f));
+            }
+            if constexpr (PD) {
+                if (ep.drop.thresh) {
+                    const long o = (long)(mw + i * 16 + (lane & 15)) * ep.ldc + nw + j * 16 + 4 * (lane >> 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ep.drop.apply(v[e], (uint64_t)(o + e));
+                }
             }
             st4v<T>(reinterpret_cast<T*>(strip + (lane & 15) * ROWB) + j * 16 + 4 * (lane >> 4), v);
         }
@@ -207,11 +232,17 @@ __device__ __forceinline__ void v3_lean_store(const EpiStore<T, STATS_NONE>& ep,
         for (int q = 0; q < NCH; ++q) {
             const int c = lane + 64 * q, r = c / CPR, ch = c % CPR;
             uint4 w = *reinterpret_cast<const uint4*>(strip + r * ROWB + ch * 16);
+            if constexpr (PD) {
+                if (ep.preact)
+                    *reinterpret_cast<uint4*>(ep.preact + (long)(mw + i * 16 + r) * ep.ldc + nw + ch * EPV) =
+                        *reinterpret_cast<const uint4*>(pstrip + r * ROWB + ch * 16);
+            }
             if (has_res) w = add16<T>(w, res[q]);
             T* dst = ep.out + (long)(mw + i * 16 + r) * ep.ldc + nw + ch * EPV + ep.split_off;
             if (ep.nt) st16_nt(dst, u32x4_t{w.x, w.y, w.z, w.w});
             else *reinterpret_cast<uint4*>(dst) = w;
         }
+        if constexpr (PD) __builtin_amdgcn_wave_barrier();     // both strips are re-written by the next step
         // (the other strip is written next: this one is re-written two steps from now, behind the next wave barrier)
     }
 }
@@ -293,8 +324,9 @@ __device__ __forceinline__ void v3_lean_store_regs(const EpiStore<T, STATS_NONE>
 // does the tile at (m0, n0) take the lean path?  (block-uniform)
 template <int BM, int BN, class EP> __device__ __forceinline__ bool v3_lean_ok(const EP& ep, int m0, int n0) {
     if constexpr (V3Lean<EP>::OK) {
-        return m0 + BM <= ep.M && n0 + BN <= ep.N && !ep.preact && ep.drop.thresh == 0u && !ep.map_on &&
-               (ep.act == ACT_NONE || ep.act == ACT_GELU || ep.act == ACT_RELU) && (ep.N & 3) == 0;
+        const bool pd = ep.preact || ep.drop.thresh != 0u;      // pre-activation copy / dropout: the GELU instantiation only (the feed-forward layer)
+        return m0 + BM <= ep.M && n0 + BN <= ep.N && (!pd || ep.act == ACT_GELU) && !ep.map_on &&
+               (ep.act == ACT_NONE || ep.act == ACT_GELU || ep.act == ACT_RELU || ep.act == ACT_SOFTMAX_GRAD) && (ep.N & 3) == 0;
     } else {
         return false;
     }
@@ -309,7 +341,8 @@ __device__ __forceinline__ bool v3_lean_epilogue(const EP& ep, f32x4_t (&acc)[BM
         if (!lean) return false;
         constexpr int WTM = BM / WM, WTN = BN / WN;
         const int mw = m0 + (wave / WN) * WTM, nw = n0 + (wave % WN) * WTN;
-        if (!strips) {                                         // registers only: no stage memory is touched, no block barrier needed
+        const bool pd = ep.preact || ep.drop.thresh != 0u;
+        if (!strips && ep.act != ACT_SOFTMAX_GRAD && !pd) {           // registers only: no stage memory is touched, no block barrier needed
             if (ep.act == ACT_NONE) v3_lean_store_regs<ACT_NONE, WTM, WTN>(ep, acc, mw, nw, lane);
             else if (ep.act == ACT_GELU) v3_lean_store_regs<ACT_GELU, WTM, WTN>(ep, acc, mw, nw, lane);
             else v3_lean_store_regs<ACT_RELU, WTM, WTN>(ep, acc, mw, nw, lane);
@@ -320,7 +353,9 @@ __device__ __forceinline__ bool v3_lean_epilogue(const EP& ep, f32x4_t (&acc)[BM
         VTX3_WAIT_LGKM(0);
         __builtin_amdgcn_s_barrier();
         if (ep.act == ACT_NONE) v3_lean_store<ACT_NONE, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
+        else if (ep.act == ACT_GELU && pd) v3_lean_store<ACT_GELU, WTM, WTN, typename EP::Out, true>(ep, acc, lds, mw, nw, lane, wave);
         else if (ep.act == ACT_GELU) v3_lean_store<ACT_GELU, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
+        else if (ep.act == ACT_SOFTMAX_GRAD) v3_lean_store<ACT_SOFTMAX_GRAD, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
         else v3_lean_store<ACT_RELU, WTM, WTN>(ep, acc, lds, mw, nw, lane, wave);
         return true;
     } else {
