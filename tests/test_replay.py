@@ -117,3 +117,46 @@ def test_every_recorded_op_is_replayed_on_the_stream_it_was_recorded_on():
             assert at == cur, (i, label, at, cur)
     finally:
         opt.disable_device_schedule()
+
+
+def _autograd_nodes(tensors):
+    """grad_fn nodes reachable from `tensors`"""
+    seen, stack = set(), [t.grad_fn for t in tensors if isinstance(t, torch.Tensor) and t.grad_fn is not None]
+    while stack:
+        n = stack.pop()
+        if n is None or n in seen:
+            continue
+        seen.add(n)
+        stack.extend(fn for fn, _ in n.next_functions)
+    return len(seen)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_replays_do_not_grow_the_autograd_graph_and_two_optimizers_share_the_epoch(backend):
+    """(1) The re-issued ATen operators run with grad mode off: the recorded tensors that still carry a grad_fn must not
+    collect a new CopyBackwards node per replay (a host-memory leak over a 500k-step run).  (2) The dropout epoch is one
+    reference-counted word per device: a second optimizer enabling / disabling its device schedule neither re-points nor
+    nulls the word the first one's replays advance."""
+    dev = select(backend)
+    dt = torch.float32 if backend == "emu" else torch.bfloat16
+    model, buckets, opt = _setup(dev, 0.1, dt)
+    other_m, other_b, other = _setup(dev, 0.1, dt)
+    try:
+        replay = StepReplay(model, buckets, opt, _batch(11, dev), warmup=1, validate=False)
+        kept = [t for t in replay.rec.keep if isinstance(t, torch.Tensor)]
+        replay(None)
+        n0 = _autograd_nodes(kept)
+        for _ in range(3):
+            replay(None)
+        assert _autograd_nodes(kept) == n0
+        other.enable_device_schedule()
+        assert other.dev["epoch"] is opt.dev["epoch"]
+        e0 = int(opt.dev["epoch"].item())
+        other.disable_device_schedule()                      # the first optimizer's registration survives ...
+        replay(None)
+        assert int(opt.dev["epoch"].item()) == e0 + 1        # ... and its replays still advance the registered word
+        la, lb = replay(None).item(), replay(None).item()
+        assert la != lb                                      # masks still change from replay to replay
+    finally:
+        opt.disable_device_schedule()
+        other.disable_device_schedule()

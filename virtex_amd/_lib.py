@@ -71,7 +71,10 @@ def call(name: str, *args):
     if rc != 0:
         raise VtxError(f"{name} failed ({rc}): {lib().vtx_last_error().decode()}")
     if _recorder is not None:            # the same call, re-issued by virtex_amd.replay (arguments are ctypes objects: kept as they are)
-        _recorder.add("kernel", lambda f=fn, a=args: f(*a), args, label=name)
+        def again(f=fn, a=args, n=name):
+            if f(*a) != 0:               # a launch that fails during a replay raises exactly as the eager call does
+                raise VtxError(f"{n} failed during launch replay: {lib().vtx_last_error().decode()}")
+        _recorder.add("kernel", again, args, label=name)
 
 
 # torch.cuda.current_stream() builds a Stream object through three Python layers (4.4 us per call, 2.5 ms of the 12 ms the

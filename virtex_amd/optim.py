@@ -15,6 +15,7 @@ order -- the order the reference's OptimizerFactory builds its one-tensor param 
 """
 import math
 import re
+import weakref
 from typing import Iterable, List, Tuple
 
 import torch
@@ -22,6 +23,36 @@ import torch
 from .streams import branch_stream, wgrad_stream
 
 NO_DECAY = r".*textual.(embedding|transformer).*(norm.*|bias)"
+
+# ---- the device word every dropout kernel mixes into its seed (vtx_set_dropout_epoch): one per device, reference-counted.
+# The C side keeps ONE process-global pointer (one process drives one GPU: DESIGN.md 7), so a registration for a second
+# device while the first is held is refused instead of silently re-pointing the first device's kernels.
+_epoch_words = {}     # device -> tensor (kept for the life of the process: 4 bytes; the registered address never dangles)
+_epoch_refs = {}      # device -> number of optimizers with an enabled device schedule
+
+
+def _epoch_acquire(device, ops):
+    held = [d for d, n in _epoch_refs.items() if n > 0 and d != device]
+    if held:
+        raise RuntimeError(f"a device dropout epoch is registered for {held[0]}; the library holds one registration per "
+                           f"process (one process per GPU) -- disable that optimizer's device schedule first")
+    word = _epoch_words.get(device)
+    if word is None:
+        word = _epoch_words[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    if _epoch_refs.get(device, 0) == 0:
+        ops.set_dropout_epoch(word)
+    _epoch_refs[device] = _epoch_refs.get(device, 0) + 1
+    return word
+
+
+def _epoch_release(device, ops):
+    n = _epoch_refs.get(device, 0) - 1
+    _epoch_refs[device] = max(n, 0)
+    if n == 0:
+        try:
+            ops.set_dropout_epoch(None)
+        except Exception:        # interpreter shutdown: the library may already be gone
+            pass
 
 
 def param_groups(named_parameters: Iterable[Tuple[str, torch.nn.Parameter]], cnn_lr=0.2, lr=0.001,
@@ -228,17 +259,21 @@ class FusedPretrainOptimizer:
         if self.dev is not None:
             return
         d = self.flat_p.device
+        # The dropout epoch is ONE word per device, owned by this module and never freed while any optimizer holds a
+        # registration (_epoch_acquire): the library dereferences the registered address from every dropout kernel of
+        # every model, so the word must not share the lifetime of one optimizer, and a second optimizer's enable /
+        # disable must not re-point or null what the first one's replays read.
         self.dev = {"step": torch.tensor([float(self.step_idx)], dtype=torch.float32, device=d),
                     "kc": torch.tensor([float(self.kc)], dtype=torch.float32, device=d),
                     "sched": torch.zeros(2, dtype=torch.float32, device=d),
-                    "epoch": torch.zeros(1, dtype=torch.int32, device=d)}
-        self.ops.set_dropout_epoch(self.dev["epoch"])
+                    "epoch": _epoch_acquire(d, self.ops)}
+        self._epoch_release = weakref.finalize(self, _epoch_release, d, self.ops)
 
     def disable_device_schedule(self):
         if self.dev is None:
             return
         self.sync_host()
-        self.ops.set_dropout_epoch(None)
+        self._epoch_release()            # detaches the finalizer; the registration goes when the LAST holder lets go
         self.dev = None
 
     def sync_host(self):

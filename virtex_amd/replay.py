@@ -99,6 +99,44 @@ def active() -> Optional[Recorder]:
     return _active
 
 
+# factory operators re-issued as a fill of the tensor the recording produced (their out= overloads take other arguments)
+_FILLS = {
+    "zeros": lambda o, a, k: (lambda: o.zero_()),
+    "zeros_like": lambda o, a, k: (lambda: o.zero_()),
+    "ones": lambda o, a, k: (lambda: o.fill_(1)),
+    "ones_like": lambda o, a, k: (lambda: o.fill_(1)),
+    "full": lambda o, a, k: (lambda v=(a[1] if len(a) > 1 else k["fill_value"]): o.fill_(v)),
+    "full_like": lambda o, a, k: (lambda v=(a[1] if len(a) > 1 else k["fill_value"]): o.fill_(v)),
+}
+_out_cache = {}
+
+
+def _out_variant(func):
+    """The `out=` overload of a functional ATen overload -- same arguments plus ONE `out` tensor, same result -- or None.
+    `o.copy_(f(...))` costs an allocation and a copy launch per replayed operator (87 copy launches per step in the round-4
+    kernel trace); the out= form writes the recorded result tensor directly."""
+    if func in _out_cache:
+        return _out_cache[func]
+    found = None
+    try:
+        packet = func.overloadpacket
+        ov = func._overloadname
+        for cand in (("out",) if ov in ("", "default") else (ov + "_out", "out")):
+            op = getattr(packet, cand, None)
+            if op is None:
+                continue
+            fa = [(a.name, str(a.type)) for a in func._schema.arguments]
+            oa = [(a.name, str(a.type)) for a in op._schema.arguments if not a.is_out]
+            n_out = sum(1 for a in op._schema.arguments if a.is_out)
+            if fa == oa and n_out == 1 and [a.name for a in op._schema.arguments if a.is_out] == ["out"]:
+                found = op
+                break
+    except Exception:
+        found = None
+    _out_cache[func] = found
+    return found
+
+
 class _RecordAten(TorchDispatchMode):
     """Every ATen operator that launches device work, as a thunk that repeats it INTO the tensors the recording produced."""
 
@@ -120,7 +158,16 @@ class _RecordAten(TorchDispatchMode):
         elif any(r.alias_info is not None for r in func._schema.returns):
             return out                                   # a view the table above does not know
         elif outs:                                       # functional: recompute, store into the recorded result
-            if len(outs) == 1:
+            single = len(outs) == 1 and isinstance(out, torch.Tensor)
+            out_op = _out_variant(func) if single else None
+            if single and name in _FILLS:                # factories: refill the recorded tensor (one launch)
+                rec.add("aten", _FILLS[name](outs[0], args, kwargs), args, kwargs, out, label=name + ".refill")
+            elif single and name in ("_to_copy", "clone") and isinstance(args[0], torch.Tensor):
+                rec.add("aten", lambda o=outs[0], src=args[0]: o.copy_(src), args, kwargs, out, label=name + ".copy_")
+            elif out_op is not None:                       # ... by the operator's own out= overload: no temporary, no copy launch
+                rec.add("aten", lambda f=out_op, a=args, k=kwargs, o=outs[0]: f(*a, **k, out=o), args, kwargs, out,
+                        label=name + ".out")
+            elif len(outs) == 1:
                 rec.add("aten", lambda f=func, a=args, k=kwargs, o=outs[0]: o.copy_(f(*a, **k)), args, kwargs, out, label=name)
             else:
                 def thunk(f=func, a=args, k=kwargs, os_=outs):
@@ -239,8 +286,11 @@ def record(step_fn: Callable[[], torch.Tensor]):
 def _run(rec: Recorder):
     """Re-issue a recording; the calling thread ends on the stream it was on (the list may end on another one)."""
     try:
-        for op in rec.ops:
-            op()
+        # no autograd: recorded tensors may still carry requires_grad / grad_fn from the recorded step, and a re-issued
+        # `o.copy_(...)` with grad mode on would hang a new CopyBackwards node on them every replay (an unbounded graph)
+        with torch.no_grad():
+            for op in rec.ops:
+                op()
     finally:
         if rec.start is not None and _current_stream_key() != rec.start:
             _set_stream_key(rec.start)
