@@ -124,6 +124,26 @@ typedef struct VtxBnBwdFusion {
 int vtx_gemm_nt_bnbwd(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb, void* C,
                       long ldc, const void* residual, long ldr, VtxBnBwdFusion* fusion, void* stream);
 
+/* ---- the backward of a Bottleneck's conv3 (1x1, 64 -> 256 @ 56x56) in one streaming kernel (csrc/conv3_bwd.hip) ----
+ * Replaces three launches of the training step's backward through torchvision's Bottleneck (visual_backbones.py:68-74 of the
+ * reference; aten::native_batch_norm_backward of bn3, aten::convolution_backward of conv3):
+ *     dx3 = BatchNormBackward(bn3)(dz)                                    -- finalize of `parts3` + apply, dx3 never stored
+ *     dy2 = mask_bn2(dx3 . wt^T), sums for bn2's backward -> f2->parts    -- as vtx_gemm_nt_bnbwd (mask recomputed from f2->x)
+ *     dw_parts[p] = partial of dx3^T . relu(bn2(x2))                      -- conv3's weight gradient, one fp32 [K][N] per workgroup
+ * dz, x3: [M][K] bf16 (gradient wrt bn3's output, already masked, with its sums in parts3[nparts3][2][K]; bn3's input);
+ * wt: [N][K] (conv3's weight, input-channel-major: vtx_weight_prep's transposed copy); dy2: [M][N]; dgamma3 / dbeta3 are
+ * ACCUMULATED; bn_workspace: vtx_bn_workspace_floats(K) floats.  f2->strips and *dw_nparts return the partial counts;
+ * fold dw_parts into the fp32 weight gradient with vtx_partials_reduce_acc (C[K][N] += sum_p dw_parts[p]).
+ * vtx_conv3_bwd_fused_supported: 1 when (dtype, M, K, N) is taken (bf16, K = 256, N = 64, M % 128 == 0, M >= 512 and the
+ * "conv3_bwd" switch is on); vtx_conv3_bwd_fused_parts(M): partials a launch produces (size dw_parts with parts*K*N floats). */
+int vtx_conv3_bwd_fused_supported(int dtype, int M, int K, int N);
+int vtx_conv3_bwd_fused_parts(int M);
+int vtx_conv3_bwd_fused(int dtype, int M, int K, int N, const void* dz, const void* x3, const float* gamma3,
+                        const float* mean3, const float* rstd3, const float* parts3, int nparts3, float* dgamma3,
+                        float* dbeta3, float* bn_workspace, const void* wt, long ldw, VtxBnBwdFusion* f2, void* dy2,
+                        float* dw_parts, long dw_parts_floats, int* dw_nparts, void* stream);
+int vtx_partials_reduce_acc(const float* ws, int nparts, int M, int N, float* C, long ldc, void* stream);
+
 /* ---- per-launch timing of the contraction kernels (bench.py roofline leg) ----------------
  * Between vtx_profile_start() and vtx_profile_stop() every contraction-kernel launch carries a start and a stop
  * HIP event (hipExtLaunchKernel: the dispatch's own begin / end timestamps, i.e. what rocprofv3 reports).  stop() synchronises the device and returns the number of kernel classes

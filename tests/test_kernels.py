@@ -1386,3 +1386,63 @@ def test_batchnorm_compaction_and_finalize_in_one_launch(backend, C, strips):
     s1, s2 = dz.float().sum(0), (dz.float() * xh).sum(0)
     dx_ref = gamma * rstd * (dz.float() - s1 / P - xh * s2 / P)
     assert rel_err(res[1][0], dx_ref) < 1e-2
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("M", [1024, 2432])
+def test_conv3_backward_in_one_streaming_kernel(backend, M):
+    """vtx_conv3_bwd_fused (csrc/conv3_bwd.hip): bn3's backward applied while the gradient is loaded, conv3's input gradient
+    with bn2's mask and sums, conv3's weight gradient -- against (1) the torch fp32 formulas and (2) the three launches it
+    replaces (bn_bwd_fused -> gemm_nt_bnbwd, gemm_tn_acc on relu(bn2(x2)) as bn_fwd stores it).  M = 19 row blocks: workgroups
+    with different round counts on the emulator's grid."""
+    import os
+    if os.environ.get("VIRTEX_AMD_CONV3_BWD", "1") == "0":
+        pytest.skip("switched off (VIRTEX_AMD_CONV3_BWD=0)")
+    dev = select(backend)
+    dt = torch.bfloat16
+    K, N = 256, 64
+    g = torch.Generator().manual_seed(M)
+    dz = (torch.randn(M, K, generator=g) * (torch.rand(M, K, generator=g) > 0.4)).to(dt)          # masked upstream gradient
+    x3 = (0.8 * torch.randn(M, K, generator=g) + 0.3 * torch.randn(K, generator=g)).to(dt)
+    x2 = (0.9 * torch.randn(M, N, generator=g) + 0.2).to(dt)
+    wt = (torch.randn(N, K, generator=g) / 16).to(dt)                                                # conv3's weight, (cin, cout)
+    gamma3 = 0.5 + torch.rand(K, generator=g); gamma2 = 0.5 + torch.rand(N, generator=g); beta2 = 0.3 * torch.randn(N, generator=g)
+    mean3 = x3.float().mean(0); rstd3 = (x3.float().var(0, unbiased=False) + 1e-5).rsqrt()
+    xh3 = (x3.float() - mean3) * rstd3
+    s1 = dz.float().sum(0); s2 = (dz.float() * xh3).sum(0)
+    parts3 = torch.stack([s1, s2]).view(1, 2, K).contiguous()
+    # bn2 forward through the library: y2 (= conv3's input), mean2, rstd2 exactly as the step has them
+    rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    y2, mean2, rstd2 = ops.bn_fwd(x2.to(dev).view(1, 1, M, N), gamma2.to(dev), beta2.to(dev), rm, rv, None, relu=True)
+    y2 = y2.view(M, N)
+    # ---- fused
+    assert ops.conv3_bwd_fused_supported(dz.to(dev), wt.to(dev))
+    dg_f, db_f = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+    bn2 = ops.BnBwd(x2.to(dev), mean2, rstd2, gamma=gamma2.to(dev), beta=beta2.to(dev))
+    dy2, st2, dwp, nparts = ops.conv3_bwd_fused(dz.to(dev), x3.to(dev), gamma3.to(dev), mean3.to(dev), rstd3.to(dev), dg_f, db_f,
+                                                ops.BnStats(parts3.to(dev), 1, None), wt.to(dev), bn2)
+    assert st2.strips == nparts and 0 < nparts <= M // 128
+    dw_f = torch.zeros(K, N, device=dev)
+    ops.partials_reduce_acc(dwp, nparts, dw_f)
+    # ---- the three launches it replaces
+    dg_r, db_r = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+    dx3 = ops.bn_bwd_fused(x3.to(dev), dz.to(dev), gamma3.to(dev), mean3.to(dev), rstd3.to(dev), dg_r, db_r, ops.BnStats(parts3.to(dev), 1, None))
+    bn2r = ops.BnBwd(x2.to(dev), mean2, rstd2, gamma=gamma2.to(dev), beta=beta2.to(dev))
+    dy2_r, st2_r = ops.gemm_nt_bnbwd(dx3, wt.to(dev), bn2r)
+    dw_r = torch.zeros(K, N, device=dev)
+    ops.gemm_tn_acc(dx3, y2, dw_r)
+    assert torch.equal(dg_f.cpu(), dg_r.cpu()) and torch.equal(db_f.cpu(), db_r.cpu())
+    assert rel_err(dy2.float().cpu(), dy2_r.float().cpu()) < 3e-3
+    sums = lambda st: st.parts[: st.strips * 2 * N].view(st.strips, 2, N).double().cpu().sum(0)     # noqa: E731
+    assert rel_err(sums(st2)[0], sums(st2_r)[0]) < 3e-3 and rel_err(sums(st2)[1], sums(st2_r)[1]) < 3e-3
+    assert rel_err(dw_f.cpu(), dw_r.cpu()) < 3e-3
+    # ---- torch fp32
+    dx3_t = gamma3 * rstd3 * (dz.float() - s1 / M - xh3 * s2 / M)
+    xh2 = (x2.float() - mean2.cpu()) * rstd2.cpu()
+    keep = xh2 * gamma2 + beta2 > 0
+    dy2_t = torch.where(keep, dx3_t @ wt.float().t(), torch.zeros(()))
+    assert rel_err(dy2.float().cpu(), dy2_t) < 1e-2
+    assert rel_err(sums(st2)[0], dy2_t.double().sum(0)) < 1e-2 and rel_err(sums(st2)[1], (dy2_t * xh2).double().sum(0)) < 1e-2
+    assert rel_err(dw_f.cpu(), dx3_t.t() @ torch.relu(xh2 * gamma2 + beta2)) < 1e-2
+    # the sums describe the STORED gradient
+    assert rel_err(sums(st2)[0], dy2.double().cpu().sum(0)) < 1e-5

@@ -736,3 +736,40 @@ def test_padding_to_a_fixed_caption_length_changes_nothing_on_the_kernels(backen
             assert rel_err(runs[1][1][n], g) < 2e-5, n
     worst = max(rel_err(runs[1][1][n], g) for n, g in runs[0][1].items() if "cnn" in n and g.norm() > 0)
     assert worst < 2e-2
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_fused_conv3_backward_leaves_the_step_unchanged(backend):
+    """VIRTEX_AMD_FUSE_CONV3_BWD: bn3's backward, conv3's input gradient (+ bn2's fused backward epilogue) and conv3's weight
+    gradient of the stage-1 Bottlenecks in ONE streaming kernel (csrc/conv3_bwd.hip) instead of three launches and a stored
+    gradient tensor: the same forward, and every gradient equal to accumulation order (the rounded values that travel between
+    the kernels -- dx3, the masked gradient -- are produced by the same formulas)."""
+    from virtex_amd import ops
+    from virtex_amd.modules import visual_backbones as vb
+    dev = select(backend)
+    _, model, batch = _build_pair("r50_l2_h128_b3_small", dev, torch.bfloat16)
+    start = {n: b.detach().clone() for n, b in model.named_buffers()}
+    saved = vb.FUSE_CONV3_BWD
+    runs = {}
+    try:
+        for flag in (False, True):
+            vb.FUSE_CONV3_BWD = flag
+            with torch.no_grad():
+                for n, b in model.named_buffers():
+                    b.copy_(start[n])
+            model.zero_grad(set_to_none=True)
+            ops.profile_start()
+            out = _run(model, batch, dev)
+            rec = ops.profile_stop()
+            fused_launches = sum(r["launches"] for r in rec if "conv3_bwd_fused" in r["name"])
+            assert fused_launches == (3 if flag else 0), fused_launches          # the three Bottlenecks of stage 1
+            runs[flag] = (out["loss"].item(), {n: p.grad.detach().float().cpu().clone() for n, p in model.named_parameters()})
+    finally:
+        vb.FUSE_CONV3_BWD = saved
+    assert runs[True][0] == runs[False][0]
+    rels = {n: rel_err(runs[True][1][n], g0) for n, g0 in runs[False][1].items() if g0.norm() > 0}
+    cnn = sorted(v for n, v in rels.items() if "cnn" in n)
+    assert cnn[len(cnn) // 2] < 5e-3 and cnn[-1] < 5e-2, (cnn[len(cnn) // 2], cnn[-1], max(rels, key=rels.get))
+    for n, v in rels.items():
+        if "cnn" not in n:
+            assert v < 1e-5 or "embedding" in n, (n, v)                           # nothing upstream of the backbone moves

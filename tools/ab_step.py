@@ -95,7 +95,7 @@ def main():
                 table[dev] = plain[kind]
     compute_streams = {}
     defaults = {(m, k): getattr(m, k) for _, kv, _, _ in variants for m, k, _ in kv if not (isinstance(m, str) and m.startswith("__"))}
-    sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512, "mc_eff128": 70, "bn_fin_wide": 0, "stats_tile": 4, "bn_adj": 1, "bn_grid": 8192, "tile64x256": 1, "tile_order": 0, "conv3x3_shared": 1, "gen3": 80, "gen3_mc": 800, "gen3_s2": 0, "bn_red_adj": 0, "epi_regs": 0, "gen3_pers": 0}
+    sw_defaults = {"wgrad3x3": int(os.environ.get("VIRTEX_AMD_WGRAD3X3", "1")), "stem_stream": 1, "expand1x1": 1, "splitk_blocks": 512, "mc_eff128": 70, "bn_fin_wide": 0, "stats_tile": 4, "bn_adj": 1, "bn_grid": 8192, "tile64x256": 1, "tile_order": 0, "conv3x3_shared": 1, "gen3": 80, "gen3_mc": 800, "gen3_s2": 0, "bn_red_adj": 0, "epi_regs": 0, "gen3_pers": 0, "conv3_bwd": 1}
     res = {n: [] for n, _, _, _ in variants}
     for r in range(a.rounds):
         for name, kv, sw, lib in variants:

@@ -822,6 +822,29 @@ extern "C" int vtx_bn_bwd_fused(int dtype, const void* x, const void* dz, const 
     return VTX_OK;
 }
 
+// The finalize half of vtx_bn_bwd_fused alone: [compaction +] bn_bwd_finalize of the epilogue partials -> coef[3][C] inside
+// `workspace` (valid until the next BatchNorm call on this stream), dgamma / dbeta accumulated.  For kernels that apply the
+// BatchNorm backward themselves while they load the gradient (conv3_bwd.hip).
+int vtx_bn_bwd_finalize_only(const float* gamma, const float* save_rstd, const float* pre_partials, int pre_nparts, float* dgamma,
+                             float* dbeta, float* workspace, int P, int C, hipStream_t st, const float** coef_out) {
+    VTX_CHECK(gamma && save_rstd && pre_partials && dgamma && dbeta && workspace && coef_out, VTX_ERR_ARG, "bn_bwd_finalize: null pointer");
+    VTX_CHECK(P > 0 && pre_nparts > 0 && bn_shape_ok(C, 8), VTX_ERR_SHAPE, "bn_bwd_finalize: C=%d must be 8*2^k, P=%d > 0", C, P);
+    workspace += VTX_BN_WS_HEADER;
+    float* coef = workspace + C; float* sums = workspace + 4 * C;
+    const float* parts = pre_partials;
+    int np = pre_nparts;
+    if (np > 512) {
+        const int per = vtx_cdiv(np, 64), ny = vtx_cdiv(np, per);
+        VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_compact_parts_kernel, dim3(vtx_cdiv(C, 32), ny), dim3(g_vtx_sw_bn_fin_wide ? 1024 : 256), 0, st, parts, sums, C, np, per);
+        parts = sums; np = ny;
+    }
+    VTX_KLAUNCH("bn_finalize", 0, 8.0 * np * C, bn_bwd_finalize_kernel, dim3(vtx_cdiv(C, FIN_CH)), fin_block(np), 0, st, parts, gamma, save_rstd, coef,
+                dgamma, dbeta, P, C, np);
+    VTX_LAUNCH_CHECK();
+    *coef_out = coef;
+    return VTX_OK;
+}
+
 // The stem's backward tail in two passes instead of three kernels and an intermediate tensor:
 //   dx = BatchNormBackward(ReLUBackward(MaxPoolBackward(dpool)))   with x = the stem convolution's output [N][H][W][C].
 // Replaces aten::max_pool2d_with_indices_backward + threshold_backward + native_batch_norm_backward of the stem

@@ -56,6 +56,7 @@ extern "C" int vtx_set_ablation(int bits) { vtxg::g_vtx_ablate = bits; return VT
 int g_vtx_sw_wgrad3x3 = getenv("VIRTEX_AMD_WGRAD3X3") ? atoi(getenv("VIRTEX_AMD_WGRAD3X3")) : 1;         // conv3x3_wgrad.hip: 0 off, 1 by image size, 2 always
 int g_vtx_sw_stem_stream = getenv("VIRTEX_AMD_STEM_STREAM") ? atoi(getenv("VIRTEX_AMD_STEM_STREAM")) : 1;  // stem.hip
 int g_vtx_sw_expand1x1 = getenv("VIRTEX_AMD_EXPAND1X1") ? atoi(getenv("VIRTEX_AMD_EXPAND1X1")) : 1;        // expand1x1.hip
+int g_vtx_sw_conv3_bwd = getenv("VIRTEX_AMD_CONV3_BWD") ? atoi(getenv("VIRTEX_AMD_CONV3_BWD")) : 1;        // conv3_bwd.hip: fused bn3-backward + conv3 input / weight gradient of the stage-1 Bottlenecks
 int g_vtx_sw_splitk_blocks = getenv("VIRTEX_AMD_SPLITK_BLOCKS") ? atoi(getenv("VIRTEX_AMD_SPLITK_BLOCKS")) : 512;   // split-K block target of the weight gradients
 int g_vtx_sw_bn_fin2 = getenv("VIRTEX_AMD_BN_FIN2") ? atoi(getenv("VIRTEX_AMD_BN_FIN2")) : 0;   // BatchNorm strips > 512: compaction + finalize in one launch (bn_fin2_kernel).  Measured: with a release fence per block 24.66 vs 24.40 ms/step (profiles/r04_ab_bn_fin2.txt), with write-through stores 24.34 vs 24.31 (r04_ab_bn_fin2_write_through.txt): a dependent 5-us launch costs what it runs, the boundary itself ~2 us -> off (two launches keep the summation order the tests were calibrated on)
 int g_vtx_sw_bn_fin_wide = getenv("VIRTEX_AMD_BN_FIN_WIDE") ? atoi(getenv("VIRTEX_AMD_BN_FIN_WIDE")) : 0;   // 1024-thread BatchNorm finalize / compaction blocks
@@ -77,6 +78,7 @@ extern "C" int vtx_set_switch(const char* name, int value) {
     if (!strcmp(name, "wgrad3x3")) g_vtx_sw_wgrad3x3 = value;
     else if (!strcmp(name, "stem_stream")) g_vtx_sw_stem_stream = value;
     else if (!strcmp(name, "expand1x1")) g_vtx_sw_expand1x1 = value;
+    else if (!strcmp(name, "conv3_bwd")) g_vtx_sw_conv3_bwd = value;
     else if (!strcmp(name, "bn_fin_wide")) g_vtx_sw_bn_fin_wide = value;
     else if (!strcmp(name, "bn_fin2")) g_vtx_sw_bn_fin2 = value;
     else if (!strcmp(name, "stats_tile")) vtxg::g_vtx_sw_stats_tile = value;

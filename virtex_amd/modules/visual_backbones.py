@@ -55,6 +55,10 @@ FUSE_STEM_FWD = os.environ.get("VIRTEX_AMD_FUSE_STEM_FWD", "1") != "0"
 # instead of the whole output tensor (2.8 GB of reads per step at bs 256; the output itself stays: it is the next
 # block's input).
 RELU_BITS = os.environ.get("VIRTEX_AMD_RELU_BITS", "1") != "0"
+# The backward of conv3 of the stage-1 Bottlenecks as one streaming kernel (csrc/conv3_bwd.hip): bn3's backward applied while
+# the gradient is loaded, conv3's input gradient with bn2's fused backward epilogue, conv3's weight gradient as per-workgroup
+# partials -- the 411-MB gradient wrt conv3's output (written by one pass, re-read by two kernels) never exists.
+FUSE_CONV3_BWD = os.environ.get("VIRTEX_AMD_FUSE_CONV3_BWD", "1") != "0"
 # the stem convolution's epilogue emits the BatchNorm statistics (streaming kernel, stem.hip)
 STEM_STATS = os.environ.get("VIRTEX_AMD_STEM_STATS", "1") != "0"
 
@@ -493,12 +497,32 @@ class _ResNetFn(torch.autograd.Function):
             """The fusion descriptor of an interior BatchNorm+ReLU: mask recomputed from its input."""
             return ops.BnBwd(s.x, s.mean, s.rstd, gamma=u.bn.weight.detach(), beta=u.bn.bias.detach()) if fuse else None
 
+        def conv3_back_fused(u3: _Unit, u2: _Unit, s3: _Saved, s2: _Saved, dz, st):
+            """bn3 backward + conv3 input gradient (+ bn2 mask / sums) + conv3 weight gradient in ONE launch; the partial
+            weight gradients are folded into the parameter's gradient on the weight-gradient stream."""
+            sg, sb = gradsink.target(u3.bn.weight), gradsink.target(u3.bn.bias)
+            dg = sg if sg is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
+            db = sb if sb is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
+            dy2, st2, parts, nparts = ops.conv3_bwd_fused(dz, s3.x, u3.bn.weight.detach(), s3.mean, s3.rstd, dg, db, st,
+                                                          s3.wt.view(u3.cin, u3.cout), relu_bn(u2, s2))
+            sink = gradsink.target(u3.conv.weight, (u3.cout, 1, 1, u3.cin))
+            dw = sink if sink is not None else torch.zeros(u3.cout, 1, 1, u3.cin, dtype=torch.float32, device=dev)
+            with wgrad_stream(dev, parts):
+                ops.partials_reduce_acc(parts, nparts, dw.view(u3.cout, u3.cin))
+            grads[u3] = [None if sink is not None else dw.permute(0, 3, 1, 2), None if sg is not None else dg,
+                         None if sb is not None else db]
+            return dy2, st2
+
         fuse = FUSE_BN_BWD and dt == torch.bfloat16
         st3 = None                  # sums for this block's bn3, when the next block's conv1 input gradient emitted them
         for bi in reversed(range(len(blocks))):
             (u1, u2, u3, ud) = blocks[bi]
             s1, s2, s3 = rec[u1], rec[u2], rec[u3]
-            if st3 is not None:     # dcur IS dz: masked by (block output > 0) in the producing epilogue
+            fused3 = (fuse and FUSE_CONV3_BWD and st3 is not None and u3.is_gemm and u3.cin_pad == u3.cin
+                      and s3.wt is not None and ops.conv3_bwd_fused_supported(dcur, s3.wt.view(u3.cin, u3.cout)))
+            if fused3:              # one kernel below does bn3's backward, conv3's input gradient and its weight gradient
+                dz, dx3 = dcur, None
+            elif st3 is not None:   # dcur IS dz: masked by (block output > 0) in the producing epilogue
                 dz = dcur
                 dx3 = bn_back_fused(u3, s3, dz, st3)
             else:
@@ -514,12 +538,15 @@ class _ResNetFn(torch.autograd.Function):
                     with wgrad_stream(dev, sd.a, dxd):
                         grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
                     dskip = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape)
-            with wgrad_stream(dev, s3.a, dx3):
-                grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
-            if fuse:
-                dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape, bn=relu_bn(u2, s2))
+            if fused3:
+                dy2, st2 = conv3_back_fused(u3, u2, s3, s2, dz, st3)
             else:
-                dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape), None
+                with wgrad_stream(dev, s3.a, dx3):
+                    grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
+                if fuse:
+                    dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape, bn=relu_bn(u2, s2))
+                else:
+                    dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape), None
             dx2 = bn_back_fused(u2, s2, dy2, st2) if st2 is not None else bn_back(u2, s2, dy2, True)
             with wgrad_stream(dev, s2.a, dx2):
                 grads[u2][0] = _conv_wgrad(u2, s2.a, dx2)

@@ -149,11 +149,10 @@ class BnBwd:
     def descriptor(self, rows, N, device):
         cap = ((rows + 63) // 64 + 4) * 2 * N
         parts = torch.empty(cap, dtype=torch.float32, device=device)
-        d = _BnBwdFusion(self.x.data_ptr(), self.ymask.data_ptr() if self.ymask is not None else None,
-                         self.mean.data_ptr(), self.rstd.data_ptr(),
-                         self.gamma.data_ptr() if self.gamma is not None else None,
-                         self.beta.data_ptr() if self.beta is not None else None, parts.data_ptr(), cap, 0,
-                         self.ybits.data_ptr() if self.ybits is not None else None)
+        # addresses through ptr(): a launch recording (virtex_amd.replay) keeps every tensor a recorded argument points into
+        a = lambda t: ptr(t).value      # noqa: E731  (None -> NULL)
+        d = _BnBwdFusion(a(self.x), a(self.ymask), a(self.mean), a(self.rstd), a(self.gamma), a(self.beta), a(parts), cap, 0,
+                         a(self.ybits))
         return d, parts
 
 
@@ -326,6 +325,47 @@ def bn_bwd_fused(x, dz, gamma, mean, rstd, dgamma, dbeta, stats: "BnStats"):
     call("vtx_bn_bwd_fused", c_int(dtype_code(x.dtype)), ptr(x), ptr(dz), ptr(gamma), ptr(mean), ptr(rstd),
          ptr(stats.parts), c_int(stats.strips), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), c_int(P), c_int(C), stream_ptr(x))
     return dx
+
+
+def conv3_bwd_fused_supported(dz, wt):
+    """May vtx_conv3_bwd_fused take this Bottleneck?  dz: (..., K) gradient wrt bn3's output, wt: (N, K)."""
+    if dz.dtype != torch.bfloat16:
+        return False
+    K = dz.shape[-1]
+    return bool(_lib.lib().vtx_conv3_bwd_fused_supported(c_int(dtype_code(dz.dtype)), c_int(dz.numel() // K), c_int(K), c_int(wt.shape[0])))
+
+
+def conv3_bwd_fused(dz, x3, gamma3, mean3, rstd3, dgamma3, dbeta3, stats3: "BnStats", wt, bn2: "BnBwd"):
+    """The backward of a Bottleneck's conv3 in one streaming kernel (csrc/conv3_bwd.hip): bn3's backward applied to `dz` on
+    the fly (its sums are `stats3`; dgamma3 / dbeta3 accumulated), conv3's input gradient with bn2's mask and backward sums,
+    and conv3's weight gradient as per-workgroup partials.  Returns (dy2, stats2, dw_parts, nparts): fold the partials into
+    the fp32 weight gradient (K, N) with partials_reduce_acc -- normally on the weight-gradient stream."""
+    K, N = dz.shape[-1], wt.shape[0]
+    M = dz.numel() // K
+    _chk(dz, "dz", torch.bfloat16); _chk(x3, "x3", torch.bfloat16); _chk(wt, "wt", torch.bfloat16)
+    assert x3.numel() == dz.numel() and wt.shape == (N, K) and bn2.x.numel() == M * N and bn2.x.is_contiguous()
+    assert bn2.gamma is not None and bn2.beta is not None and bn2.ymask is None and bn2.ybits is None
+    lib = _lib.lib()
+    nparts = lib.vtx_conv3_bwd_fused_parts(c_int(M))
+    dw_parts = torch.empty(nparts, K, N, dtype=torch.float32, device=dz.device)
+    dy2 = torch.empty(*dz.shape[:-1], N, dtype=dz.dtype, device=dz.device)
+    d, parts = bn2.descriptor(M, N, dz.device)
+    ws = bn_workspace(dz.device, K)
+    got = c_int(0)
+    call("vtx_conv3_bwd_fused", c_int(dtype_code(dz.dtype)), c_int(M), c_int(K), c_int(N), ptr(dz), ptr(x3), ptr(gamma3),
+         ptr(mean3), ptr(rstd3), ptr(stats3.parts), c_int(stats3.strips), ptr(dgamma3), ptr(dbeta3), ptr(ws), ptr(wt),
+         c_long(wt.stride(0)), _lib.ctypes.byref(d), ptr(dy2), ptr(dw_parts), c_long(dw_parts.numel()),
+         _lib.ctypes.byref(got), stream_ptr(dz))
+    return dy2, BnStats(parts, d.strips, None), dw_parts, nparts
+
+
+def partials_reduce_acc(parts, nparts, out):
+    """out (M, N) fp32 += sum of parts[:nparts] (each (M, N) fp32)."""
+    M, N = out.shape
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and parts.dtype == torch.float32 and parts.is_contiguous()
+    assert parts.numel() >= nparts * M * N
+    call("vtx_partials_reduce_acc", ptr(parts), c_int(nparts), c_int(M), c_int(N), ptr(out), c_long(out.stride(0)), stream_ptr(out))
+    return out
 
 
 def bn_fwd_maxpool(x, gamma, beta, running_mean, running_var, nbt, eps=1e-5, momentum=0.1, stats=None):
