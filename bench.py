@@ -231,6 +231,19 @@ def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1, f
                              "TFLOP/s": round(r["flops"] / r["seconds"] / 1e12, 1), "mfma_frac": round(r["flops"] / r["seconds"] / 1e12 / peak_tf, 4),
                              "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1), "hbm_frac": round(r["bytes"] / r["seconds"] / 1e12 / PEAK_HBM_TBS, 4)}
     out["mfma_kernels"] = dict(sorted(mk.items(), key=lambda kv: -kv[1]["ms_per_step"]))
+    # The largest SINGLE contraction instantiation by summed time, whatever the family-merged headline above points at: a
+    # round cannot "improve" the headline fraction by shrinking a worse kernel below a better one.
+    # Times are the survey step's (every launch timed, side streams off); traffic from the PMC table when it has this class.
+    if mk:
+        dk, dv = max(mk.items(), key=lambda kv: kv[1]["ms_per_step"])
+        dtraffic = table.get(dk) if table else None
+        out["dominant_contraction"] = {
+            "kernel": dk, "launches_per_step": dv["launches_per_step"], "ms_per_step": dv["ms_per_step"],
+            "avg_launch_us": round(dv["ms_per_step"] / max(dv["launches_per_step"], 1) * 1e3, 1),
+            "TFLOP/s": dv["TFLOP/s"], "GB/s": dv["GB/s"], "mfma_frac": dv["mfma_frac"], "hbm_frac": dv["hbm_frac"],
+            "bound": "mfma" if dv["mfma_frac"] >= dv["hbm_frac"] else "hbm", "frac": max(dv["mfma_frac"], dv["hbm_frac"]),
+            "algorithmic_bytes": round(by_name[dk]["bytes"] / by_name[dk]["launches"], 1),
+            "traffic": dtraffic, "traffic_ratio": (round(dtraffic / (by_name[dk]["bytes"] / by_name[dk]["launches"]), 3) if dtraffic else None)}
     out["families"] = {k: {"ms_per_step": round(v["ms_per_step"], 3), "GB/s": round(v["bytes"] / v["seconds"] / 1e9, 1) if v["seconds"] else 0.0,
                            "TFLOP/s": round(v["flops"] / v["seconds"] / 1e12, 1) if v["seconds"] else 0.0}
                        for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms_per_step"])}
@@ -361,7 +374,7 @@ def main(argv=None, device=None, backend=None):
     device_sync()
     # Launch replay / hipGraph (single process: the all-reduces of N > 1 stay eager).  The issued step is the SAME function;
     # dropout epoch, LR multiplier and Lookahead phase advance on the device (virtex_amd/replay.py, graph.py).
-    gstep, launch_mode = None, "eager"
+    gstep, launch_mode, launch_fallback = None, "eager", None
     want = a.launch
     if want == "auto":
         want = "replay" if (world == 1 and dev.type == "cuda" and not a.roofline_live) else "eager"
@@ -382,6 +395,7 @@ def main(argv=None, device=None, backend=None):
             if a.launch != "auto":
                 raise
             print(f"bench.py: launch {want} failed ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr)
+            launch_fallback = f"{want} failed: {type(e).__name__}: {e}"[:400]
             gstep = None
             opt.disable_device_schedule()
             device_sync()
@@ -401,8 +415,20 @@ def main(argv=None, device=None, backend=None):
     vd.synchronize()
     device_sync()
     elapsed = time.perf_counter() - t0
+    eager_ms = None
     if gstep is not None:
         gstep.sync()
+        # the same step issued by its Python (what N > 1 and any training loop without a fixed batch shape run): timed beside
+        # the replayed one, same process, same state -- `value` stays the replayed step, config.eager_ms_per_step says what
+        # the difference is
+        n_eager = min(a.steps, 20)
+        step(0)
+        device_sync()
+        t1 = time.perf_counter()
+        for i in range(n_eager):
+            step(i)
+        device_sync()
+        eager_ms = (time.perf_counter() - t1) / n_eager * 1e3
     live_recs = None
     if live:
         live_recs = ops.profile_stop()
@@ -490,6 +516,8 @@ def main(argv=None, device=None, backend=None):
                                    "30-tok captions, full step (fwd+bwd+clip+SGD+Lookahead), dropout "
                                    f"{a.dropout}", "global_batch": a.batch * world,
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "launch": launch_mode,
+                       "eager_ms_per_step": (round(eager_ms, 3) if eager_ms is not None else (round(elapsed / a.steps * 1e3, 3) if launch_mode == "eager" else None)),
+                       "launch_fallback_reason": launch_fallback,
                        "host_enqueue_ms_per_step": round(host_issue / a.steps * 1e3, 3),
                        "host_enqueue_note": "wall time of the issuing loop / steps; a host faster than the GPU spends the difference "
                                             "blocked on the full HIP queue, so a value near ms_per_step means 'host not the limit' "

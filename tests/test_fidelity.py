@@ -114,6 +114,9 @@ def test_bf16_step_against_fp32_step_b32_calibrated_on_autocast(state):
     assert pin["backbone"]["median_rel"] < 2e-2 and pin["text"]["max_rel"] < 1e-3
     ob, cb = ours["backbone"], cal["backbone"]
     assert ob["tensors"] == cb["tensors"]
+    # the calibration must itself be a signal before it may serve as a bound (at B = 2 it is noise: min cosine -0.17); the
+    # randomised BatchNorm state is the harder one (autocast 0.87) and keeps a floor of its own
+    assert cb["min_cos"] >= (0.95 if state == "reference_init" else 0.80), cb
     assert ob["median_rel"] <= 1.25 * cb["median_rel"], (ob, cb)
     assert ob["max_rel"] <= 1.5 * cb["max_rel"], (ob, cb)
     assert ob["min_cos"] >= cb["min_cos"] - 0.03, (ob, cb)

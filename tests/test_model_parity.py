@@ -242,41 +242,25 @@ def test_model_fp32_gpu(case):
 
 @pytest.mark.gpu
 def test_model_bf16_gpu():
-    """bf16 compute mode (the throughput mode) is NOT a parity claim; it is bounded against the fp32 oracle where bf16
-    storage permits -- loss to 2e-3, every text-side gradient with cosine >= 0.99 -- and, for the backbone gradients
-    (round 4; rounds 1-3 only required them to be finite), CALIBRATED on PyTorch's own bf16 AMP of the reference on the
-    same state and batch: the distance of our bf16 step from the fp32 oracle must be no worse than the distance of
-    torch.autocast(bfloat16) of the oracle from it (median over the tensors within 1.25x, worst tensor within 1.5x,
-    minimum cosine within 0.03) -- a 16-bit forward flips ReLU masks whoever computes it."""
-    import copy
-    from virtex_amd import fidelity
+    """bf16 compute mode (the throughput mode) is NOT a parity claim; on this B = 2 golden case it is bounded against the fp32
+    oracle where bf16 storage permits: loss to 2e-3, every gradient finite, every text-side gradient with cosine >= 0.99.
+    The BACKBONE gradients are deliberately not bounded here: at B = 2 `torch.autocast(bfloat16)` of the reference is itself
+    at median rel 1.32 / min cosine -0.17 from its fp32 run (profiles/r04_parity_bf16_b2_backbone_vs_autocast.json) -- a
+    calibration against it passes for uncorrelated gradients.  The backbone claim of the bf16 mode
+    lives where the calibration means something: tests/test_fidelity.py (B = 32: autocast min cosine 0.979, asserted >= 0.95
+    there before it is used as a bound; B = 256: median <= 0.25, min cosine >= 0.95)."""
     dev = select("gpu")
     oracle_model, model, batch = _build_pair("r50_l1_h1024_b2_full", dev, torch.bfloat16)
     oracle_model.train()
-    amp_model = copy.deepcopy(oracle_model)
     oo = oracle_model(batch)
     oo["loss"].backward()
-    with torch.autocast("cpu", dtype=torch.bfloat16):
-        ao = amp_model(batch)
-    ao["loss"].backward()
     out = _run(model, batch, dev)
     assert abs(out["loss"].item() - oo["loss"].item()) < 2e-3 * abs(oo["loss"].item())
-    g32 = {n: q.grad for n, q in oracle_model.named_parameters()}
-    gamp = {n: q.grad.float() for n, q in amp_model.named_parameters()}
-    gours = {}
     for (n, p), (_, q) in zip(model.named_parameters(), oracle_model.named_parameters()):
         assert torch.isfinite(p.grad).all(), n
-        gours[n] = p.grad.cpu().float()
         if "cnn" not in n:
             a, b = p.grad.cpu().double().flatten(), q.grad.double().flatten()
             assert (a @ b / (a.norm() * b.norm())).item() > 0.99, n
-    cal = fidelity.summarize(fidelity.gradient_distance(gamp, g32))["backbone"]
-    ours = fidelity.summarize(fidelity.gradient_distance(gours, g32))["backbone"]
-    _dump_rows("parity_bf16_b2_backbone_vs_autocast.json", {"autocast_bf16_vs_fp32_oracle": cal, "hip_bf16_vs_fp32_oracle": ours}, [])
-    assert ours["tensors"] == cal["tensors"]
-    assert ours["median_rel"] <= 1.25 * cal["median_rel"], (ours, cal)
-    assert ours["max_rel"] <= 1.5 * cal["max_rel"], (ours, cal)
-    assert ours["min_cos"] >= cal["min_cos"] - 0.03, (ours, cal)
 
 
 def test_state_dict_layout():
