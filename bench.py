@@ -372,13 +372,15 @@ def main(argv=None, device=None, backend=None):
     for i in range(a.warmup):
         loss = step(i)
     device_sync()
-    # Launch replay / hipGraph (single process: the all-reduces of N > 1 stay eager).  The issued step is the SAME function;
+    # Launch replay (any N: the recorded list carries the bucket all-reduces) / hipGraph (single process).  The issued step is the SAME function;
     # dropout epoch, LR multiplier and Lookahead phase advance on the device (virtex_amd/replay.py, graph.py).
     gstep, launch_mode, launch_fallback = None, "eager", None
     want = a.launch
     if want == "auto":
-        want = "replay" if (world == 1 and dev.type == "cuda" and not a.roofline_live) else "eager"
-    if want in ("replay", "graph") and world == 1 and not a.roofline_live:
+        want = "replay" if (dev.type == "cuda" and not a.roofline_live) else "eager"
+    if want == "graph" and world > 1:
+        want = "eager"               # the hipGraph of the step is single-process; launch replay carries the all-reduces (round 5)
+    if want in ("replay", "graph") and not a.roofline_live:
         del loss
         try:
             if want == "graph":

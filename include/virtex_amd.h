@@ -144,6 +144,23 @@ int vtx_conv3_bwd_fused(int dtype, int M, int K, int N, const void* dz, const vo
                         float* dw_parts, long dw_parts_floats, int* dw_nparts, void* stream);
 int vtx_partials_reduce_acc(const float* ws, int nparts, int M, int N, float* C, long ldc, void* stream);
 
+/* ---- JPEG decode (csrc/jpeg.hip) ------------------------------------
+ * Replaces cv2.imread + cv2.cvtColor(BGR2RGB) of the reference's dataset item (virtex/data/datasets/coco_captions.py:59-60):
+ * libjpeg(-turbo)'s baseline decoder with default settings, bit for bit (JDCT_ISLOW, fancy upsampling, its YCbCr -> RGB
+ * tables; EXIF orientation applied as cv2.imread does).  Three steps, so that the serial part stays on the host and the
+ * per-block / per-pixel part runs on the device:
+ *   vtx_jpeg_info            header: info[8] = {width, height, components, luma h, luma v sampling, EXIF orientation,
+ *                            coefficient blocks, plane bytes}
+ *   vtx_jpeg_entropy_decode  Huffman decoding into coef[blocks][64] int16 (natural order; host memory) + qt[4][64] uint16
+ *   vtx_jpeg_reconstruct     device: dequantise + inverse DCT + upsampling + colour conversion -> rgb[outH][outW][3] uint8
+ *                            (planes: info[7] bytes of device scratch; apply_orientation: rotate / mirror by the EXIF tag,
+ *                            (outW, outH) = (height, width) for orientations 5-8)
+ * VTX_ERR_SHAPE: a stream this decoder does not take (progressive, arithmetic, 12-bit, CMYK, exotic sampling). */
+int vtx_jpeg_info(const void* data, long nbytes, int* info);
+int vtx_jpeg_entropy_decode(const void* data, long nbytes, short* coef, long coef_elems, unsigned short* qt);
+int vtx_jpeg_reconstruct(const void* data, long nbytes, const short* coef_dev, const unsigned short* qt_dev,
+                         unsigned char* planes_dev, unsigned char* rgb_dev, int apply_orientation, void* stream);
+
 /* ---- per-launch timing of the contraction kernels (bench.py roofline leg) ----------------
  * Between vtx_profile_start() and vtx_profile_stop() every contraction-kernel launch carries a start and a stop
  * HIP event (hipExtLaunchKernel: the dispatch's own begin / end timestamps, i.e. what rocprofv3 reports).  stop() synchronises the device and returns the number of kernel classes

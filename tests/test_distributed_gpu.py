@@ -79,8 +79,9 @@ def test_two_ranks_one_gpu_full_step():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("launch", ["eager", "replay"])
 @pytest.mark.parametrize("payload", ["fp32", "bf16"])
-def test_bench_through_rccl_with_one_rank(payload):
+def test_bench_through_rccl_with_one_rank(payload, launch):
     """The whole N > 1 path of bench.py on the ONE GPU of the test box, through RCCL: `init_process_group("nccl")`
     (communicator creation), `broadcast_parameters`, the bucketed all-reduces on the communication stream fenced by
     events against the compute / weight-gradient / branch streams, the barrier with `device_ids`, the roofline and
@@ -90,7 +91,7 @@ def test_bench_through_rccl_with_one_rank(payload):
     import json
     args = ["--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "8", "--image-size", "64", "--vocab-size", "1000",
             "--textual", "transdec_postnorm::L1_H128_A2_F256", "--no-cpu-baseline", "--roofline-steps", "1", "--dropout", "0.0",
-            "--launch", "eager"]        # (launch replay is single-process: both runs issue the eager step, the same number of times)
+            "--launch", launch]         # replay (round 5): the recorded launch list carries the RCCL all-reduces and their waits
     def run(extra_env):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
@@ -102,6 +103,7 @@ def test_bench_through_rccl_with_one_rank(payload):
                 "MASTER_PORT": str(_free_port()), "VIRTEX_AMD_DP_PAYLOAD": payload}
     rccl = run(dist_env)
     assert rccl["n_gpus"] == 1 and rccl["value"] > 0 and "error" not in rccl.get("fidelity", {})
+    assert rccl["config"]["launch"] == launch and plain["config"]["launch"] == launch, (rccl["config"], plain["config"])
     if payload == "fp32":       # (the embedding's fp32 atomics make runs differ at 1e-7, nothing more)
         assert abs(rccl["config"]["final_loss"] - plain["config"]["final_loss"]) <= 2e-4
     else:

@@ -1,0 +1,161 @@
+"""JPEG decode (csrc/jpeg.hip, virtex_amd/jpeg.py) and the COCO Captions reader: SURVEY.md 8f row f2.
+
+Pinning chain: Pillow's libjpeg-turbo (the same library family cv2.imread of the reference uses, default settings) ==
+oracle/jpeg.py (bit for bit, test_oracle_*) == the HIP kernels through the C ABI (bit for bit, emulator and GPU).  The committed
+fixture tests/golden/jpeg_cases.npz (made by tests/golden/make_jpeg_goldens.py from Pillow) keeps the first link checkable
+where Pillow is absent."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from backends import BACKENDS, select
+from oracle import jpeg as oj
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jpeg_cases.npz")
+
+
+def _image(h, w, rng, smooth=True):
+    if smooth:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([127 + 100 * np.sin(xx / 7.0 + c) * np.cos(yy / 5.0 - c) for c in range(3)], -1) + rng.normal(0, 12, (h, w, 3))
+    else:
+        img = rng.integers(0, 256, (h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _encode(arr, **kw):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(arr).save(buf, "JPEG", **kw)
+    return buf.getvalue()
+
+
+def _pil_decode(data, orient=True):
+    from PIL import Image, ImageOps
+    im = Image.open(io.BytesIO(data))
+    if orient:
+        im = ImageOps.exif_transpose(im)
+    return np.asarray(im.convert("RGB"))
+
+
+def _with_orientation(data, orientation):
+    """insert an EXIF APP1 segment carrying only the orientation tag behind SOI"""
+    tiff = b"MM\x00\x2a\x00\x00\x00\x08" + b"\x00\x01" + b"\x01\x12\x00\x03\x00\x00\x00\x01" + bytes([0, orientation, 0, 0]) + b"\x00\x00\x00\x00"
+    payload = b"Exif\x00\x00" + tiff
+    return data[:2] + b"\xff\xe1" + (len(payload) + 2).to_bytes(2, "big") + payload + data[2:]
+
+
+CASES = [(16, 16, 0, 75), (37, 53, 2, 75), (64, 48, 1, 90), (5, 3, 2, 50), (1, 1, 2, 75), (8, 9, 1, 30), (100, 131, 2, 95),
+         (17, 4, 2, 75), (3, 5, 1, 75), (56, 72, 0, 20)]
+
+
+def test_oracle_is_bitwise_equal_to_pillows_libjpeg():
+    PIL = pytest.importorskip("PIL")  # noqa: F841
+    rng = np.random.default_rng(0)
+    for (h, w, sub, q) in CASES:
+        for smooth in (True, False):
+            data = _encode(_image(h, w, rng, smooth), quality=q, subsampling=sub)
+            assert np.array_equal(oj.decode(data), _pil_decode(data)), (h, w, sub, q, smooth)
+    grey = _encode(_image(33, 47, rng)[..., 0], quality=80)
+    assert np.array_equal(oj.decode(grey), _pil_decode(grey))
+    rst = _encode(_image(64, 80, rng), quality=80, optimize=True, restart_marker_blocks=2)
+    assert oj.parse(rst)["restart"] == 2 and np.array_equal(oj.decode(rst), _pil_decode(rst))
+    base = _encode(_image(24, 40, rng), quality=85, subsampling=2)
+    for o in range(1, 9):                                  # EXIF orientation as cv2.imread / ImageOps.exif_transpose apply it
+        data = _with_orientation(base, o)
+        assert np.array_equal(oj.decode(data), _pil_decode(data)), o
+
+
+def test_oracle_reproduces_the_committed_fixture():
+    z = np.load(GOLDEN)
+    n = int(z["count"])
+    assert n >= 8
+    for i in range(n):
+        assert np.array_equal(oj.decode(z[f"jpeg_{i}"].tobytes()), z[f"rgb_{i}"]), i
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_device_decoder_is_bitwise_equal_to_the_oracle(backend):
+    from virtex_amd import jpeg as vj
+    dev = select(backend)
+    z = np.load(GOLDEN)
+    for i in range(int(z["count"])):
+        data = z[f"jpeg_{i}"].tobytes()
+        got = vj.decode_jpeg(data, dev).cpu().numpy()
+        assert got.shape == z[f"rgb_{i}"].shape and np.array_equal(got, z[f"rgb_{i}"]), i
+        info = vj.jpeg_info(data)
+        assert (info["width"], info["height"]) in ((got.shape[1], got.shape[0]), (got.shape[0], got.shape[1]))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_device_decoder_against_pillow_on_fresh_images(backend):
+    pytest.importorskip("PIL")
+    from virtex_amd import jpeg as vj
+    dev = select(backend)
+    rng = np.random.default_rng(5)
+    sizes = [(224, 224), (333, 500), (61, 47)] if backend == "gpu" else [(40, 56), (23, 31)]
+    for (h, w) in sizes:
+        for sub in (0, 1, 2):
+            data = _encode(_image(h, w, rng), quality=int(rng.integers(40, 96)), subsampling=sub,
+                           restart_marker_blocks=int(rng.integers(0, 3)))
+            assert np.array_equal(vj.decode_jpeg(data, dev).cpu().numpy(), _pil_decode(data)), (h, w, sub)
+    data = _with_orientation(_encode(_image(24, 40, rng), quality=85), 6)
+    assert np.array_equal(vj.decode_jpeg(data, dev).cpu().numpy(), _pil_decode(data))
+    assert vj.decode_jpeg(data, dev, apply_orientation=False).shape == (24, 40, 3)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_streams_the_decoder_does_not_take_are_refused(backend):
+    pytest.importorskip("PIL")
+    from virtex_amd import _lib, jpeg as vj
+    dev = select(backend)
+    rng = np.random.default_rng(1)
+    prog = _encode(_image(32, 32, rng), quality=80, progressive=True)
+    with pytest.raises(_lib.VtxError):
+        vj.decode_jpeg(prog, dev)
+    with pytest.raises(_lib.VtxError):
+        vj.decode_jpeg(b"not a jpeg at all", dev)
+    good = _encode(_image(32, 32, rng), quality=80)
+    with pytest.raises(_lib.VtxError):
+        vj.decode_jpeg(good[: len(good) // 3], dev)          # truncated in the headers / tables
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_coco_captions_reader_matches_the_reference_dataset(backend, tmp_path):
+    """Annotation bookkeeping, caption normalisation and instance order of the reference's CocoCaptionsDataset
+    (coco_captions.py:22-52), pixels from the device decoder."""
+    pytest.importorskip("PIL")
+    from virtex_amd import jpeg as vj
+    dev = select(backend)
+    rng = np.random.default_rng(2)
+    root = tmp_path
+    (root / "val2017").mkdir(); (root / "annotations").mkdir()
+    images, anns, pixels = [], [], {}
+    for k, (h, w) in enumerate([(32, 48), (40, 24), (17, 33)]):
+        name = f"{k:012d}.jpg"
+        data = _encode(_image(h, w, rng), quality=85)
+        (root / "val2017" / name).write_bytes(data)
+        pixels[100 + k] = _pil_decode(data)
+        images.append({"id": 100 + k, "file_name": name})
+    caps = [(101, "A Café on the LEFT side."), (100, "Two dogs  run"), (101, "Ünïcode açcents"), (102, "plain")]
+    for j, (iid, c) in enumerate(caps):
+        anns.append({"image_id": iid, "id": j, "caption": c})
+    (root / "annotations" / "captions_val2017.json").write_text(json.dumps({"images": images, "annotations": anns}))
+    ds = vj.CocoCaptionsReader(str(root), "val", device=dev)
+    assert len(ds) == 3 and [i[0] for i in ds.instances] == [101, 100, 102]           # order of first appearance
+    item = ds[0]
+    assert item["image_id"] == 101 and item["captions"] == ["a cafe on the left side.", "unicode accents"]
+    assert np.array_equal(item["image"].cpu().numpy(), pixels[101])
+    if os.path.isdir("/root/reference"):                                               # the live reference class, where it exists
+        import sys
+        import types
+        sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_coco", "/root/reference/virtex/data/datasets/coco_captions.py")
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+        ref = mod.CocoCaptionsDataset(str(root), "val")
+        assert [(a, c) for a, _, c in ref.instances] == [(a, c) for a, _, c in ds.instances]

@@ -61,6 +61,12 @@ def _run(cmd):
     return r.stdout
 
 
+# per-file flags of the HIP build.  conv3_bwd.hip: hipcc's SLP vectoriser turns the BatchNorm arithmetic of the transform and
+# the epilogue into v_pk_*_f32; the kernel is issue- / latency-bound with two waves per SIMD and runs 4 % faster without
+# (225.5 vs 234.1 us, profiles/r05_conv3_bwd_variants.txt)
+FILE_FLAGS = {"conv3_bwd.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile_all(compiler, flags, objdir, hdr_mtime, verbose):
     os.makedirs(objdir, exist_ok=True)
     jobs, objs = [], []
@@ -69,7 +75,8 @@ def _compile_all(compiler, flags, objdir, hdr_mtime, verbose):
         objs.append(obj)
         if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_mtime):
             continue
-        jobs.append([compiler] + flags + ["-c", src, "-o", obj])
+        extra = FILE_FLAGS.get(os.path.basename(src), []) if compiler == HIPCC else []
+        jobs.append([compiler] + flags + extra + ["-c", src, "-o", obj])
     if jobs:
         with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             for out in ex.map(_run, jobs):
@@ -110,8 +117,9 @@ def main():
     ap.add_argument("-v", "--verbose", action="store_true")
     ap.add_argument("--variant", default=None, help="A/B build: libvirtex_amd_<variant>.so")
     ap.add_argument("--define", action="append", default=[], help="extra -D for an A/B build")
+    ap.add_argument("--flag", action="append", default=[], help="extra compiler flag for an A/B build (e.g. --flag=-fno-slp-vectorize)")
     a = ap.parse_args()
-    path = build_emu(a.verbose) if a.emu else build_hip(a.verbose, a.variant, ["-D" + d for d in a.define])
+    path = build_emu(a.verbose) if a.emu else build_hip(a.verbose, a.variant, ["-D" + d for d in a.define] + list(a.flag))
     print(path)
 
 

@@ -2,7 +2,7 @@
 //
 //      dz  (gradient wrt bn3's output, masked by the producing join kernel)      [M][256] bf16  -- read once
 //      x3  (bn3's input = conv3's output)                                         [M][256] bf16  -- read once
-//   -> dx3 = BatchNorm3-backward apply: a0*dz - (x3 - mu)*a1 - a2                 (registers / LDS only: never in HBM)
+//   -> dx3 = BatchNorm3-backward apply: a0*dz - a1*x3 - (a2 - mu*a1)                (registers / LDS only: never in HBM)
 //   -> dy2 = dx3 . W3          (conv3's input gradient, MFMA)  + bn2's ReLU mask + bn2's backward sums   [M][64] -- written once
 //   -> dW3 += dx3^T . a3       (conv3's weight gradient, MFMA), a3 = relu(bn2(x2)) recomputed from x2   [M][64] -- read once
 //
@@ -40,6 +40,10 @@ extern int g_vtx_sw_conv3_bwd;
 int vtx_bn_bwd_finalize_only(const float* gamma, const float* save_rstd, const float* pre_partials, int pre_nparts, float* dgamma,
                              float* dbeta, float* workspace, int P, int C, hipStream_t st, const float** coef_out);
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
+
+#ifndef VTX_CB_ABL
+#define VTX_CB_ABL 0       // measurement builds only (tools/r05_s5.sh): 1 no weight gradient, 2 no input-gradient MFMAs, 4 no epilogue,
+#endif                     // 8 transform = copy, 16 no dz / x3 loads -- results are wrong with any of them set
 
 namespace {
 
@@ -113,7 +117,8 @@ __global__ __launch_bounds__(CB_T, 2) void conv3_bwd_fused_kernel(const Conv3Bwd
     for (int k = tid; k < CB_K; k += CB_T) {
         // dx = k0*(dz - k1 - xhat*k2), xhat = (x - mu)*rs  ==  k0*dz - (x - mu)*(k0*k2*rs) - k0*k1   (bn_bwd_apply_fused_kernel)
         const float k0 = a.coef3[k], k1 = a.coef3[CB_K + k], k2 = a.coef3[2 * CB_K + k];
-        tc[k] = a.mean3[k]; tc[CB_K + k] = k0; tc[2 * CB_K + k] = k0 * k2 * a.rstd3[k]; tc[3 * CB_K + k] = k0 * k1;
+        const float a1 = k0 * k2 * a.rstd3[k];
+        tc[k] = a.mean3[k]; tc[CB_K + k] = k0; tc[2 * CB_K + k] = a1; tc[3 * CB_K + k] = k0 * k1 - a.mean3[k] * a1;
     }
     for (int n = tid; n < CB_N; n += CB_T) {
         const float rs = a.rstd2[n], mu = a.mean2[n], ga = a.gamma2[n];
@@ -142,19 +147,22 @@ __global__ __launch_bounds__(CB_T, 2) void conv3_bwd_fused_kernel(const Conv3Bwd
         const bool more = rb + (int)gridDim.x < a.nrb;                 // wave-uniform
         const uint4 x2c0 = rx2[0], x2c1 = rx2[1];
         {
-            float mu[8], c0[8], c1[8], c2[8];
-            ld8(tc + kc, mu); ld8(tc + CB_K + kc, c0); ld8(tc + 2 * CB_K + kc, c1); ld8(tc + 3 * CB_K + kc, c2);
+            float c0[8], c1[8], c2[8];
+            ld8(tc + CB_K + kc, c0); ld8(tc + 2 * CB_K + kc, c1); ld8(tc + 3 * CB_K + kc, c2);
             auto chunk = [&](int j) {
                 float g[8], x[8];
                 unpack8(rdz[j], g); unpack8(rx3[j], x);
                 uint32_t o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v0 = c0[2 * e] * g[2 * e] - (x[2 * e] - mu[2 * e]) * c1[2 * e] - c2[2 * e];
-                    const float v1 = c0[2 * e + 1] * g[2 * e + 1] - (x[2 * e + 1] - mu[2 * e + 1]) * c1[2 * e + 1] - c2[2 * e + 1];
+                    // a0*dz - a1*x - (a2 - mu*a1): two FMAs per element (bn_bwd_apply_fused_kernel centres x first: three
+                    // operations; the difference is rounding of the small x-term, 2.7e-5 relative on dy2)
+                    const float v0 = c0[2 * e] * g[2 * e] - (x[2 * e] * c1[2 * e] + c2[2 * e]);
+                    const float v1 = c0[2 * e + 1] * g[2 * e + 1] - (x[2 * e + 1] * c1[2 * e + 1] + c2[2 * e + 1]);
                     o[e] = f2bf2(v0, v1);
                 }
                 const int m = 16 * j + l15;
+                if (VTX_CB_ABL & 8) { o[0] = rdz[j].x ^ rx3[j].x; o[1] = rdz[j].y; o[2] = rdz[j].z; o[3] = rdz[j].w; }
                 *reinterpret_cast<uint4*>(smem + OFF_DX + m * (CB_K * 2) + swz_dx(4 * wave + slot, m) * 16) = make_uint4(o[0], o[1], o[2], o[3]);
             };
             {
@@ -166,8 +174,10 @@ __global__ __launch_bounds__(CB_T, 2) void conv3_bwd_fused_kernel(const Conv3Bwd
                 for (int j = 0; j < 8; ++j) {
                     chunk(j);
                     vtx_loads_issued();                                // (scheduling barriers: the refill stays behind the chunk's last use)
-                    rdz[j] = *reinterpret_cast<const uint4*>(a.dz + o + j * js);
-                    rx3[j] = *reinterpret_cast<const uint4*>(a.x3 + o + j * js);
+                    if (!(VTX_CB_ABL & 16)) {
+                        rdz[j] = *reinterpret_cast<const uint4*>(a.dz + o + j * js);
+                        rx3[j] = *reinterpret_cast<const uint4*>(a.x3 + o + j * js);
+                    }
                     vtx_loads_issued();
                 }
                 const long o2 = more ? ((long)(rb + gridDim.x) * CB_RB + 16 * wave + (lane >> 3)) * CB_N + 8 * (lane & 7) : 0;
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(CB_T, 2) void conv3_bwd_fused_kernel(const Conv3Bwd
         f32x4_t acc[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        {
+        if (!(VTX_CB_ABL & 2)) {
             const int mr = 16 * wave + l15;
             const char* arow = smem + OFF_DX + mr * (CB_K * 2);
 #pragma unroll
@@ -203,18 +213,24 @@ __global__ __launch_bounds__(CB_T, 2) void conv3_bwd_fused_kernel(const Conv3Bwd
                 make_uint2(f2bf2(acc[j][0], acc[j][1]), f2bf2(acc[j][2], acc[j][3]));
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < ((VTX_CB_ABL & 4) ? 0 : 2); ++q) {
             const int r = er0 + 8 * q;
             const uint4 w = *reinterpret_cast<const uint4*>(strip + r * CB_SROWB + ech * 16);
-            float g[8], x[8], rs[8], sh[8], ga[8], be[8], xh[8];
+            float g[8], x[8], rs[8], sh[8], be[8], xh[8];
             unpack8(w, g); unpack8(q == 0 ? x2c0 : x2c1, x);
             const float* pl = par + 8 * ech;
-            ld8(pl, rs); ld8(pl + CB_N, sh); ld8(pl + 2 * CB_N, ga); ld8(pl + 3 * CB_N, be);
+            ld8(pl, rs); ld8(pl + CB_N, sh); ld8(pl + 3 * CB_N, be);
             uint32_t wo[4];
+            // the mask as the forward pass took it: y2 = (x2 - mean) * scale + beta > 0 -- bn_apply_kernel's expression, which
+            // the recomputed conv3 input below needs anyway (EpiStore<.., STATS_BWD> tests xhat * gamma + beta > 0: the same
+            // predicate up to the rounding of a value at the threshold)
+            float mu2l[8], sc2l[8], yl[8];
+            ld8(pl + 4 * CB_N, mu2l); ld8(pl + 5 * CB_N, sc2l);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 xh[e] = x[e] * rs[e] + sh[e];
-                g[e] = xh[e] * ga[e] + be[e] > 0.f ? g[e] : 0.f;
+                yl[e] = (x[e] - mu2l[e]) * sc2l[e] + be[e];
+                g[e] = yl[e] > 0.f ? g[e] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {                                  // sums of what is stored (the ROUNDED gradient)
@@ -226,15 +242,9 @@ __global__ __launch_bounds__(CB_T, 2) void conv3_bwd_fused_kernel(const Conv3Bwd
             for (int e = 0; e < 8; ++e) { s1[e] += g[e]; s2[e] += g[e] * xh[e]; }
             *reinterpret_cast<uint4*>(a.dy2 + (m0 + 16 * wave + r) * CB_N + 8 * ech) = make_uint4(wo[0], wo[1], wo[2], wo[3]);
             // conv3's input, recomputed: y2 = relu((x2 - mean) * scale + beta) as bn_apply_kernel stored it
-            float mu2[8], sc2[8];
-            ld8(pl + 4 * CB_N, mu2); ld8(pl + 5 * CB_N, sc2);
             uint32_t yo[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float y0 = fmaxf((x[2 * e] - mu2[2 * e]) * sc2[2 * e] + be[2 * e], 0.f);
-                const float y1 = fmaxf((x[2 * e + 1] - mu2[2 * e + 1]) * sc2[2 * e + 1] + be[2 * e + 1], 0.f);
-                yo[e] = f2bf2(y0, y1);
-            }
+            for (int e = 0; e < 4; ++e) yo[e] = f2bf2(fmaxf(yl[2 * e], 0.f), fmaxf(yl[2 * e + 1], 0.f));
             const int m = 16 * wave + r;
             *reinterpret_cast<uint4*>(smem + OFF_A3 + m * (CB_N * 2) + swz_a3(ech, m) * 16) = make_uint4(yo[0], yo[1], yo[2], yo[3]);
         }
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(CB_T, 2) void conv3_bwd_fused_kernel(const Conv3Bwd
 
         // ---- (4) weight gradient of channels 32w .. 32w+31: dW3[ko][n] += sum_m dx3[m][ko] * a3[m][n]
 #pragma unroll 1            // (unrolled: 256 VGPRs + scratch; rolled: 237, and the addresses differ by immediates only)
-        for (int t = 0; t < CB_RB / 32; ++t) {
+        for (int t = 0; t < ((VTX_CB_ABL & 1) ? 0 : CB_RB / 32); ++t) {
             const int ka = 32 * t + 8 * slot + (l15 >> 2), c4 = 4 * (l15 & 3);
             vtx_v4s_t ry[2][2], rx[4][2];
 #pragma unroll

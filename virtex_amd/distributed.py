@@ -162,6 +162,21 @@ def execution_order(model: torch.nn.Module) -> List[torch.nn.Parameter]:
     return text + list(reversed(cnn))
 
 
+class _RecordedHandle:
+    """The work handle of a recorded all-reduce: `slot[0]` is the handle of the most recent issue (the recording's, then each
+    replay's); wait() waits for it and, while recording, appends that wait to the list."""
+
+    def __init__(self, slot):
+        self.slot = slot
+
+    def wait(self):
+        from . import replay
+        self.slot[0].wait()
+        rec = replay.active()
+        if rec is not None:
+            rec.add("collective", lambda s=self.slot: s[0].wait(), label="all_reduce.wait")
+
+
 class GradientBuckets:
     """payload: "fp32" (default) exchanges the flat gradient buffer itself; "bf16" rounds every bucket to bf16 first
     (half the xGMI bytes: 138.9 instead of 277.9 MB per step) and widens the summed result back into the fp32 buffer
@@ -267,14 +282,40 @@ class GradientBuckets:
         if self.pending[b] == 0:
             self._launch(b)
 
+    @staticmethod
+    def _all_reduce(t):
+        """One asynchronous SUM all-reduce.  While a launch recording is being made (virtex_amd.replay) the collective and
+        the later wait() on its handle become ops of the recorded list: a replay re-issues them in the recorded order."""
+        from . import replay
+        h = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        rec = replay.active()
+        if rec is None:
+            return h
+        slot = [h]
+        rec.add("collective", lambda t=t, slot=slot: slot.__setitem__(0, dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)),
+                t, label=f"all_reduce {t.numel()} x {str(t.dtype).split('.')[-1]}")
+        return _RecordedHandle(slot)
+
+    @staticmethod
+    def _copy(dst, src):
+        """dst.copy_(src) of the payload conversions: recorded exactly once, whichever thread / dispatch mode runs it."""
+        from . import replay
+        rec = replay.active()
+        if rec is None:
+            dst.copy_(src)
+            return
+        with replay.explicit_ops():
+            dst.copy_(src)
+        rec.add("aten", lambda d=dst, s_=src: d.copy_(s_), dst, src, label="copy_ (gradient payload)")
+
     def _reduce(self, s, e):
         """The collective of one bucket (runs on the communication stream when there is one)."""
         chunk = self.flat[s:e]
         if self.wire is None:
-            return dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
+            return self._all_reduce(chunk)
         wire = self.wire[s:e]
-        wire.copy_(chunk)                                   # fp32 -> bf16 (round to nearest even)
-        h = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True)
+        self._copy(wire, chunk)                             # fp32 -> bf16 (round to nearest even)
+        h = self._all_reduce(wire)
         self.widen.append((h, chunk, wire))
         return h
 
@@ -312,7 +353,7 @@ class GradientBuckets:
                 for h in self.handles:
                     h.wait()
                 for (_, chunk, wire) in self.widen:
-                    chunk.copy_(wire)               # bf16 sum -> the fp32 buffer the optimizer reads
+                    self._copy(chunk, wire)         # bf16 sum -> the fp32 buffer the optimizer reads
             # how long the compute stream sits in this wait = the part of the gradient exchange the backward pass did NOT
             # hide; two events per step, read (and synchronised) only by comm_exposed_ms()
             cur = torch.cuda.current_stream()
@@ -330,7 +371,7 @@ class GradientBuckets:
             for h in self.handles:
                 h.wait()
             for (_, chunk, wire) in self.widen:
-                chunk.copy_(wire)
+                self._copy(chunk, wire)
         self.last_early = len(self.early)    # how many gradients were announced from inside a backward node (diagnostic)
         self.begin()                    # armed for the next backward
         return 1.0 / self.world

@@ -27,7 +27,12 @@ must reproduce that step's loss, gradients and updated state; a recorded launch 
 recording left in its buffers -- X-values -- and fails the comparison.  `tests/test_replay.py` also walks the list the way the
 replay does and checks every op against the stream it saw when it was recorded.
 
-Single process only (the data-parallel all-reduces are torch.distributed calls issued from autograd hooks).
+Data parallelism (round 5): the gradient exchange is part of the list.  `distributed.GradientBuckets` records every bucket
+all-reduce it issues (`torch.distributed.all_reduce(..., async_op=True)` on the communication stream, behind the recorded event
+/ stream waits that fence it against the three compute streams) and the `wait()` that orders the streams after it; a replay
+re-issues the collectives from the main thread in the recorded order -- the order every rank recorded, so ranks may even mix
+replayed and eager steps.  world_size-2 gloo test on the emulator: tests/test_distributed_emu.py; RCCL with one forced rank on
+the GPU: tests/test_distributed_gpu.py.
 """
 import threading
 from typing import Callable, Dict, List, Optional
@@ -67,7 +72,7 @@ class Recorder:
         self.at_stream: List[Optional[int]] = []   # id of the calling thread's current stream when the op was recorded (tests)
         self.keep = []                   # tensors / ctypes objects whose memory the recorded arguments point into
         self.lock = threading.Lock()
-        self.counts = {"kernel": 0, "aten": 0, "stream": 0, "engine_switch": 0}
+        self.counts = {"kernel": 0, "aten": 0, "stream": 0, "engine_switch": 0, "collective": 0}
         self.cur = _current_stream_key()         # the stream the replay will be on at this point of the list
         self.start = self.cur
 
@@ -93,6 +98,20 @@ class Recorder:
 
 
 _active: Optional[Recorder] = None
+_tl = threading.local()
+
+
+class explicit_ops:
+    """Inside this context the ATen dispatch recorder records nothing: the caller adds its own thunks (`active().add`).  For
+    code that may run either inside a traced backward (dispatch mode on) or from an autograd hook on the engine's thread
+    (dispatch mode off) and must be recorded exactly once: the data-parallel engine's payload conversions."""
+
+    def __enter__(self):
+        _tl.explicit = getattr(_tl, "explicit", 0) + 1
+
+    def __exit__(self, *exc):
+        _tl.explicit -= 1
+        return False
 
 
 def active() -> Optional[Recorder]:
@@ -144,7 +163,7 @@ class _RecordAten(TorchDispatchMode):
         kwargs = kwargs or {}
         out = func(*args, **kwargs)
         rec = _active
-        if rec is None:
+        if rec is None or getattr(_tl, "explicit", 0):
             return out
         name = func._schema.name.split("::")[-1]
         if name in _VIEW_NAMES or name in _NO_WORK:
@@ -304,8 +323,6 @@ class StepReplay:
 
     def __init__(self, model: torch.nn.Module, buckets, optimizer, example_batch: Dict[str, torch.Tensor], warmup: int = 2,
                  validate: bool = True):
-        if getattr(buckets, "enabled", False):
-            raise ValueError("StepReplay is single-process: the gradient exchange of N > 1 stays on the eager path")
         self.model, self.buckets, self.opt = model, buckets, optimizer
         self.static = {k: v.clone() for k, v in example_batch.items()}
         optimizer.enable_device_schedule()
