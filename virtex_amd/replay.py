@@ -402,8 +402,16 @@ class StepReplay:
         self._sync()
         restored_batch = batch_x
 
-        def close(a, b):                                     # (the embedding's fp32 atomics reorder sums: 1e-7 relative)
+        # the embedding's fp32 atomics reorder sums (1e-7 relative); with the bf16 gradient payload of the data-parallel engine
+        # such a difference can cross a rounding boundary: one bf16 ulp (2^-8 relative) on single elements of the exchanged buffer
+        # (and into the momentum / parameters it updates): the comparison is then one of norms at the payload's precision -- a
+        # launch that ran before its producer differs by the whole tensor, not by rounding
+        bf16_wire = getattr(self.buckets, "enabled", False) and getattr(self.buckets, "payload", "fp32") == "bf16"
+
+        def close(a, b):
             if a.dtype.is_floating_point:
+                if bf16_wire:
+                    return (a.double() - b.double()).norm().item() <= 1e-3 * max(a.double().norm().item(), 1e-30)
                 scale = max(a.abs().max().item(), 1e-30)
                 return (a.double() - b.double()).abs().max().item() <= 2e-5 * scale
             return torch.equal(a, b)
