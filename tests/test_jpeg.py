@@ -159,3 +159,15 @@ def test_coco_captions_reader_matches_the_reference_dataset(backend, tmp_path):
         mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
         ref = mod.CocoCaptionsDataset(str(root), "val")
         assert [(a, c) for a, _, c in ref.instances] == [(a, c) for a, _, c in ds.instances]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_batch_decode_on_host_threads_equals_single_decodes(backend):
+    from virtex_amd import jpeg as vj
+    dev = select(backend)
+    z = np.load(GOLDEN)
+    blobs = [z[f"jpeg_{i}"].tobytes() for i in range(int(z["count"]))]
+    outs = vj.decode_jpeg_batch(blobs, dev, threads=4)
+    assert len(outs) == len(blobs)
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy(), z[f"rgb_{i}"]), i

@@ -50,6 +50,36 @@ def decode_jpeg(data: bytes, device, apply_orientation: bool = True) -> torch.Te
     return rgb
 
 
+def decode_jpeg_batch(blobs, device, threads: int = 8, apply_orientation: bool = True) -> List[torch.Tensor]:
+    """Many files at once: the serial Huffman decoding of the images runs on `threads` host threads (the C entry points hold no
+    Python state and ctypes releases the GIL), every image's device work is enqueued on the caller's stream as its coefficients
+    become available.  Returns the uint8 (H, W, 3) tensors in input order."""
+    from concurrent.futures import ThreadPoolExecutor
+    device = torch.device(device)
+    pin = device.type == "cuda"
+
+    def host(data):
+        info = jpeg_info(data)
+        coef = torch.empty(info["blocks"] * 64, dtype=torch.int16, pin_memory=pin)
+        qt = torch.empty(4 * 64, dtype=torch.int16, pin_memory=pin)
+        _lib.call("vtx_jpeg_entropy_decode", ctypes.c_char_p(data), c_long(len(data)), ctypes.c_void_p(coef.data_ptr()),
+                  c_long(coef.numel()), ctypes.c_void_p(qt.data_ptr()))
+        return info, coef, qt
+
+    out = []
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
+        for data, (info, coef, qt) in zip(blobs, pool.map(host, blobs)):
+            coef_d, qt_d = coef.to(device, non_blocking=True), qt.to(device, non_blocking=True)
+            planes = torch.empty(info["plane_bytes"], dtype=torch.uint8, device=device)
+            swap = apply_orientation and info["orientation"] >= 5
+            H, W = (info["width"], info["height"]) if swap else (info["height"], info["width"])
+            rgb = torch.empty(H, W, 3, dtype=torch.uint8, device=device)
+            _lib.call("vtx_jpeg_reconstruct", ctypes.c_char_p(data), c_long(len(data)), ptr(coef_d), ptr(qt_d), ptr(planes), ptr(rgb),
+                      c_int(1 if apply_orientation else 0), stream_ptr(rgb))
+            out.append(rgb)
+    return out
+
+
 def normalize_caption(caption: str) -> str:
     """The reference's caption normalisation (coco_captions.py:33-38): lowercase, NFKD, combining marks stripped."""
     caption = unicodedata.normalize("NFKD", caption.lower())
