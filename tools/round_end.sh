@@ -36,4 +36,7 @@ cd $R
 python tools/rocpd_stats.py $(find gpurun_out/prof_c4 -name "*.db" | head -1) 40 > gpurun_out/kernel_stats_serial_config4.txt
 python tools/rocpd_stats.py $(find gpurun_out/prof_c5 -name "*.db" | head -1) 40 > gpurun_out/kernel_stats_serial_config5.txt
 find gpurun_out -name "*.db" -delete; rm -rf gpurun_out/prof_c4 gpurun_out/prof_c5 gpurun_out/prof_kt gpurun_out/prof_ks gpurun_out/prof_fetch gpurun_out/prof_write
+# round 5: the fused conv3 backward against the launches it replaces; JPEG decode throughput of the input pipeline
+timeout 300 python tools/bench_conv3_bwd.py > gpurun_out/conv3_bwd.txt 2>&1
+timeout 300 python tools/bench_jpeg.py > gpurun_out/bench_jpeg.txt 2>&1
 cat gpurun_out/gpu_tests.txt
