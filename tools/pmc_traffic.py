@@ -22,7 +22,7 @@ FAMILIES = [("bn_bwd_apply_fused_kernel", "bn_bwd_apply"), ("pool_bn_bwd_apply_k
             ("bn_relu_maxpool_fwd_kernel", "bn_fwd_apply"), ("bn_apply_kernel", "bn_fwd_apply"), ("pool_bn_bwd_reduce_kernel", "bn_bwd_reduce"),
             ("bn_reduce_kernel", "bn_reduce"), ("ln_fwd_kernel", "layernorm_fwd"), ("ln_bwd_kernel", "layernorm_bwd"),
             ("embed_fwd_kernel", "embedding_fwd"), ("embed_bwd_kernel", "embedding_bwd"), ("sgd_lookahead_kernel", "optimizer_step"),
-            ("expand1x1_fwd_kernel", "expand1x1_fwd"), ("stem_stream_fwd_kernel", "stem_stream_fwd"),
+            ("expand1x1_fwd_kernel", "expand1x1_fwd"), ("conv3_bwd_fused_kernel", "conv3_bwd_fused"), ("stem_stream_fwd_kernel", "stem_stream_fwd"),
             ("conv3x3_wgrad_stream_kernel", "conv3x3_wgrad_stream"), ("splitk_reduce_kernel", "splitk_reduce"),
             ("maxpool_fwd_kernel", "maxpool_fwd"), ("maxpool_bwd_kernel", "maxpool_bwd"), ("weight_prep_batched_kernel", "weight_prep")]
 
