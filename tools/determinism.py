@@ -16,7 +16,7 @@ batch = synthetic.synthetic_batch(B, dev)
 bn_state = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
 
 def run():
-    th._seed_counter = itertools.count(1)
+    th.dropout_seed_state(0)                 # the same dropout seeds in every run
     model.load_state_dict(bn_state, strict=False)
     buckets.zero(); buckets.begin()
     out = model(batch); out["loss"].backward(); buckets.finish()
