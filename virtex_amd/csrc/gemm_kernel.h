@@ -1268,6 +1268,9 @@ __device__ __forceinline__ void epi_prefetch(const EP& ep, float (&pre)[EpiShape
 #ifndef VTX_EPI_OPS_ALL
 #define VTX_EPI_OPS_ALL 1      // 1: the epilogue operands of ALL 16-row steps of a wave tile are fetched up front (<= 4 chunks)
 #endif
+#ifndef VTX_EPI_ALL_MAX
+#define VTX_EPI_ALL_MAX 4      // ... up to this many chunks per lane (measurement builds: 8 = the four-wave 128x128 tile too)
+#endif
 // acc: the wave's MT x NT accumulator tiles (D = Btile x Atile: lane holds C[m = .. + (lane&15)][n = .. + 4*(lane>>4) + 0..3]);
 // lds: the block's stage memory (LDS_BYTES), free once every wave has left the K loop; tile_m / tile_n: the tile's place in
 // the grid (statistics strip / column group)
@@ -1336,7 +1339,7 @@ __device__ __forceinline__ void tile_epilogue(EP& ep, f32x4_t (&acc)[BM / WM / 1
                 const char* rd_ptr = strip + r0 * ROWB + ch * 16;
                 const float alpha = ep.alpha;
                 // wave tiles of at most four chunks per lane: the operand chunks of ALL steps are requested up front
-                constexpr bool ALL = VTX_EPI_OPS_ALL && SM == STATS_BWD && MT * NCHL <= 4;
+                constexpr bool ALL = VTX_EPI_OPS_ALL && SM == STATS_BWD && MT * NCHL <= VTX_EPI_ALL_MAX;
                 typename EP::Ops o[ALL ? MT : 1][NCHL];
                 if constexpr (ALL) {
 #pragma unroll
