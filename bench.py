@@ -520,6 +520,10 @@ def main(argv=None, device=None, backend=None):
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "launch": launch_mode,
                        "eager_ms_per_step": (round(eager_ms, 3) if eager_ms is not None else (round(elapsed / a.steps * 1e3, 3) if launch_mode == "eager" else None)),
                        "launch_fallback_reason": launch_fallback,
+                       # peak of torch's allocator over the whole run: under launch replay this is the validation's peak (two recordings
+                       # of a step pinned at once + an eager step), the steady state holds one recording
+                       "peak_memory_gb": (round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),
+                       "steady_memory_gb": (round(torch.cuda.memory_allocated(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),
                        "host_enqueue_ms_per_step": round(host_issue / a.steps * 1e3, 3),
                        "host_enqueue_note": "wall time of the issuing loop / steps; a host faster than the GPU spends the difference "
                                             "blocked on the full HIP queue, so a value near ms_per_step means 'host not the limit' "
