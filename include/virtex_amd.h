@@ -380,6 +380,9 @@ int vtx_colsum_acc(int dtype, const void* x, long ld, float* out /*[C] +=*/, flo
 int vtx_add(int dtype, const void* a, const void* b, void* out, long n, void* stream);
 int vtx_gelu_bwd(int dtype, const void* h, const void* da, void* dh, long n, float p_drop, uint64_t seed,
                  void* stream);
+/* dy = dropout'(dx) with the mask of (seed, element index): the gradient through x + dropout(y) of a PRE-norm decoder sub-layer
+ * (textual_heads.py:181-194 with norm_first=True; aten::native_dropout_backward) */
+int vtx_dropout_bwd(int dtype, const void* dx, void* dy, long n, float p_drop, uint64_t seed, void* stream);
 
 /* ---- fused optimizer tail over flat fp32 buffers (csrc/optim.hip) -----------------------
  * Replaces clip_grad_norm_ + SGD(momentum, per-tensor lr / weight decay) + Lookahead of

@@ -40,6 +40,10 @@ CASES = {
     "r50_l2_h128_b3_small": (
         dict(textual="transdec_postnorm::L2_H128_A2_F256", vocab_size=1000),
         dict(batch_size=3, image_size=64, max_len=12, vocab_size=1000, seed=2, ragged=True)),
+    # the pre-norm decoder product (reference: factories.py "transdec_prenorm")
+    "r50_l2_h128_b3_prenorm": (
+        dict(textual="transdec_prenorm::L2_H128_A2_F256", vocab_size=1000),
+        dict(batch_size=3, image_size=64, max_len=12, vocab_size=1000, seed=3, ragged=True)),
 }
 
 
@@ -118,7 +122,10 @@ def main():
     if not reference_import.available():
         sys.exit("needs /root/reference")
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only = sys.argv[1:]                      # optional: the cases to (re)generate; default all
     for name, (mkw, bkw) in CASES.items():
+        if only and name not in only:
+            continue
         rec = run_case(name, mkw, bkw, use_reference=True)
         rec["meta"] = {"model": mkw, "batch": bkw, "torch": torch.__version__,
                        "generator": "oracle/make_goldens.py (verbatim /root/reference classes)"}

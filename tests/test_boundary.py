@@ -91,10 +91,12 @@ def test_register_installs_native_products_in_the_reference_registries(reference
     from virtex_amd.modules import textual_heads, visual_backbones
 
     ref_f, Config, replaced, saved = reference_registries
-    assert len(replaced) == 7
+    assert len(replaced) == 8
     assert ref_f.VisualBackboneFactory.PRODUCTS["torchvision"] is visual_backbones.TorchvisionVisualBackbone
     assert set(ref_f.TextualHeadFactory.PRODUCTS) == {"transdec_prenorm", "transdec_postnorm", "none"}
-    assert ref_f.TextualHeadFactory.PRODUCTS["transdec_prenorm"] is saved[1]["transdec_prenorm"]     # untouched
+    assert ref_f.TextualHeadFactory.PRODUCTS["transdec_prenorm"].func is textual_heads.TransformerDecoderTextualHead
+    assert ref_f.TextualHeadFactory.PRODUCTS["transdec_prenorm"].keywords == {"norm_first": True}
+    assert ref_f.TextualHeadFactory.PRODUCTS["none"] is saved[1]["none"]                              # untouched
     assert ref_f.PretrainingModelFactory.PRODUCTS["masked_lm"] is saved[2]["masked_lm"]
     assert ref_f.CaptionDecoderFactory.PRODUCTS["beam_search"] is decoding.AutoRegressiveBeamSearch
 

@@ -142,7 +142,8 @@ def test_device_beam_step_reproduces_reference_goldens(backend, case):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_incremental_decoding_step_equals_full_prefix_recompute(backend, dtype):
+@pytest.mark.parametrize("kind", ["transdec_postnorm", "transdec_prenorm"])
+def test_incremental_decoding_step_equals_full_prefix_recompute(backend, dtype, kind):
     """The KV-cached step (one token per call) against `model.decoding_step` (the reference's semantics: the whole
     prefix through the head at every call) on the SAME model: logits of every step of a beam search with re-ordered,
     duplicated and dropped beams, driven by the prefixes alone (no `reorder` hint -- what a foreign decoder gives)."""
@@ -151,7 +152,7 @@ def test_incremental_decoding_step_equals_full_prefix_recompute(backend, dtype):
     from virtex_amd.decoding import IncrementalDecodingStep
     dev = select(backend)
     torch.manual_seed(3)
-    model = vf.build_bicaptioning_model(textual="transdec_postnorm::L2_H128_A2_F256", vocab_size=300, dropout=0.0,
+    model = vf.build_bicaptioning_model(textual=kind + "::L2_H128_A2_F256", vocab_size=300, dropout=0.0,
                                         compute_dtype=dtype, max_caption_length=12).to(dev).eval()
     synth.randomize_state(model, 7)
     feats = torch.randn(3, 2048, 2, 2, device=dev).to(dtype if dtype == torch.bfloat16 else torch.float32)

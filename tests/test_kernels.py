@@ -62,6 +62,27 @@ def test_layernorm_dropout_statistics(backend):
     assert torch.equal(dy3, dy)
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N", [(96, 128), (130, 200), (37, 72)])
+def test_dropout_bwd_replays_the_mask_of_the_gemm_epilogue(backend, dtype, M, N):
+    """vtx_dropout_bwd(seed) keeps exactly the elements the GEMM epilogue kept under the same seed (the join
+    x + dropout(y) of a pre-norm sub-layer and its backward), scaled by 1 / (1 - p); ragged sizes included."""
+    dev = select(backend)
+    p, seed = 0.25, 4242
+    a = torch.randn(M, 64, device=dev).to(dtype)
+    b = torch.randn(N, 64, device=dev).to(dtype)
+    bias = torch.full((N,), 100.0, device=dev)                   # no output element is zero before the mask
+    y = ops.gemm_nt(a, b, bias=bias, p_drop=p, seed=seed)
+    kept = y != 0
+    assert abs(kept.float().mean().item() - (1 - p)) < 0.03
+    dx = (torch.randn(M, N, device=dev).abs() + 0.5).to(dtype)
+    dy = ops.dropout_bwd(dx, p, seed)
+    assert torch.equal(dy != 0, kept)
+    assert torch.allclose(dy[kept].float(), dx[kept].float() / (1 - p), **tol(dtype))
+    assert ops.dropout_bwd(dx, 0.0, seed) is dx
+
+
 def _gemm_tol(dtype, K):
     # fp32 MFMA is an exact fmaf chain; bf16 inputs are exact products accumulated in fp32,
     # so against the fp32 product of the SAME (already rounded) inputs both are tight.

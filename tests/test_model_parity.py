@@ -240,6 +240,61 @@ def test_model_fp32_gpu(case):
     _check(case, dev, torch.float32, text_tol=1e-3, loss_tol=1e-5, cnn_factor=4.0 if toy else None, cnn_floor=1.5e-2 if toy else None)
 
 
+@pytest.mark.emu
+def test_small_prenorm_model_fp32_emulator():
+    """the "transdec_prenorm" product (reference: factories.py:358-366): loss, every gradient (incl. the closing LayerNorm
+    of the stack) and the buffers against the oracle and the reference's golden of that case"""
+    _check("r50_l2_h128_b3_prenorm", select("emu"), torch.float32, text_tol=1e-3, loss_tol=1e-5, cnn_factor=4.0, cnn_floor=1.5e-2)
+
+
+@pytest.mark.emu
+def test_small_prenorm_model_eval_fp32_emulator():
+    _check_eval("r50_l2_h128_b3_prenorm", select("emu"), torch.float32, feat_tol=1e-4, loss_tol=1e-5)
+
+
+@pytest.mark.gpu
+def test_prenorm_model_fp32_gpu():
+    dev = select("gpu")
+    _check("r50_l2_h128_b3_prenorm", dev, torch.float32, text_tol=1e-3, loss_tol=1e-5, cnn_factor=4.0, cnn_floor=1.5e-2)
+    _check_eval("r50_l2_h128_b3_prenorm", dev, torch.float32, feat_tol=1e-4, loss_tol=1e-5)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_prenorm_dropout_masks_of_forward_and_backward_agree(backend):
+    """With dropout on, the pre-norm joins x + dropout(y) are GEMM epilogues and their backward masks come from
+    vtx_dropout_bwd with the same (seed, element index): the text-side gradients must be those of the torch graph built
+    from the SAME masks.  The masks are recovered from the kernels themselves (identity weights are not needed: one
+    layer, compared through a directional derivative of the loss, which only matches when every mask agrees)."""
+    dev = select(backend)
+    import virtex_amd.modules.textual_heads as th
+    torch.manual_seed(0)
+    head = th.TransformerDecoderTextualHead(64, 200, 128, 2, 2, 256, dropout=0.3, norm_first=True,
+                                            max_caption_length=12, compute_dtype=torch.float32).to(dev).train()
+    vis = torch.randn(2, 64, 3, 3, device=dev)
+    tok = torch.randint(1, 200, (2, 12), device=dev)
+    lens = torch.tensor([12, 7], device=dev)
+    w = torch.randn(2, 12, 128, device=dev)
+    params = [p for p in head.parameters() if p.requires_grad]
+    direction = [torch.randn_like(p) * 1e-2 for p in params]
+
+    def loss_at(eps):
+        if eps:
+            for p, d in zip(params, direction):
+                p.add_(d, alpha=eps)
+        th.dropout_seed_state(1234)                      # the same masks at every evaluation
+        out = (head.features(vis, tok, lens).float() * w).sum()
+        if eps:
+            for p, d in zip(params, direction):
+                p.add_(d, alpha=-eps)
+        return out
+    loss_at(0.0).backward()
+    analytic = sum((p.grad.double() * d.double()).sum().item() for p, d in zip(params, direction) if p.grad is not None)
+    h = 1e-2
+    with torch.no_grad():
+        numeric = (loss_at(h).double().item() - loss_at(-h).double().item()) / (2 * h)
+    assert abs(analytic - numeric) <= 2e-3 * max(abs(numeric), 1.0), (analytic, numeric)
+
+
 @pytest.mark.gpu
 def test_model_bf16_gpu():
     """bf16 compute mode (the throughput mode) is NOT a parity claim; on this B = 2 golden case it is bounded against the fp32

@@ -87,6 +87,20 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ h, 
     }
 }
 
+// dy = dropout'(dx): the gradient through y -> x + dropout(y) of a pre-norm decoder sub-layer (the mask is the one the GEMM
+// epilogue that produced x + dropout(y) drew: same seed, element index = position in the dense [rows][H] output)
+template <class T>
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const T* __restrict__ dx, T* __restrict__ dy, long nvec, Dropout drop) {
+    constexpr int VEC = Elem<T>::VEC;
+    drop = drop.resolved();
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        Vec16<T> g; g.load(dx + i * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g.v[j] = drop.apply(g.v[j], (uint64_t)(i * VEC + j));
+        g.store(dy + i * VEC);
+    }
+}
+
 static int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -149,6 +163,24 @@ extern "C" int vtx_gelu_bwd(int dtype, const void* h, const void* da, void* dh, 
         VTX_KLAUNCH("gelu_bwd", 0, 6.0 * n, (gelu_bwd_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h, (const bf16_t*)da, (bf16_t*)dh, n / vec, d);
     else
         VTX_KLAUNCH("gelu_bwd", 0, 12.0 * n, (gelu_bwd_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)h, (const float*)da, (float*)dh, n / vec, d);
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
+
+// Gradient through a residual sub-layer's dropout, x_out = x + dropout(y)  ->  dy = mask(seed) * dx / (1 - p): the pre-norm
+// decoder layers (nn.TransformerDecoderLayer(norm_first=True), /root/reference/virtex/modules/textual_heads.py:181-194;
+// aten::native_dropout_backward).  The post-norm layers get this from vtx_layernorm_residual_bwd.
+extern "C" int vtx_dropout_bwd(int dtype, const void* dx, void* dy, long n, float p_drop, uint64_t seed, void* stream) {
+    VTX_CHECK(dx && dy, VTX_ERR_ARG, "dropout_bwd: null pointer");
+    VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "dropout_bwd: bad dtype");
+    const int vec = dtype == VTX_BF16 ? 8 : 4;
+    VTX_CHECK(n >= 0 && n % vec == 0, VTX_ERR_SHAPE, "dropout_bwd: n must be a multiple of %d", vec);
+    if (n == 0) return VTX_OK;
+    Dropout d = make_dropout(p_drop, seed);
+    if (dtype == VTX_BF16)
+        VTX_KLAUNCH("dropout_bwd", 0, 4.0 * n, (dropout_bwd_kernel<bf16_t>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, (bf16_t*)dy, n / vec, d);
+    else
+        VTX_KLAUNCH("dropout_bwd", 0, 8.0 * n, (dropout_bwd_kernel<float>), dim3(grid_for(n / vec)), dim3(256), 0, (hipStream_t)stream, (const float*)dx, (float*)dy, n / vec, d);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -246,11 +246,24 @@ class IncrementalDecodingStep:
             if L["K"] is None:
                 L["K"] = torch.zeros(N, self.Tmax, H, dtype=dt, device=partial.device)
                 L["V"] = torch.zeros(N, self.Tmax, H, dtype=dt, device=partial.device)
-            qkv = ops.gemm_nt(x, w["Win"], bias=layer.self_attn.in_proj_bias.detach())                  # (N, 3H)
+            pre = getattr(head, "norm_first", False)
+
+            def norm(v, ln):                 # pre-norm layers normalise the sub-layer INPUT, the join is then a plain sum
+                return ops.layernorm_residual_fwd(v, None, ln.weight.detach(), ln.bias.detach(), ln.eps)[0]
+            h1 = norm(x, layer.norm1) if pre else x
+            qkv = ops.gemm_nt(h1, w["Win"], bias=layer.self_attn.in_proj_bias.detach())                 # (N, 3H)
             L["K"][:, pos] = qkv[:, H:2 * H]
             L["V"][:, pos] = qkv[:, 2 * H:]
             o1 = ops.attention_fwd(qkv[:, :H], L["K"].view(N * self.Tmax, H), L["V"].view(N * self.Tmax, H), N, A, 1, self.Tmax,
                                    False, lens)
+            if pre:
+                x1 = ops.gemm_nt(o1, w["Wo"], bias=layer.self_attn.out_proj.bias.detach(), residual=x)
+                q2 = ops.gemm_nt(norm(x1, layer.norm2), w["Win2"][:H], bias=layer.multihead_attn.in_proj_bias.detach()[:H])
+                o2 = ops.attention_fwd(q2, L["kv"][:, :H], L["kv"][:, H:], N, A, 1, self.S, False, None)
+                x2 = ops.gemm_nt(o2, w["Wo2"], bias=layer.multihead_attn.out_proj.bias.detach(), residual=x1)
+                a = ops.gemm_nt(norm(x2, layer.norm3), w["W1"], bias=layer.linear1.bias.detach(), act=ops.ACT_GELU)
+                x = ops.gemm_nt(a, w["W2"], bias=layer.linear2.bias.detach(), residual=x2)
+                continue
             y1 = ops.gemm_nt(o1, w["Wo"], bias=layer.self_attn.out_proj.bias.detach())
             x1, _, _ = ops.layernorm_residual_fwd(x, y1, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
             q2 = ops.gemm_nt(x1, w["Win2"][:H], bias=layer.multihead_attn.in_proj_bias.detach()[:H])
@@ -260,4 +273,7 @@ class IncrementalDecodingStep:
             a = ops.gemm_nt(x2, w["W1"], bias=layer.linear1.bias.detach(), act=ops.ACT_GELU)
             y3 = ops.gemm_nt(a, w["W2"], bias=layer.linear2.bias.detach())
             x, _, _ = ops.layernorm_residual_fwd(x2, y3, layer.norm3.weight.detach(), layer.norm3.bias.detach(), layer.norm3.eps)
+        if getattr(head, "norm_first", False):                                  # the stack's closing LayerNorm (textual_heads.py:192-193)
+            fn = head.transformer.norm
+            x = ops.layernorm_residual_fwd(x, None, fn.weight.detach(), fn.bias.detach(), fn.eps)[0]
         return ops.gemm_nt(x, self.Wout, bias=head.output.bias.detach(), out_f32=True)                  # (N, V) fp32 logits

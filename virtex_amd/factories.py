@@ -52,6 +52,7 @@ class VisualBackboneFactory(Factory):
 
 class TextualHeadFactory(Factory):
     PRODUCTS: Dict[str, Callable] = {
+        "transdec_prenorm": partial(textual_heads.TransformerDecoderTextualHead, norm_first=True),
         "transdec_postnorm": partial(textual_heads.TransformerDecoderTextualHead, norm_first=False),
     }
 

@@ -133,9 +133,7 @@ class TransformerDecoderTextualHead(TextualHead):
                  max_caption_length: int = 30, padding_idx: int = 0,
                  compute_dtype: torch.dtype = torch.bfloat16):
         super().__init__(visual_feature_size, vocab_size, hidden_size)
-        if norm_first:
-            raise NotImplementedError("pre-norm decoder (transdec_prenorm) is outside the bicaptioning "
-                                      "hot path; only the post-norm variant is implemented")
+        self.norm_first = bool(norm_first)
         if hidden_size % attention_heads != 0 or hidden_size // attention_heads != 64:
             raise ValueError("the fused attention kernel needs head_dim == 64 (H/A)")
         self.num_layers, self.attention_heads = num_layers, attention_heads
@@ -151,8 +149,9 @@ class TransformerDecoderTextualHead(TextualHead):
         self.transformer = nn.TransformerDecoder(
             nn.TransformerDecoderLayer(self.textual_feature_size, attention_heads,
                                        dim_feedforward=feedforward_size, dropout=dropout, activation="gelu",
-                                       batch_first=True, norm_first=False),
-            num_layers=num_layers, norm=None)
+                                       batch_first=True, norm_first=self.norm_first),
+            # a final LayerNorm closes a pre-norm stack (reference: textual_heads.py:192-193)
+            num_layers=num_layers, norm=nn.LayerNorm(self.hidden_size) if self.norm_first else None)
         self.apply(self._init_weights)
         self.output = nn.Linear(self.textual_feature_size, vocab_size)
         self.output.weight = self.embedding.words.weight
@@ -201,10 +200,14 @@ class TransformerDecoderTextualHead(TextualHead):
         for layer in self.transformer.layers:
             params += self._layer_params(layer)
         p = self.dropout if self.training else 0.0
+        fn = _DecoderFn
+        if self.norm_first:                       # "transdec_prenorm" (virtex/factories.py:358-366): the final LayerNorm's parameters last
+            fn = _PreNormDecoderFn
+            params += [self.transformer.norm.weight, self.transformer.norm.bias]
         if memory is not None:
             B, _, h, w = visual_features.shape
-            return _DecoderFn.apply(memory, x0, caption_lengths, self, p, (B, h * w), *params)
-        return _DecoderFn.apply(visual_features, x0, caption_lengths, self, p, None, *params)
+            return fn.apply(memory, x0, caption_lengths, self, p, (B, h * w), *params)
+        return fn.apply(visual_features, x0, caption_lengths, self, p, None, *params)
 
     def forward(self, visual_features, caption_tokens, caption_lengths):
         """Returns (B,T,V) fp32 logits, like the reference (textual_heads.py:216-278)."""
@@ -434,6 +437,178 @@ class _DecoderFn(torch.autograd.Function):
         dWv, rWv = sink(ctx.vis_owner[0])
         dbv, rbv = sink(ctx.vis_owner[1])
         if rWv is None and rbv is None:          # shared by both heads: both go through the one side stream, in order
+            with wgrad_stream(dev, dmem, ctx.mem_in):
+                ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
+                ops.colsum_acc(dmem, dbv)
+        else:
+            ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
+            ops.colsum_acc(dmem, dbv)
+        dvis = None
+        if ctx.needs_vis_grad:
+            Bv, C, h, w = ctx.vshape
+            dvis = ops.gemm_nt(dmem, ctx.Wv_t).view(Bv, h, w, C).permute(0, 3, 1, 2)
+        return (dvis, dx.view(B, T, H), None, None, None, None, rWv, rbv, *pgrads)
+
+
+class _PreNormDecoderFn(torch.autograd.Function):
+    """visual_projection + L PRE-norm decoder layers + the final LayerNorm (reference: textual_heads.py:181-194 with
+    norm_first=True; torch/nn/modules/transformer.py: x = x + sa(norm1(x)); x = x + mha(norm2(x), mem); x = x + ff(norm3(x))),
+    on the kernels of the post-norm path: plain LayerNorm = vtx_layernorm_residual_fwd without a sub-layer operand, the
+    residual join x + dropout(y) = the epilogue of the GEMM that produces y, its backward mask = vtx_dropout_bwd."""
+
+    @staticmethod
+    def forward(ctx, visual_features, x0, lengths, head, p, shared_memory, *params):
+        dt = head.compute_dtype
+        A, H = head.attention_heads, head.hidden_size
+        ctx.shared = shared_memory is not None
+        if ctx.shared:
+            B, S = shared_memory
+            mem, mem_in, Wv_t = visual_features, None, None
+            if mem.dtype != dt or not mem.is_contiguous():
+                mem = mem.to(dt).contiguous()
+        else:
+            mem_in, B, S = _nhwc_rows(visual_features, dt)
+            Wv, Wv_t = ops.prepped(params[0], dt)
+            Wv, Wv_t = Wv.view(H, -1), Wv_t.view(-1, H)
+            mem = ops.gemm_nt(mem_in, Wv, bias=params[1].detach())
+        T = x0.shape[1]
+        x = x0.reshape(B * T, H)
+        if x.dtype != dt or not x.is_contiguous():
+            x = x.to(dt).contiguous()
+        lengths = lengths.contiguous()
+        saved_layers = []
+        for li in range(head.num_layers):
+            raw = params[2 + 18 * li: 2 + 18 * (li + 1)]
+            P = [t.detach() for t in raw]
+            (Win, bin_, Wo, bo, g1, b1, Win2, bin2, Wo2, bo2, g2, b2, W1, bf1, W2, bf2, g3, b3) = P
+            seeds = [next_dropout_seed() for _ in range(7)]
+            cw = {}
+            for name, idx in (("Win", 0), ("Wo", 2), ("Win2", 6), ("Wo2", 8), ("W1", 12), ("W2", 14)):
+                w, wt = ops.prepped(raw[idx], dt)
+                cw[name] = (w.view(P[idx].shape), wt.view(P[idx].shape[1], P[idx].shape[0]))
+            # ---- masked self-attention on norm1(x), joined to x
+            h1, m1, r1 = ops.layernorm_residual_fwd(x, None, g1, b1, 1e-5)
+            qkv = ops.gemm_nt(h1, cw["Win"][0], bias=bin_)
+            o1 = ops.attention_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, A, T, T,
+                                   head.mask_future_positions, lengths, p, seeds[0])
+            x1 = ops.gemm_nt(o1, cw["Wo"][0], bias=bo, residual=x, p_drop=p, seed=seeds[1])
+            # ---- cross-attention over the visual grid on norm2(x1)
+            h2, m2, r2 = ops.layernorm_residual_fwd(x1, None, g2, b2, 1e-5)
+            q2 = ops.gemm_nt(h2, cw["Win2"][0][:H], bias=bin2[:H])
+            kv2 = ops.gemm_nt(mem, cw["Win2"][0][H:], bias=bin2[H:])
+            o2 = ops.attention_fwd(q2, kv2[:, :H], kv2[:, H:], B, A, T, S, False, None, p, seeds[2])
+            x2 = ops.gemm_nt(o2, cw["Wo2"][0], bias=bo2, residual=x1, p_drop=p, seed=seeds[3])
+            # ---- feed-forward on norm3(x2)
+            h3, m3, r3 = ops.layernorm_residual_fwd(x2, None, g3, b3, 1e-5)
+            a, hpre = ops.gemm_nt(h3, cw["W1"][0], bias=bf1, act=ops.ACT_GELU, want_preact=True, p_drop=p, seed=seeds[4])
+            x3 = ops.gemm_nt(a, cw["W2"][0], bias=bf2, residual=x2, p_drop=p, seed=seeds[5])
+            saved_layers.append(dict(x=x, h1=h1, m1=m1, r1=r1, qkv=qkv, o1=o1, x1=x1, h2=h2, m2=m2, r2=r2, q2=q2, kv2=kv2,
+                                     o2=o2, x2=x2, h3=h3, m3=m3, r3=r3, a=a, hpre=hpre, seeds=seeds, cw=cw, P=P))
+            x = x3
+        gf, bf = params[-2].detach(), params[-1].detach()
+        out, mf, rf = ops.layernorm_residual_fwd(x, None, gf, bf, 1e-5)
+        ctx.head, ctx.p, ctx.dims = head, p, (B, T, S, H, A)
+        ctx.layer_params = [list(params[2 + 18 * li: 2 + 18 * (li + 1)]) for li in range(head.num_layers)]
+        ctx.final = (x, mf, rf, gf, params[-2], params[-1])
+        ctx.saved_layers, ctx.mem, ctx.mem_in, ctx.Wv_t, ctx.lengths = saved_layers, mem, mem_in, Wv_t, lengths
+        ctx.vis_owner = (params[0], params[1])
+        ctx.vshape = visual_features.shape
+        ctx.needs_vis_grad = visual_features.requires_grad
+        return out.view(B, T, H)
+
+    @staticmethod
+    @traced_backward
+    def backward(ctx, dhid):
+        head, p = ctx.head, ctx.p
+        B, T, S, H, A = ctx.dims
+        dt = head.compute_dtype
+        dev = dhid.device
+        dout = dhid.reshape(B * T, H)
+        if dout.dtype != dt or not dout.is_contiguous():
+            dout = dout.to(dt).contiguous()
+
+        def linear_grads(inp, dy, wp, bp):
+            dW, rW = _sink_or_zeros(wp)
+            db, rb = _sink_or_zeros(bp)
+            if rW is None and rb is None:
+                with wgrad_stream(dev, inp, dy):
+                    ops.gemm_tn_acc(dy, inp, dW)
+                    ops.colsum_acc(dy, db)
+            else:
+                ops.gemm_tn_acc(dy, inp, dW)
+                ops.colsum_acc(dy, db)
+            return rW, rb
+
+        def norm_back(x_in, gamma, mean, rstd, dh, gp, bp):
+            """gradient of h = LayerNorm(x_in) wrt x_in; the norm's own parameter gradients accumulated"""
+            dg, rdg = _sink_or_zeros(gp)
+            db, rdb = _sink_or_zeros(bp)
+            dz, _ = ops.layernorm_residual_bwd(x_in, None, gamma, mean, rstd, dh, dg, db)
+            return dz, rdg, rdb
+
+        xL, mf, rf, gf, gfp, bfp = ctx.final
+        dx, rdgf, rdbf = norm_back(xL, gf, mf, rf, dout, gfp, bfp)
+        dmem = None
+        pgrads = []
+        for li in reversed(range(head.num_layers)):
+            L = ctx.saved_layers[li]
+            (Win, bin_, Wo, bo, g1, b1, Win2, bin2, Wo2, bo2, g2, b2, W1, bf1, W2, bf2, g3, b3) = L["P"]
+            PP = ctx.layer_params[li]
+            cw, seeds = L["cw"], L["seeds"]
+            # ---- x3 = x2 + dropout(linear2(dropout(gelu(linear1(norm3(x2))))))
+            dy3 = ops.dropout_bwd(dx, p, seeds[5])
+            dW2, dbf2 = linear_grads(L["a"], dy3, PP[14], PP[15])
+            da = ops.gemm_nt(dy3, cw["W2"][1])
+            dh = ops.gelu_bwd(L["hpre"], da, p, seeds[4])
+            dW1, dbf1 = linear_grads(L["h3"], dh, PP[12], PP[13])
+            dh3 = ops.gemm_nt(dh, cw["W1"][1])
+            dz3, rdg3, rdb3 = norm_back(L["x2"], g3, L["m3"], L["r3"], dh3, PP[16], PP[17])
+            dx2 = ops.add(dx, dz3)
+            # ---- x2 = x1 + dropout(out_proj(cross-attention(norm2(x1), mem)))
+            dy2 = ops.dropout_bwd(dx2, p, seeds[3])
+            dWo2, dbo2 = linear_grads(L["o2"], dy2, PP[8], PP[9])
+            do2 = ops.gemm_nt(dy2, cw["Wo2"][1])
+            dq2 = torch.empty_like(L["q2"])
+            dkv2 = torch.empty_like(L["kv2"])
+            ops.attention_bwd(L["q2"], L["kv2"][:, :H], L["kv2"][:, H:], do2, dq2, dkv2[:, :H], dkv2[:, H:],
+                              B, A, T, S, False, None, p, seeds[2])
+            dWin2, rWin2 = _sink_or_zeros(PP[6])
+            dbin2, rbin2 = _sink_or_zeros(PP[7])
+
+            def cross_in_proj_grads():
+                ops.gemm_tn_acc(dq2, L["h2"], dWin2[:H])
+                ops.gemm_tn_acc(dkv2, ctx.mem, dWin2[H:])
+                ops.colsum_acc(dq2, dbin2[:H])
+                ops.colsum_acc(dkv2, dbin2[H:])
+            if rWin2 is None and rbin2 is None:
+                with wgrad_stream(dev, dq2, dkv2, L["h2"], ctx.mem):
+                    cross_in_proj_grads()
+            else:
+                cross_in_proj_grads()
+            dh2 = ops.gemm_nt(dq2, _wt_cols(cw["Win2"][1], 0, H))
+            dmem = ops.gemm_nt(dkv2, _wt_cols(cw["Win2"][1], H, 3 * H), residual=dmem)
+            dz2, rdg2, rdb2 = norm_back(L["x1"], g2, L["m2"], L["r2"], dh2, PP[10], PP[11])
+            dx1 = ops.add(dx2, dz2)
+            # ---- x1 = x + dropout(out_proj(self-attention(norm1(x))))
+            dy1 = ops.dropout_bwd(dx1, p, seeds[1])
+            dWo, dbo = linear_grads(L["o1"], dy1, PP[2], PP[3])
+            do1 = ops.gemm_nt(dy1, cw["Wo"][1])
+            qkv = L["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], do1, dqkv[:, :H], dqkv[:, H:2 * H],
+                              dqkv[:, 2 * H:], B, A, T, T, head.mask_future_positions, ctx.lengths, p, seeds[0])
+            dWin, dbin = linear_grads(L["h1"], dqkv, PP[0], PP[1])
+            dh1 = ops.gemm_nt(dqkv, cw["Win"][1])
+            dz1, rdg1, rdb1 = norm_back(L["x"], g1, L["m1"], L["r1"], dh1, PP[4], PP[5])
+            dx = ops.add(dx1, dz1)
+            pgrads = [dWin, dbin, dWo, dbo, rdg1, rdb1, rWin2, rbin2, dWo2, dbo2, rdg2, rdb2, dW1, dbf1, dW2, dbf2,
+                      rdg3, rdb3] + pgrads
+        pgrads += [rdgf, rdbf]
+        if ctx.shared:
+            return (dmem, dx.view(B, T, H), None, None, None, None, None, None, *pgrads)
+        dWv, rWv = _sink_or_zeros(ctx.vis_owner[0])
+        dbv, rbv = _sink_or_zeros(ctx.vis_owner[1])
+        if rWv is None and rbv is None:
             with wgrad_stream(dev, dmem, ctx.mem_in):
                 ops.gemm_tn_acc(dmem, ctx.mem_in, dWv)
                 ops.colsum_acc(dmem, dbv)

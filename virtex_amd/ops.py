@@ -780,6 +780,17 @@ def gelu_bwd(h, da, p_drop=0.0, seed=0):
     return dh
 
 
+def dropout_bwd(dx, p_drop, seed):
+    """dy = mask(seed) * dx / (1 - p): the gradient through x + dropout(y) (pre-norm decoder sub-layers); p = 0: dx itself."""
+    if p_drop <= 0.0:
+        return dx
+    _chk(dx, "dx")
+    dy = torch.empty_like(dx)
+    call("vtx_dropout_bwd", c_int(dtype_code(dx.dtype)), ptr(dx), ptr(dy), c_long(dx.numel()), c_float(p_drop), c_u64(seed),
+         stream_ptr(dx))
+    return dy
+
+
 # ---------------------------------------------------------------------------------------
 def sumsq(x, partials, out):
     call("vtx_sumsq", ptr(x), c_long(x.numel()), ptr(partials), ptr(out), stream_ptr(x))
