@@ -140,6 +140,32 @@ vd.broadcast_parameters(model)
 buckets = vd.GradientBuckets(model, bucket_mb=2.0, payload=os.environ["VTX_PAYLOAD"])
 opt = FusedPretrainOptimizer(model, buckets, total_steps=50, warmup_steps=6, start_step=2, lookahead_k=3)
 batch = lambda s: {k: v.to(dev) for k, v in synth.synthetic_batch(seed=s, **bk).items()}
+if os.environ.get("VTX_SABOTAGE_RANK") == str(rank):
+    # this rank's replayed step "differs" from its eager step: both ranks must give up the recording TOGETHER
+    from virtex_amd import replay as _rp
+    _orig_run = _rp._run
+    def _bad_run(rec):
+        _orig_run(rec)
+        buckets.flat.add_(1.0)
+    _rp._run = _bad_run
+if "VTX_SABOTAGE_RANK" in os.environ:
+    def eager():
+        buckets.zero(); buckets.begin()
+        out = model(batch(90 + rank)); out["loss"].backward()
+        opt.step(grad_scale=buckets.finish())
+        return out["loss"].item()
+    msg = None
+    try:
+        StepReplay(model, buckets, opt, batch(70 + rank), warmup=1, validate=True)
+    except RuntimeError as e:
+        msg = str(e)
+    opt.disable_device_schedule()
+    loss = eager()                      # the fallback of bench.py: an eager step on EVERY rank; a lone rank here would hang
+    samp = {n: p.detach().flatten()[:: max(1, p.numel() // 32)][:32].tolist() for n, p in model.named_parameters()}
+    with open(os.environ["VTX_OUT"] + f".{rank}", "w") as f:
+        json.dump({"rank": rank, "error": msg, "loss": loss, "params": samp}, f)
+    dist.barrier(); dist.destroy_process_group()
+    sys.exit(0)
 try:
     # construction records one step INCLUDING the bucket all-reduces and validates the recording against an eager step
     # (both under the world-2 exchange) on a second batch; then three replayed steps on per-rank batches
@@ -182,4 +208,30 @@ def test_two_ranks_launch_replay_carries_the_gradient_exchange(tmp_path, payload
         assert o["step"] == outs[0]["step"]
     assert outs[0]["losses"] != outs[1]["losses"]                                 # different batches per rank ...
     for n, v in outs[0]["params"].items():                                        # ... the same parameters after the exchange
+        assert v == outs[1]["params"][n], n
+
+
+@pytest.mark.emu
+def test_two_ranks_give_up_a_recording_together(tmp_path):
+    """A recording that fails its validation on ONE rank is refused on every rank (the verdict is reduced over the ranks): the
+    ranks then take the eager step together -- a rank deciding alone would issue a different number of gradient exchanges than
+    its peer and the job would hang (bench.py's fallback at N > 1)."""
+    port_no = _free_port()
+    out_base = str(tmp_path / "rank")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_no), RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r),
+                   VTX_ROOT=ROOT, VTX_KW=json.dumps(KW), VTX_BK=json.dumps(BK), VTX_OUT=out_base, OMP_NUM_THREADS="2",
+                   VTX_PAYLOAD="fp32", VTX_SABOTAGE_RANK="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", REPLAY_WORKER], env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for r, p in enumerate(procs):
+        _, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-3000:]
+        with open(f"{out_base}.{r}") as f:
+            outs.append(json.load(f))
+    outs.sort(key=lambda o: o["rank"])
+    assert "on another rank" in outs[0]["error"]
+    assert "gradients differ" in outs[1]["error"]
+    for n, v in outs[0]["params"].items():                                        # the eager step after the refusal exchanged gradients
         assert v == outs[1]["params"][n], n

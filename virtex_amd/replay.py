@@ -428,5 +428,16 @@ class StepReplay:
         for k, v in self.static.items():
             v.copy_(restored_batch[k])
         restore()
+        # Data parallel: every rank validated on its own batch, and every rank must take the same decision -- a rank that alone
+        # falls back to the eager step issues a different number of gradient exchanges than its peers and the job hangs.  The
+        # verdict is therefore the minimum over the ranks (one more collective, at the same point of every rank's sequence).
+        peers_ok = True
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            dev = next(self.model.parameters()).device
+            flag = torch.tensor([0.0 if bad else 1.0], device=dev if dev.type == "cuda" else "cpu")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            peers_ok = bool(flag.item() > 0.5)
         if bad:
             raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step: " + "; ".join(bad[:4]))
+        if not peers_ok:
+            raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step on another rank")
