@@ -90,22 +90,38 @@ PEAK_HBM_TBS = 8.0                                         # MI355X HBM3E (MI355
 TRAFFIC_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic_table.json")
 
 
-def load_traffic_table():
+# the workloads a table exists for: the default one and BASELINE configs 4 / 5 (one table per workload: the launches of a class
+# differ in shape from workload to workload, so their bytes per launch do too)
+TABLED_WORKLOADS = {
+    (256, "bf16", "transdec_postnorm::L1_H1024_A16_F4096", "torchvision::resnet50", 1, 224, 10000): "",
+    (128, "bf16", "transdec_postnorm::L4_H1024_A16_F4096", "torchvision::resnet50", 1, 224, 10000): "config4",
+    (64, "bf16", "transdec_postnorm::L1_H2048_A32_F8192", "torchvision::resnet101", 1, 224, 10000): "config5",
+}
+
+
+def traffic_table_path(tag):
+    """'' (the default workload) -> profiles/traffic_table.json; 'config4' -> profiles/traffic_table_config4.json"""
+    return TRAFFIC_TABLE if not tag else TRAFFIC_TABLE[:-len(".json")] + f"_{tag}.json"
+
+
+def load_traffic_table(path=None):
     """(per-launch bytes by class name, source string) or ({}, None) when the table is missing or stale."""
+    path = path or TRAFFIC_TABLE
+    rel = os.path.join("profiles", os.path.basename(path))
     try:
-        with open(TRAFFIC_TABLE) as fh:
+        with open(path) as fh:
             t = json.load(fh)
     except (OSError, ValueError):
-        print(f"bench.py: ERROR -- {TRAFFIC_TABLE} missing or unreadable: roofline.traffic = null (regenerate with tools/round_end.sh)", file=sys.stderr)
+        print(f"bench.py: ERROR -- {path} missing or unreadable: roofline.traffic = null (regenerate with tools/round_end.sh)", file=sys.stderr)
         return {}, None
     from virtex_amd.build import csrc_hash
     if t.get("csrc_sha256") != csrc_hash():
-        print("bench.py: ERROR -- profiles/traffic_table.json was measured on different kernel sources (sha256 mismatch): "
+        print(f"bench.py: ERROR -- {rel} was measured on different kernel sources (sha256 mismatch): "
               "roofline.traffic = null until tools/round_end.sh regenerates it", file=sys.stderr)
         return {}, None
     table = dict(t.get("per_launch_bytes", {}))
     table["__per_kernel__"] = t.get("per_kernel", {})
-    return table, f"profiles/traffic_table.json ({t.get('source')}; {t.get('rule')})"
+    return table, f"{rel} ({t.get('source')}; {t.get('rule')})"
 
 
 def lookup_traffic(table, name, n_classes, launches_per_step):
@@ -179,7 +195,7 @@ def merge_classes(recs):
     return out
 
 
-def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1, focused_steps=None):
+def step_roofline(recs, dtype, workload_tag, focused=None, survey_steps=1, focused_steps=None):
     """Roofline of the step's dominant kernel, measured LIVE: HIP events attached to every launch of the step function
     the timed region runs (`recs` = ops.profile_stop() of `survey_steps` fully timed steps).  The dominant kernel is the
     one with the largest summed time; achieved = its algorithmic FLOPs (or bytes) / its summed launch time; the binding
@@ -197,11 +213,12 @@ def step_roofline(recs, dtype, default_workload, focused=None, survey_steps=1, f
     tbs = dom["bytes"] / dom["seconds"] / 1e12
     f_mfma, f_hbm = tf / peak_tf, tbs / PEAK_HBM_TBS
     bound = "mfma" if f_mfma >= f_hbm else "hbm"
-    table, table_source = load_traffic_table() if default_workload else ({}, None)
+    default_workload = workload_tag is not None          # a workload with a PMC table of its own (TABLED_WORKLOADS)
+    table, table_source = load_traffic_table(traffic_table_path(workload_tag)) if default_workload else ({}, None)
     per_step = dom["launches"] / focused_steps if (focused is not None and focused_steps) else None
     traffic, instantiation = lookup_traffic(table, dom["name"], len(dom["cls"]) if focused is not None else 1, per_step)
     if default_workload and table_source and traffic is None:
-        print(f"bench.py: ERROR -- profiles/traffic_table.json has no entry for the dominant kernel {dom['name']!r}; "
+        print(f"bench.py: ERROR -- {os.path.basename(traffic_table_path(workload_tag))} has no entry for the dominant kernel {dom['name']!r}; "
               "reporting traffic = null", file=sys.stderr)
     out = {"bound": bound, "kernel": instantiation or dom["name"],
            "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": peak_tf if bound == "mfma" else PEAK_HBM_TBS * 1e3,
@@ -539,8 +556,7 @@ def main(argv=None, device=None, backend=None):
             rec["step_mfma"] = {"gflop_per_image": gflop, "achieved_tflops": round(tf, 1),
                                 "peak_tflops": peak * world, "frac": round(tf / (peak * world), 4)}
         if not a.no_roofline:
-            default_workload = (a.batch, a.dtype, a.textual, a.visual, world, a.image_size, a.vocab_size) == (
-                256, "bf16", "transdec_postnorm::L1_H1024_A16_F4096", "torchvision::resnet50", 1, 224, 10000)
+            default_workload = TABLED_WORKLOADS.get((a.batch, a.dtype, a.textual, a.visual, world, a.image_size, a.vocab_size))
             if live_recs is not None:
                 rec["roofline"] = step_roofline(live_recs, a.dtype, default_workload)
                 if rec["roofline"]:

@@ -88,6 +88,13 @@ def test_traffic_table_is_keyed_to_the_kernel_sources(tmp_path, monkeypatch, cap
     p.write_text(json.dumps({"csrc_sha256": csrc_hash(), "per_launch_bytes": {"k": 1.0}, "source": "s", "rule": "r"}))
     table, src = bench.load_traffic_table()
     assert table["k"] == 1.0 and "traffic_table.json" in src
+    # BASELINE configs 4 / 5 read tables of their own (other shapes, other bytes per launch); any other workload has none
+    assert bench.traffic_table_path("") == str(p) and bench.traffic_table_path("config4") == str(tmp_path / "traffic_table_config4.json")
+    assert bench.TABLED_WORKLOADS[(128, "bf16", "transdec_postnorm::L4_H1024_A16_F4096", "torchvision::resnet50", 1, 224, 10000)] == "config4"
+    assert bench.TABLED_WORKLOADS.get((32, "bf16", "transdec_postnorm::L1_H1024_A16_F4096", "torchvision::resnet50", 1, 224, 10000)) is None
+    (tmp_path / "traffic_table_config4.json").write_text(json.dumps({"csrc_sha256": csrc_hash(), "per_launch_bytes": {"k": 2.0}, "source": "s", "rule": "r"}))
+    table4, src4 = bench.load_traffic_table(bench.traffic_table_path("config4"))
+    assert table4["k"] == 2.0 and "traffic_table_config4.json" in src4
     # a launch family of several instantiations: the focused pass of bench.py times ONE of them, found by launches per step
     p.write_text(json.dumps({"csrc_sha256": csrc_hash(), "per_launch_bytes": {"fam": 300.0, "solo": 7.0}, "source": "s", "rule": "r",
                              "per_kernel": {"fam": {"kern<2>": {"launches_per_step": 47.0, "bytes": 229.0},

@@ -27,6 +27,20 @@ grep -h '^{' gpurun_out/prof_ks.log | tail -1 > gpurun_out/bench_serial.json
 # BASELINE configs 4 and 5 (host-bound at these batch sizes): bench line with the roofline leg + kernel trace each
 C4="--textual transdec_postnorm::L4_H1024_A16_F4096 --batch 128"
 C5="--visual torchvision::resnet101 --textual transdec_postnorm::L1_H2048_A32_F8192 --batch 64"
+# their own PMC tables (bytes per launch depend on the workload's shapes): roofline.traffic of these two lines
+for C in 4 5; do
+  [ -n "$SKIP_PMC" ] && break
+  if [ $C = 4 ]; then CF="$C4"; else CF="$C5"; fi
+  cd /tmp
+  rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch$C -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 $CF > $R/gpurun_out/prof_fetch$C.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/prof_write$C -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 $CF > $R/gpurun_out/prof_write$C.log 2>&1
+  cd $R
+  python tools/pmc_dump.py $(find gpurun_out/prof_fetch$C -name "*.db" | head -1) "" > gpurun_out/pmc_fetch_config$C.txt 2>&1
+  python tools/pmc_dump.py $(find gpurun_out/prof_write$C -name "*.db" | head -1) "" > gpurun_out/pmc_write_config$C.txt 2>&1
+  python tools/pmc_traffic.py gpurun_out/pmc_fetch_config$C.txt gpurun_out/pmc_write_config$C.txt --json gpurun_out/traffic_table_config$C.json > gpurun_out/pmc_traffic_config$C.txt 2>&1
+  cp gpurun_out/traffic_table_config$C.json profiles/traffic_table_config$C.json
+  rm -rf gpurun_out/prof_fetch$C gpurun_out/prof_write$C
+done
 python bench.py --no-cpu-baseline --no-fidelity $C4 > gpurun_out/bench_config4.json 2> gpurun_out/bench_config4.err
 python bench.py --no-cpu-baseline --no-fidelity $C5 > gpurun_out/bench_config5.json 2> gpurun_out/bench_config5.err
 cd /tmp
