@@ -22,6 +22,8 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
   "fidelity"     : the bf16 step against the fp32 step (the mode pinned to the oracle) on the timed batch: loss and
                    per-tensor gradient distance / cosine (virtex_amd/fidelity.py)
   "cpu_baseline" : the oracle port of the reference step timed on this box's host cores (B = 16, and config 1's B = 2).
+  "stock_pytorch_baseline" (--stock-pytorch-baseline only): the same port on THIS GPU through stock PyTorch-ROCm (MIOpen /
+                   hipBLASLt / ATen, autocast bf16) -- what the reference's own code reaches on the part.
 """
 import argparse
 import json
@@ -50,6 +52,9 @@ def parse(argv=None):
     ap.add_argument("--visual", default="torchvision::resnet50")
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stock-pytorch-baseline", action="store_true",
+                    help="also time the reference's module graph (the oracle port) on this GPU through stock PyTorch-ROCm "
+                         "(MIOpen / hipBLASLt, autocast bf16): `stock_pytorch_baseline` in the record")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fidelity", action="store_true")
     ap.add_argument("--bn-fusion", default=None, choices=["none", "bwd", "fwd", "both"],
@@ -322,6 +327,49 @@ def cpu_baseline(batch, steps, budget_s=40.0):
     return out
 
 
+def stock_pytorch_baseline(batch, dev, steps=10, warmup=3):
+    """The reference step as the reference itself would run on this GPU: the oracle port (the reference's module graph built
+    from torch.nn, oracle/bicaptioning.py) through stock PyTorch-ROCm -- MIOpen convolutions / BatchNorm, hipBLASLt GEMMs, ATen
+    attention -- under `torch.autocast(bfloat16)` (the reference's AMP loop, scripts/pretrain_virtex.py:150-161; bf16 needs no
+    GradScaler), clip + SGD + Lookahead with the reference's 202 parameter groups; in the reference's own memory format (NCHW)
+    and in channels_last, `value` = the faster of the two.  SURVEY.md 8(d) "secondary comparison": a reported baseline like
+    `cpu_baseline` (and like it the only other place the oracle is executed), never the measured product.  Off by default
+    (--stock-pytorch-baseline): MIOpen's solver search makes the first steps slow."""
+    from oracle import bicaptioning as port, synth
+
+    def run(fmt):
+        torch.manual_seed(0)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        model = port.build_model(dropout=0.1).to(dev).to(memory_format=fmt).train()
+        inner = model.forward
+
+        def amp_forward(b):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return inner(b)
+        model.forward = amp_forward
+        step = port.TrainStep(model, start_step=100)
+        b = {k: v.to(dev) for k, v in synth.synthetic_batch(batch, seed=0).items()}
+        b["image"] = b["image"].contiguous(memory_format=fmt)
+        t_w = time.time()
+        for _ in range(warmup):
+            step(b)
+        torch.cuda.synchronize()
+        t_w = time.time() - t_w
+        t0 = time.time()
+        for _ in range(steps):
+            loss = step(b)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        return {"value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "warmup_s": round(t_w, 1),
+                "final_loss": round(float(loss), 4), "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
+    runs = {"nchw (the reference's layout)": run(torch.contiguous_format), "channels_last": run(torch.channels_last)}
+    best = max(runs, key=lambda k: runs[k]["value"])
+    return {"value": runs[best]["value"], "unit": "images/sec", "ms_per_step": runs[best]["ms_per_step"], "layout": best, "runs": runs,
+            "what": f"oracle port on cuda through stock PyTorch-ROCm {torch.__version__} (MIOpen / hipBLASLt / ATen), autocast bf16, "
+                    f"B={batch}, {steps} steps after {warmup} warm-up steps (MIOpen's solver search is in warmup_s)"}
+
+
 def set_streams(concurrent: bool):
     """Turn the side streams of the step on / off at run time (virtex_amd/streams.py, models.HEAD_STREAMS)."""
     from virtex_amd import models, streams
@@ -577,6 +625,13 @@ def main(argv=None, device=None, backend=None):
                                       "forward_statistics_in_conv_epilogue": bool(vbm.FUSE_BN_STATS and a.dtype == "bf16")}
         if world == 1 and not a.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(a.cpu_batch, a.cpu_steps)
+        if world == 1 and a.stock_pytorch_baseline and dev.type == "cuda":
+            del model, buckets, opt, batches                     # the product's memory back before the baseline allocates its own
+            torch.cuda.empty_cache()
+            try:
+                rec["stock_pytorch_baseline"] = stock_pytorch_baseline(a.batch, dev)
+            except Exception as e:                               # (an out-of-memory or MIOpen failure of the BASELINE is not the product's)
+                rec["stock_pytorch_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(rec), flush=True)
     vd.synchronize()
 
