@@ -327,7 +327,8 @@ def cpu_baseline(batch, steps, budget_s=40.0):
     return out
 
 
-def stock_pytorch_baseline(batch, dev, steps=10, warmup=3):
+def stock_pytorch_baseline(batch, dev, steps=10, warmup=3, visual="torchvision::resnet50",
+                           textual="transdec_postnorm::L1_H1024_A16_F4096", vocab_size=10000):
     """The reference step as the reference itself would run on this GPU: the oracle port (the reference's module graph built
     from torch.nn, oracle/bicaptioning.py) through stock PyTorch-ROCm -- MIOpen convolutions / BatchNorm, hipBLASLt GEMMs, ATen
     attention -- under `torch.autocast(bfloat16)` (the reference's AMP loop, scripts/pretrain_virtex.py:150-161; bf16 needs no
@@ -341,7 +342,7 @@ def stock_pytorch_baseline(batch, dev, steps=10, warmup=3):
         torch.manual_seed(0)
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats(dev)
-        model = port.build_model(dropout=0.1).to(dev).to(memory_format=fmt).train()
+        model = port.build_model(visual=visual, textual=textual, vocab_size=vocab_size, dropout=0.1).to(dev).to(memory_format=fmt).train()
         inner = model.forward
 
         def amp_forward(b):
@@ -349,7 +350,7 @@ def stock_pytorch_baseline(batch, dev, steps=10, warmup=3):
                 return inner(b)
         model.forward = amp_forward
         step = port.TrainStep(model, start_step=100)
-        b = {k: v.to(dev) for k, v in synth.synthetic_batch(batch, seed=0).items()}
+        b = {k: v.to(dev) for k, v in synth.synthetic_batch(batch, seed=0, vocab_size=vocab_size).items()}
         b["image"] = b["image"].contiguous(memory_format=fmt)
         t_w = time.time()
         for _ in range(warmup):
@@ -629,7 +630,8 @@ def main(argv=None, device=None, backend=None):
             del model, buckets, opt, batches                     # the product's memory back before the baseline allocates its own
             torch.cuda.empty_cache()
             try:
-                rec["stock_pytorch_baseline"] = stock_pytorch_baseline(a.batch, dev)
+                rec["stock_pytorch_baseline"] = stock_pytorch_baseline(a.batch, dev, visual=a.visual, textual=a.textual,
+                                                                        vocab_size=a.vocab_size)
             except Exception as e:                               # (an out-of-memory or MIOpen failure of the BASELINE is not the product's)
                 rec["stock_pytorch_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(rec), flush=True)
