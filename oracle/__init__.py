@@ -2,8 +2,10 @@
 
 TEST INFRASTRUCTURE ONLY.  Nothing under ``virtex_amd/`` may import, call or link
 anything in this package: only ``tests/``, ``__graft_entry__.smoke()`` and the
-``cpu_baseline`` leg of ``bench.py`` do, and only as the checker / the reported CPU
-baseline -- never as the thing that is measured or shipped.
+baseline legs of ``bench.py`` do (``cpu_baseline``: this port on the host cores; and,
+only on request with ``--stock-pytorch-baseline``, the same port on the GPU through stock
+PyTorch-ROCm = what the reference's own code reaches on the part), and only as the
+checker / the reported baseline -- never as the thing that is measured or shipped.
 
 What it is
 ----------
