@@ -5,6 +5,7 @@ set -x
 R=$GRAFT_REPO_ROOT
 cd $R
 python -m pytest tests -q -m gpu 2>&1 | tail -3 > gpurun_out/gpu_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.txt 2>&1; echo "rc=$?" >> gpurun_out/smoke.txt
 cd /tmp && export TMPDIR=/tmp
 # PMC passes FIRST: the default bench line below then reports roofline.traffic from a table measured on these very sources
 [ -n "$SKIP_PMC" ] || rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/prof_fetch -- python $R/bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 2 --warmup 1 > $R/gpurun_out/prof_fetch.log 2>&1
