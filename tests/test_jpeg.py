@@ -171,3 +171,70 @@ def test_batch_decode_on_host_threads_equals_single_decodes(backend):
     assert len(outs) == len(blobs)
     for i, o in enumerate(outs):
         assert np.array_equal(o.cpu().numpy(), z[f"rgb_{i}"]), i
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_oversubscribed_huffman_table_is_refused(backend):
+    """A DHT whose code lengths over-subscribe the code space (three codes of length 1) used to index past the 9-bit lookahead
+    table while it was being built (found by tests/fuzz/jpeg_host_fuzz.cpp under AddressSanitizer): refused now."""
+    pytest.importorskip("PIL")
+    from virtex_amd import _lib, jpeg as vj
+    dev = select(backend)
+    good = bytearray(_encode(_image(16, 16, np.random.default_rng(5)), quality=75))
+    i = good.find(b"\xff\xc4")
+    assert i > 0
+    good[i + 5] = 3                                       # bits[0]: three codes of length 1
+    with pytest.raises(_lib.VtxError, match="Huffman|DHT"):
+        vj.decode_jpeg(bytes(good), dev)
+    # a frame header asking for more than 2^28 pixels is refused before anything is allocated
+    big = bytearray(_encode(_image(16, 16, np.random.default_rng(5)), quality=75))
+    j = big.find(b"\xff\xc0")
+    big[j + 5:j + 9] = bytes([0xFF, 0xFF, 0xFF, 0xFF])   # 65535 x 65535
+    with pytest.raises(_lib.VtxError, match="pixel"):
+        vj.jpeg_info(bytes(big))
+
+
+def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path):
+    """The host half of the decoder (markers, tables, Huffman scan: the part that reads bytes from files) compiled with
+    -fsanitize=address,undefined and driven with 40 000 mutated streams (byte flips, truncations, planted markers, insertions;
+    baseline, optimised-table, grey and restart-interval seeds): every stream is decoded or refused, nothing is read or written
+    out of bounds."""
+    pytest.importorskip("PIL")
+    import shutil
+    import subprocess
+    from PIL import Image
+    from virtex_amd import build as vb
+    select("emu")                                         # the emulator objects the harness links against are built
+    clang = vb.HOST_CLANG
+    if not os.path.exists(clang):
+        pytest.skip("no host clang")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    obj = os.path.join(vb.EMU_DIR, "obj")
+    flags = [f for f in vb.EMU_FLAGS if f != "-O2"] + ["-O1", "-I", os.path.join(root, "include"), "-fsanitize=address,undefined",
+                                                        "-fno-omit-frame-pointer"]
+    jo, ho, exe = str(tmp_path / "jpeg_asan.o"), str(tmp_path / "harness.o"), str(tmp_path / "harness")
+    r = subprocess.run([clang] + flags + ["-c", os.path.join(root, "virtex_amd", "csrc", "jpeg.hip"), "-o", jo], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("sanitizer runtime not available")
+    assert r.returncode == 0, r.stderr[-2000:]
+    subprocess.run([clang, "-x", "c++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-c",
+                    os.path.join(root, "tests", "fuzz", "jpeg_host_fuzz.cpp"), "-o", ho], check=True)
+    r = subprocess.run([clang, "-fsanitize=address,undefined", "-pthread", ho, jo, os.path.join(obj, "core.o"),
+                        os.path.join(obj, "hipemu_rt.o"), "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("cannot link the sanitizer runtime: " + r.stderr[-300:])
+    rng = np.random.default_rng(0)
+    seeds = []
+    for name, (h, w, kw) in {"a": (16, 16, dict(quality=75, subsampling=0)), "b": (37, 53, dict(quality=75, subsampling=2)),
+                             "c": (64, 48, dict(quality=90, subsampling=1)), "d": (24, 40, dict(quality=60, subsampling=2, optimize=True)),
+                             "f": (40, 56, dict(quality=85, subsampling=2, restart_marker_blocks=2))}.items():
+        path = str(tmp_path / (name + ".jpg"))
+        Image.fromarray(_image(h, w, rng)).save(path, "JPEG", **kw)
+        seeds.append(path)
+    grey = str(tmp_path / "e.jpg")
+    Image.fromarray(_image(20, 28, rng)[:, :, 0].copy()).save(grey, "JPEG", quality=80)
+    seeds.append(grey)
+    r = subprocess.run([exe, "40000"] + seeds, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stderr[-3000:], r.stdout[-300:])
+    decoded, refused = (int(x) for x in r.stdout.split()[1::2])
+    assert decoded > 5000 and refused > 5000              # the mutations reach both the scan and the refusal paths

@@ -46,6 +46,7 @@ bool build_huff(Huff& h, const unsigned char* bits /*[16]*/, const unsigned char
         h.valptr[l] = k - code;
         for (int i = 0; i < bits[l - 1]; ++i, ++k, ++code) {
             if (k >= nvals || k >= 256) return false;
+            if (code >= (1 << l)) return false;          // over-subscribed code lengths (a corrupt table): no such code of length l
             if (l <= 9) {
                 const int first = code << (9 - l);
                 for (int f = 0; f < (1 << (9 - l)); ++f) h.look[first + f] = (unsigned short)((vals[k] << 4) | l);
@@ -211,6 +212,9 @@ int parse(const unsigned char* d, long n, Parsed& P) {
                         P.c[2].h == 1 && P.c[2].v == 1 && !(P.c[0].h == 1 && P.c[0].v == 2);
         if (!ok) { vtx_set_error("jpeg: sampling %dx%d,%dx%d,%dx%d is not taken (4:4:4, 4:2:2, 4:2:0)", P.c[0].h, P.c[0].v, P.c[1].h, P.c[1].v, P.c[2].h, P.c[2].v); return VTX_ERR_SHAPE; }
     }
+    // info[] carries block and byte counts as int: 2^28 pixels (16 384 x 16 384) is the largest frame taken (cv2.imread's own
+    // limit, CV_IO_MAX_IMAGE_PIXELS, is 2^30); a corrupt header must not turn into a multi-gigabyte allocation request either
+    if ((long)P.W * P.H > (1l << 28)) { vtx_set_error("jpeg: %d x %d pixels exceed the 2^28-pixel limit", P.W, P.H); return VTX_ERR_SHAPE; }
     P.mcux = vtx_cdiv(P.W, 8 * P.hmax); P.mcuy = vtx_cdiv(P.H, 8 * P.vmax);
     long off = 0;
     for (int k = 0; k < P.ncomp; ++k) {
