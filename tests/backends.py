@@ -17,7 +17,10 @@ BACKENDS = [pytest.param("emu", marks=pytest.mark.emu), pytest.param("gpu", mark
 def select(backend: str) -> torch.device:
     if backend == "emu":
         path = build.EMU_LIB_PATH
-        if not os.path.exists(path) or os.environ.get("VTX_REBUILD_EMU", "1") == "1":
+        if os.environ.get("VTX_EMU_LIB"):
+            # an instrumented build of the emulator library (AddressSanitizer: tools/build_emu_asan.sh), used as it is
+            path = os.environ["VTX_EMU_LIB"]
+        elif not os.path.exists(path) or os.environ.get("VTX_REBUILD_EMU", "1") == "1":
             path = build.build_emu()
         _lib.use_library(path)
         assert _lib.is_emulator()
