@@ -219,6 +219,9 @@ def test_device_side_schedule_equals_host_side_schedule(backend):
     oa = FusedPretrainOptimizer(ma, ba, total_steps=50, warmup_steps=10, start_step=3)
     ob = FusedPretrainOptimizer(mb, bb, total_steps=50, warmup_steps=10, start_step=3)
     ob.enable_device_schedule()
+    # the dropout epoch is ONE word per device, shared by every optimizer that is on the device-side schedule (a recording of an
+    # earlier test that is still alive holds it too): what this optimizer adds to it is asserted, not its absolute value
+    epoch0 = int(ob.dev["epoch"].item())
     try:
         _steps(ma, oa, ba, dev, range(12))
         _steps(mb, ob, bb, dev, range(12))
@@ -226,7 +229,7 @@ def test_device_side_schedule_equals_host_side_schedule(backend):
             assert torch.allclose(p.detach().cpu(), q.detach().cpu(), rtol=1e-6, atol=1e-7), n
         ob.sync_host()
         assert ob.step_idx == oa.step_idx == 15 and ob.kc == oa.kc
-        assert int(ob.dev["epoch"].item()) == 12                  # the dropout epoch advanced once per step
+        assert int(ob.dev["epoch"].item()) - epoch0 == 12         # the dropout epoch advanced once per step
         sd = ob.state_dict()
         assert sd["virtex_amd"] == oa.state_dict()["virtex_amd"]
     finally:

@@ -52,9 +52,9 @@ python tools/rocpd_stats.py $(find gpurun_out/prof_c4 -name "*.db" | head -1) 40
 python tools/rocpd_stats.py $(find gpurun_out/prof_c5 -name "*.db" | head -1) 40 > gpurun_out/kernel_stats_serial_config5.txt
 find gpurun_out -name "*.db" -delete; rm -rf gpurun_out/prof_c4 gpurun_out/prof_c5 gpurun_out/prof_kt gpurun_out/prof_ks gpurun_out/prof_fetch gpurun_out/prof_write
 # round 5: the reference's module graph through stock PyTorch-ROCm (MIOpen / hipBLASLt) on this GPU, next to the product's step
-timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 > gpurun_out/bench_stock_pytorch_baseline.json 2> gpurun_out/bench_stock_pytorch_baseline.err
-timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 $C4 > gpurun_out/bench_stock_pytorch_baseline_config4.json 2> gpurun_out/bench_stock_pytorch_baseline_config4.err
-timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 $C5 > gpurun_out/bench_stock_pytorch_baseline_config5.json 2> gpurun_out/bench_stock_pytorch_baseline_config5.err
+[ -n "$SKIP_STOCK" ] || timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 > gpurun_out/bench_stock_pytorch_baseline.json 2> gpurun_out/bench_stock_pytorch_baseline.err
+[ -n "$SKIP_STOCK" ] || timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 $C4 > gpurun_out/bench_stock_pytorch_baseline_config4.json 2> gpurun_out/bench_stock_pytorch_baseline_config4.err
+[ -n "$SKIP_STOCK" ] || timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 $C5 > gpurun_out/bench_stock_pytorch_baseline_config5.json 2> gpurun_out/bench_stock_pytorch_baseline_config5.err
 # round 5: the pre-norm decoder product on the default shape (same step, the other TextualHeadFactory key)
 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --textual transdec_prenorm::L1_H1024_A16_F4096 > gpurun_out/bench_prenorm.json 2> gpurun_out/bench_prenorm.err
 # round 5: the fused conv3 backward against the launches it replaces; JPEG decode throughput of the input pipeline
