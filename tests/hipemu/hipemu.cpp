@@ -39,6 +39,7 @@ struct Worker {
     void* sched_sp = nullptr;
     const std::function<void()>* body = nullptr;
     std::vector<char> dyn;
+    void* dyn_exact = nullptr;
     int nthreads = 0, nwaves = 0;
     Worker() : fibers(kMaxThreads), waves(kMaxThreads / 64) {
         for (auto& f : fibers) {
@@ -189,8 +190,19 @@ struct Pool {
         w.body = j->body;
         w.nthreads = j->block.x * j->block.y * j->block.z;
         w.nwaves = (w.nthreads + 63) / 64;
-        if (w.dyn.size() < j->shmem + 64) w.dyn.resize(j->shmem + 64);
-        tls.dyn = (char*)(((uintptr_t)w.dyn.data() + 63) & ~(uintptr_t)63);
+        static const bool exact_lds = getenv("HIPEMU_EXACT_LDS") != nullptr;
+        if (exact_lds) {
+            // sanitizer runs (tools/build_emu_asan.sh): the dynamic LDS of every launch is a heap block of EXACTLY the requested
+            // size, so an access past the launch's LDS request is a heap overflow the sanitizer reports (the pooled buffer
+            // below keeps whatever the largest earlier launch asked for)
+            free(w.dyn_exact);
+            w.dyn_exact = nullptr;
+            if (j->shmem && posix_memalign(&w.dyn_exact, 64, j->shmem) != 0) abort();
+            tls.dyn = (char*)w.dyn_exact;
+        } else {
+            if (w.dyn.size() < j->shmem + 64) w.dyn.resize(j->shmem + 64);
+            tls.dyn = (char*)(((uintptr_t)w.dyn.data() + 63) & ~(uintptr_t)63);
+        }
         tls.bdim = {j->block.x, j->block.y, j->block.z};
         tls.gdim = {j->grid.x, j->grid.y, j->grid.z};
         for (;;) {

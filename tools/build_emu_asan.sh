@@ -3,7 +3,7 @@
 # launch is bounds-checked against the real allocations (torch's CPU tensors are ordinary heap blocks under the preloaded runtime).
 #   tools/build_emu_asan.sh            -> tests/hipemu/asan/libvirtex_amd_emu_asan.so   (~8 min on 8 cores)
 #   RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
-#   LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:verify_asan_link_order=0 \
+#   HIPEMU_EXACT_LDS=1 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:verify_asan_link_order=0 \
 #     VTX_EMU_LIB=tests/hipemu/asan/libvirtex_amd_emu_asan.so python -m pytest tests/test_kernels.py -q -m "not gpu"
 # The fiber runtime itself (hand-written context switches, tests/hipemu/hipemu.cpp) stays uninstrumented.
 set -e
