@@ -22,7 +22,13 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
+#ifdef HIPEMU_STATIC_LDS
+// sanitizer builds run with ONE worker thread (HIPEMU_THREADS=1): static LDS arrays become plain statics, which AddressSanitizer
+// fences with red zones (it does not instrument thread-local storage) -- tools/build_emu_asan.sh
+#define __shared__ static
+#else
 #define __shared__ static thread_local
+#endif
 #define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)hipemu::dyn_smem();
 
 typedef void* hipStream_t;
