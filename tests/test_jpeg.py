@@ -234,6 +234,9 @@ def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path)
     grey = str(tmp_path / "e.jpg")
     Image.fromarray(_image(20, 28, rng)[:, :, 0].copy()).save(grey, "JPEG", quality=80)
     seeds.append(grey)
+    probe = subprocess.run([exe, "1"] + seeds[:1], capture_output=True, text=True, timeout=120)
+    if probe.returncode != 0 and "ERROR: AddressSanitizer" not in probe.stderr and "runtime error" not in probe.stderr:
+        pytest.skip("the sanitizer runtime does not start in this environment: " + probe.stderr[-200:])
     r = subprocess.run([exe, "40000"] + seeds, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stderr[-3000:], r.stdout[-300:])
     decoded, refused = (int(x) for x in r.stdout.split()[1::2])
