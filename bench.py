@@ -364,7 +364,9 @@ def stock_pytorch_baseline(batch, dev, steps=10, warmup=3, visual="torchvision::
         dt = time.time() - t0
         return {"value": round(batch * steps / dt, 1), "ms_per_step": round(dt / steps * 1e3, 2), "warmup_s": round(t_w, 1),
                 "final_loss": round(float(loss), 4), "peak_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1)}
-    runs = {"nchw (the reference's layout)": run(torch.contiguous_format), "channels_last": run(torch.channels_last)}
+    layouts = {"nchw (the reference's layout)": torch.contiguous_format, "channels_last": torch.channels_last}
+    only = os.environ.get("VTX_STOCK_LAYOUT")                 # (kernel traces of ONE layout: tools/r05_s19.sh)
+    runs = {k: run(v) for k, v in layouts.items() if not only or k.startswith(only)}
     best = max(runs, key=lambda k: runs[k]["value"])
     return {"value": runs[best]["value"], "unit": "images/sec", "ms_per_step": runs[best]["ms_per_step"], "layout": best, "runs": runs,
             "what": f"oracle port on cuda through stock PyTorch-ROCm {torch.__version__} (MIOpen / hipBLASLt / ATen), autocast bf16, "

@@ -1,5 +1,7 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / %.
-Usage: python tools/rocpd_stats.py results.db [top_n]  -> text summary on stdout."""
+Usage: python tools/rocpd_stats.py results.db [top_n] [--tail-ms X]  -> text summary on stdout.
+--tail-ms X: only the dispatches that start in the last X ms of the trace (the steady state of a run whose beginning is set-up:
+MIOpen's solver search in the stock-PyTorch baseline)."""
 import re
 import sqlite3
 import sys
@@ -14,7 +16,13 @@ def short(name):
 
 def main():
     db = sys.argv[1]
-    top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    argv = list(sys.argv)
+    tail_ms = None
+    if "--tail-ms" in argv:
+        i = argv.index("--tail-ms")
+        tail_ms = float(argv[i + 1])
+        del argv[i:i + 2]
+    top = int(argv[2]) if len(argv) > 2 else 40
     con = sqlite3.connect(db)
     cur = con.cursor()
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
@@ -22,6 +30,9 @@ def main():
     rows = cur.execute(f"select {namecol}, start, end from kernels").fetchall()
     agg = {}
     t0 = min(r[1] for r in rows); t1 = max(r[2] for r in rows)
+    if tail_ms is not None:
+        rows = [r for r in rows if r[1] >= t1 - tail_ms * 1e6]
+        t0 = min(r[1] for r in rows)
     for n, s, e in rows:
         a = agg.setdefault(short(n), [0, 0])
         a[0] += 1; a[1] += e - s
