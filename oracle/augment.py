@@ -11,6 +11,8 @@ cv2 are not installed in this environment, so this follows their published formu
 cv2's INTER_LINEAR convention: source coordinate = (dst + 0.5) * scale - 0.5, taps clamped to the window.  Every stage
 returns to the uint8 grid (round half to even, clip) like uint8 images do on the CPU path; cv2's 11-bit fixed-point
 interpolation weights and its uint8 HSV tables can differ from this by one count.
+Cross-checked (not pinned): resize geometry vs torch F.interpolate, luma vs Pillow convert("L"), hue rotation vs colorsys, each
+within one count -- tests/test_data.py::test_augmentation_oracle_building_blocks_agree_with_independent_implementations.
 """
 import numpy as np
 

@@ -171,3 +171,45 @@ def test_sentencepiece_tokenizer_and_caption_cache(tmp_path):
     assert cache.tokens(1, flipped=True) == cache.tokens(1) and cache.plain[0].dtype == np.int16
     item = vdata.caption_instance(7, torch.zeros(8, 8, 3, dtype=torch.uint8), cache.tokens(0))
     assert item["caption_tokens"][0] == 1 and item["caption_tokens"][-1] == 2 and int(item["caption_lengths"]) == len(ids) + 2
+
+
+def test_augmentation_oracle_building_blocks_agree_with_independent_implementations():
+    """cv2 / albumentations are not installable here, so `oracle/augment.py` restates their published formulas (parity unpinned,
+    DESIGN.md 8 f2).  What CAN be checked is that its building blocks are the textbook operations, against implementations that
+    are installed and share no code with it: the bilinear geometry of cv2.INTER_LINEAR (half-pixel centres, no antialiasing,
+    edge clamping) = torch's `interpolate(mode="bilinear", align_corners=False)`; the ITU-R 601 luma of the grayscale used by
+    contrast / saturation = Pillow's `convert("L")`; the hue rotation = Python's `colorsys` round trip.  Each within ONE count of
+    the uint8 grid (the same margin cv2's fixed-point weights / integer HSV tables have against the formulas)."""
+    import colorsys
+    import torch.nn.functional as F
+    from PIL import Image
+    from oracle import augment as oa
+    rng = np.random.default_rng(11)
+    # -- crop + bilinear resize, up- and down-scaling, odd windows
+    for (H, W, x0, y0, cw, ch, size) in [(97, 131, 5, 9, 100, 71, 64), (60, 80, 0, 0, 80, 60, 224), (300, 200, 17, 33, 150, 240, 224),
+                                          (40, 40, 3, 2, 31, 37, 32)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        mine = oa.resize_crop(img, x0, y0, cw, ch, size)
+        crop = torch.from_numpy(img[y0:y0 + ch, x0:x0 + cw].astype(np.float32)).permute(2, 0, 1)[None]
+        ref = F.interpolate(crop, size=(size, size), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        ref = np.clip(np.rint(ref), 0, 255)
+        diff = np.abs(mine - ref)
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.99, (H, W, size, diff.max(), (diff == 0).mean())
+    # -- luma
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    pil = np.asarray(Image.fromarray(img).convert("L")).astype(np.float32)
+    diff = np.abs(oa.gray(img.astype(np.float32)) - pil)
+    assert diff.max() <= 1 and (diff == 0).mean() > 0.95
+    # -- hue rotation: colorsys round trip per pixel (float), back on the uint8 grid
+    img = rng.integers(0, 256, (24, 24, 3), dtype=np.uint8)
+    for h in (0.1, -0.07, 0.5):
+        mine = oa.hue_shift(img.astype(np.float32), h)
+        ref = np.empty_like(mine)
+        for y in range(img.shape[0]):
+            for x in range(img.shape[1]):
+                r, g, b = (float(v) / 255.0 for v in img[y, x])
+                hh, ss, vv = colorsys.rgb_to_hsv(r, g, b)
+                ref[y, x] = [c * 255.0 for c in colorsys.hsv_to_rgb((hh + h) % 1.0, ss, vv)]
+        ref = np.clip(np.rint(ref), 0, 255)
+        diff = np.abs(mine - ref)
+        assert diff.max() <= 1 and (diff == 0).mean() > 0.97, (h, diff.max(), (diff == 0).mean())
