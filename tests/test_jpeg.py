@@ -241,3 +241,17 @@ def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path)
     assert r.returncode == 0 and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (r.stderr[-3000:], r.stdout[-300:])
     decoded, refused = (int(x) for x in r.stdout.split()[1::2])
     assert decoded > 5000 and refused > 5000              # the mutations reach both the scan and the refusal paths
+
+
+@pytest.mark.gpu
+def test_large_frames_decode_bitwise_gpu():
+    """camera-sized frames (the fixtures are thumbnails): 2048 x 1536 4:2:0 with restart intervals and an odd-sized 1999 x 1333
+    4:2:2 frame -- 12 288 / 10 500 MCUs, plane offsets in the millions -- against Pillow, bit for bit"""
+    pytest.importorskip("PIL")
+    from virtex_amd import jpeg as vj
+    dev = select("gpu")
+    rng = np.random.default_rng(21)
+    for (h, w, kw) in [(1536, 2048, dict(quality=88, subsampling=2, restart_marker_rows=4)), (1333, 1999, dict(quality=75, subsampling=1))]:
+        data = _encode(_image(h, w, rng), **kw)
+        out = vj.decode_jpeg(data, dev).cpu().numpy()
+        assert out.shape == (h, w, 3) and np.array_equal(out, _pil_decode(data)), (h, w)
