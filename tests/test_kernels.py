@@ -5,7 +5,7 @@ import torch
 import torch.nn.functional as F
 
 from backends import BACKENDS, rel_err, select, tol
-from virtex_amd import ops
+from virtex_amd import _lib, ops
 
 DTYPES = [torch.float32, torch.bfloat16]
 
@@ -308,7 +308,10 @@ def test_embedding(backend, dtype, B, T, H, V):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,A,T,S,causal", [(2, 4, 12, 12, True), (3, 2, 30, 49, False), (2, 16, 30, 30, True)])
+@pytest.mark.parametrize("B,A,T,S,causal", [(2, 4, 12, 12, True), (3, 2, 30, 49, False), (2, 16, 30, 30, True),
+                                            # beyond the tuned envelope (T <= 32, S <= 56): the general kernels -- the 8 x 8 grid of
+                                            # 256 x 256 images, the 12 x 12 grid of 384 x 384, captions of 48 tokens, an odd grid
+                                            (2, 2, 30, 64, False), (1, 2, 30, 144, False), (2, 2, 48, 48, True), (1, 1, 40, 99, False)])
 def test_attention(backend, dtype, B, A, T, S, causal):
     dev = select(backend)
     g = torch.Generator().manual_seed(T + S)
@@ -352,6 +355,16 @@ def test_attention(backend, dtype, B, A, T, S, causal):
     assert rel_err(dq.float().cpu(), unheads(qr.grad, T)) < 2 * e
     assert rel_err(dk.float().cpu(), unheads(kr.grad, S)) < 2 * e
     assert rel_err(dv.float().cpu(), unheads(vr.grad, S)) < 2 * e
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_attention_refuses_tiles_that_do_not_fit_lds(backend):
+    """beyond the tuned envelope one (batch, head) must still fit one workgroup's 160 KiB: refused with the sizes in the message"""
+    dev = select(backend)
+    q = torch.zeros(30, 64, device=dev)
+    kv = torch.zeros(400, 128, device=dev)
+    with pytest.raises(_lib.VtxError, match="LDS"):
+        ops.attention_fwd(q, kv[:, :64], kv[:, 64:], 1, 1, 30, 400, False, None)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -577,7 +590,7 @@ def test_contraction_profiler_counts_launches_flops_bytes(backend):
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,A,T,S,causal", [(2, 3, 30, 49, False), (3, 2, 30, 30, True)])
+@pytest.mark.parametrize("B,A,T,S,causal", [(2, 3, 30, 49, False), (3, 2, 30, 30, True), (2, 2, 30, 64, False), (2, 2, 40, 40, True)])
 def test_attention_dropout_mask_is_shared_by_forward_and_backward(backend, dtype, B, A, T, S, causal):
     """Attention dropout is a counter-based hash re-evaluated in backward (no mask tensor).  Recover the mask the
     forward pass used by running it with V = identity (then O[i][j] = dropout(P)[i][j]), rebuild the op in torch

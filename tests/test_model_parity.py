@@ -260,6 +260,30 @@ def test_prenorm_model_fp32_gpu():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("image_size,max_len", [(256, 30), (224, 44), (320, 40)])
+def test_shapes_beyond_the_tuned_attention_envelope_fp32_gpu(image_size, max_len):
+    """Another crop size (256 x 256 -> an 8 x 8 grid of 64 keys; 320 x 320 -> 100) or a longer caption limit (44 > 32 queries) takes
+    the general attention kernels: loss and every text-side gradient against the oracle at the north-star bound, backbone
+    gradients finite (their rule lives in the golden cases)."""
+    dev = select("gpu")
+    kw = dict(textual="transdec_postnorm::L1_H128_A2_F256", vocab_size=500, max_caption_length=max_len)
+    oracle_model = synth.seeded_model(port.build_model, seed=0, dropout=0.0, **kw).train()
+    model = vf.build_bicaptioning_model(visual="torchvision::resnet50", dropout=0.0, compute_dtype=torch.float32, **kw)
+    missing = model.load_state_dict(oracle_model.state_dict())
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model = model.to(dev)
+    batch = synth.synthetic_batch(2, image_size=image_size, max_len=max_len, vocab_size=500, seed=5, ragged=True)
+    oo = oracle_model(batch)
+    oo["loss"].backward()
+    out = _run(model, batch, dev)
+    assert abs(out["loss"].item() - oo["loss"].item()) < 1e-5 * abs(oo["loss"].item())
+    for (n, p), (_, q) in zip(model.named_parameters(), oracle_model.named_parameters()):
+        assert torch.isfinite(p.grad).all(), n
+        if "cnn" not in n:
+            assert rel_err(p.grad.cpu(), q.grad) < 1e-3, n
+
+
+@pytest.mark.gpu
 def test_prenorm_model_bf16_gpu():
     """The pre-norm head in the throughput mode on the 3-image toy case: loss to 2e-3, every gradient finite, and every text-side
     gradient held to what `torch.autocast(bfloat16)` of the oracle itself reaches on this case (computed here, on the CPU):

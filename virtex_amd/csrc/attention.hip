@@ -1,5 +1,5 @@
-// Fused multi-head attention for the tiny tiles of the caption decoder (T <= 32 queries,
-// S <= 56 keys, head_dim = 64): one workgroup per (batch, head); Q/K/V tiles live in LDS, the
+// Fused multi-head attention for the tiny tiles of the caption decoder (tuned for T <= 32 queries,
+// S <= 56 keys, head_dim = 64; larger tiles: the general kernels below): one workgroup per (batch, head); Q/K/V tiles live in LDS, the
 // whole score matrix in LDS, softmax in fp32 with wave64 shuffles.  The backward kernel
 // recomputes the probabilities instead of reading them from HBM.
 //
@@ -169,6 +169,144 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs a, const T* __re
                     [&](int i, int j) { return sG[i * SMAX + j]; });
     matmul_store<T>(dk + (long)b * a.S * lddk + h * D, lddk, a.S, tid, a.T, sQ, D,
                     [&](int j, int i) { return sG[i * SMAX + j]; });
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Shapes outside the tuned envelope (T > 32 queries or S > 56 keys: another crop size -- 256 x 256 images give an 8 x 8 grid --
+// or a longer caption limit): the same algorithm with run-time tile sizes in dynamic LDS and a softmax that walks a row in
+// steps of 64 lanes.  A correctness path (the reference takes any shape: scaled_dot_product_attention), not a tuned one;
+// both compute dtypes; bounded by LDS: 4 * (T*64 + 2*S'*65 + T*S') bytes forward, 4 * (2*T*64 + 2*S'*65 + 2*T*S') backward
+// (S' = S rounded up to 4) must fit 160 KiB -- e.g. T = 32 with S <= 288 forward / 224 backward (448 x 448 images: S = 196).
+// The dropout mask of element (i, j) of block `bh` is drawn at index bh*T*S + i*S + j in both directions.
+struct BigLds { float *q, *o, *k, *v, *p, *g; };
+__device__ __forceinline__ BigLds big_carve(float* base, int T, int S, bool bwd) {
+    const int S4r = (S + 3) / 4 * 4;
+    BigLds l;
+    l.q = base; base += T * D;
+    l.o = base; if (bwd) base += T * D;
+    l.k = base; base += S4r * KP;
+    l.v = base; base += S4r * KP;
+    l.p = base; base += T * S;
+    l.g = base;
+    return l;
+}
+static size_t big_lds_bytes(int T, int S, bool bwd) {
+    const size_t S4r = (size_t)(S + 3) / 4 * 4;
+    return 4 * ((bwd ? 2 : 1) * (size_t)T * D + 2 * S4r * KP + (bwd ? 2 : 1) * (size_t)T * S);
+}
+
+__device__ __forceinline__ void big_scores_softmax(const BigLds& l, const AttnArgs& a, int len, int tid) {
+    const int S = a.S, S4 = (S + 3) / 4;
+    for (int idx = tid; idx < a.T * S4; idx += 256) {
+        const int i = idx / S4, j0 = (idx % S4) * 4;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* q = l.q + i * D;
+        const float* k0 = l.k + j0 * KP;    // rows S .. S' exist in the buffer (whatever they hold is never stored)
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+            const float qv = q[d];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[t] += qv * k0[t * KP + d];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = j0 + t;
+            if (j < S) l.p[i * S + j] = ((a.causal && j > i) || j >= len) ? -INFINITY : s[t] * a.scale;
+        }
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int i = wv; i < a.T; i += 4) {
+        float* row = l.p + i * S;
+        float m = -INFINITY;
+        for (int j = lane; j < S; j += 64) m = fmaxf(m, row[j]);
+        m = wave_max(m);
+        float sum = 0.f;
+        for (int j = lane; j < S; j += 64) {
+            const float e = m > -INFINITY ? __expf(row[j] - m) : 0.f;
+            row[j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = sum > 0.f ? 1.f / sum : 0.f;
+        for (int j = lane; j < S; j += 64) row[j] *= inv;
+    }
+    __syncthreads();
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void attn_fwd_big_kernel(AttnArgs a, T* __restrict__ o) {
+    a.drop = a.drop.resolved();
+    HIP_DYNAMIC_SHARED(float, smem)
+    const BigLds l = big_carve(smem, a.T, a.S, false);
+    const int tid = threadIdx.x, S = a.S;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    load_tile<T>(l.q, D, (const T*)a.q + (long)b * a.T * a.ldq + h * D, a.ldq, a.T, tid);
+    load_tile<T>(l.k, KP, (const T*)a.k + (long)b * S * a.ldk + h * D, a.ldk, S, tid);
+    load_tile<T>(l.v, KP, (const T*)a.v + (long)b * S * a.ldv + h * D, a.ldv, S, tid);
+    __syncthreads();
+    const int len = a.lengths ? (int)a.lengths[b] : S;
+    big_scores_softmax(l, a, len, tid);
+    const uint64_t pbase = (uint64_t)blockIdx.x * (uint64_t)(a.T * S);
+    if (a.drop.thresh) {
+        for (int idx = tid; idx < a.T * S; idx += 256) l.p[idx] = a.drop.apply(l.p[idx], pbase + idx);
+        __syncthreads();
+    }
+    matmul_store<T>(o + (long)b * a.T * a.ldo + h * D, a.ldo, a.T, tid, S, l.v, KP,
+                    [&](int i, int j) { return l.p[i * S + j]; });
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void attn_bwd_big_kernel(AttnArgs a, const T* __restrict__ dout, T* __restrict__ dq,
+                                                           T* __restrict__ dk, T* __restrict__ dv, long lddq,
+                                                           long lddk, long lddv) {
+    a.drop = a.drop.resolved();
+    HIP_DYNAMIC_SHARED(float, smem)
+    const BigLds l = big_carve(smem, a.T, a.S, true);
+    const int tid = threadIdx.x, S = a.S;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    load_tile<T>(l.q, D, (const T*)a.q + (long)b * a.T * a.ldq + h * D, a.ldq, a.T, tid);
+    load_tile<T>(l.o, D, dout + (long)b * a.T * a.ldo + h * D, a.ldo, a.T, tid);
+    load_tile<T>(l.k, KP, (const T*)a.k + (long)b * S * a.ldk + h * D, a.ldk, S, tid);
+    load_tile<T>(l.v, KP, (const T*)a.v + (long)b * S * a.ldv + h * D, a.ldv, S, tid);
+    __syncthreads();
+    const int len = a.lengths ? (int)a.lengths[b] : S;
+    big_scores_softmax(l, a, len, tid);
+    const uint64_t pbase = (uint64_t)blockIdx.x * (uint64_t)(a.T * S);
+    // dV[j][d] = sum_i Pd[i][j] dO[i][d]
+    matmul_store<T>(dv + (long)b * S * lddv + h * D, lddv, S, tid, a.T, l.o, D,
+                    [&](int j, int i) { return a.drop.apply(l.p[i * S + j], pbase + i * S + j); });
+    // dP[i][j] = dropout'( sum_d dO[i][d] V[j][d] )
+    const int S4 = (S + 3) / 4;
+    for (int idx = tid; idx < a.T * S4; idx += 256) {
+        const int i = idx / S4, j0 = (idx % S4) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* go = l.o + i * D;
+        const float* v0 = l.v + j0 * KP;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) {
+            const float gv = go[d];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] += gv * v0[t * KP + d];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (j0 + t < S) l.g[i * S + j0 + t] = a.drop.apply(acc[t], pbase + i * S + j0 + t);
+    }
+    __syncthreads();
+    // dS = P * (dP - rowsum(dP * P)) * scale   (written over g)
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int i = wv; i < a.T; i += 4) {
+        float dot = 0.f;
+        for (int j = lane; j < S; j += 64) dot += l.p[i * S + j] * l.g[i * S + j];
+        dot = wave_sum(dot);
+        for (int j = lane; j < S; j += 64) l.g[i * S + j] = l.p[i * S + j] * (l.g[i * S + j] - dot) * a.scale;
+    }
+    __syncthreads();
+    matmul_store<T>(dq + (long)b * a.T * lddq + h * D, lddq, a.T, tid, S, l.k, KP,
+                    [&](int i, int j) { return l.g[i * S + j]; });
+    matmul_store<T>(dk + (long)b * S * lddk + h * D, lddk, S, tid, a.T, l.q, D,
+                    [&](int j, int i) { return l.g[i * S + j]; });
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -508,8 +646,21 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(AttnArgs a, const bf
 static int check(const char* who, int dtype, int B, int heads, int T, int S, int head_dim) {
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "%s: bad dtype", who);
     VTX_CHECK(B >= 0 && heads > 0 && T > 0 && S > 0, VTX_ERR_ARG, "%s: bad shape", who);
-    VTX_CHECK(head_dim == D && T <= TMAX && S <= SMAX, VTX_ERR_SHAPE,
-              "%s: supports head_dim == 64, T <= %d, S <= %d (got d=%d T=%d S=%d)", who, TMAX, SMAX, head_dim, T, S);
+    VTX_CHECK(head_dim == D, VTX_ERR_SHAPE, "%s: supports head_dim == 64 (got %d)", who, head_dim);
+    return VTX_OK;
+}
+// the tuned kernels take T <= 32, S <= 56; anything else runs on the general kernels while its tiles fit the 160 KiB of LDS
+constexpr size_t BIG_LDS_MAX = 160 * 1024;
+static bool tuned_shape(int T, int S) { return T <= TMAX && S <= SMAX; }
+template <class K> static int big_prepare(const char* who, K kern, int T, int S, bool bwd, size_t* lds) {
+    *lds = big_lds_bytes(T, S, bwd);
+    VTX_CHECK(*lds <= BIG_LDS_MAX, VTX_ERR_SHAPE, "%s: T=%d queries x S=%d keys need %zu bytes of LDS (limit %zu): beyond the "
+              "tuned envelope (T <= %d, S <= %d) the tiles of one (batch, head) must fit one workgroup", who, T, S, *lds, BIG_LDS_MAX, TMAX, SMAX);
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds) != hipSuccess) {
+        (void)hipGetLastError();
+        vtx_set_error("%s: cannot reserve %zu bytes of LDS", who, *lds);
+        return VTX_ERR_LAUNCH;
+    }
     return VTX_OK;
 }
 
@@ -525,8 +676,22 @@ extern "C" int vtx_attention_fwd(int dtype, const void* q, long ldq, const void*
     AttnArgs a{q, k, v, ldq, ldk, ldv, ldo, T, S, heads, 1.0f / sqrtf((float)head_dim), causal, key_lengths,
                make_dropout(p_drop, seed)};
     dim3 grid(B * heads), block(256);
-    if (dtype == VTX_BF16) {
+    if (dtype == VTX_BF16)
         VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, VTX_ERR_SHAPE, "attention_fwd: row strides must be multiples of 8");
+    if (!tuned_shape(T, S)) {
+        size_t lds = 0;
+        if (dtype == VTX_BF16) {
+            VTX_CHECK(ldo % 8 == 0, VTX_ERR_SHAPE, "attention_fwd: row strides must be multiples of 8");
+            if ((rc = big_prepare("attention_fwd", attn_fwd_big_kernel<bf16_t>, T, S, false, &lds))) return rc;
+            hipLaunchKernelGGL((attn_fwd_big_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, (bf16_t*)o);
+        } else {
+            if ((rc = big_prepare("attention_fwd", attn_fwd_big_kernel<float>, T, S, false, &lds))) return rc;
+            hipLaunchKernelGGL((attn_fwd_big_kernel<float>), grid, block, lds, (hipStream_t)stream, a, (float*)o);
+        }
+        VTX_LAUNCH_CHECK();
+        return VTX_OK;
+    }
+    if (dtype == VTX_BF16) {
         VTX_KLAUNCH("attention_fwd", 4.0 * B * heads * T * S * 64, 2.0 * B * heads * 64 * (2.0 * T + 2.0 * S), attn_fwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 4)), block, 0, (hipStream_t)stream, a, (bf16_t*)o, B * heads);
     }
     else hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a, (float*)o);
@@ -545,9 +710,25 @@ extern "C" int vtx_attention_bwd(int dtype, const void* q, long ldq, const void*
     AttnArgs a{q, k, v, ldq, ldk, ldv, ldo, T, S, heads, 1.0f / sqrtf((float)head_dim), causal, key_lengths,
                make_dropout(p_drop, seed)};
     dim3 grid(B * heads), block(256);
-    if (dtype == VTX_BF16) {
+    if (dtype == VTX_BF16)
         VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
                   VTX_ERR_SHAPE, "attention_bwd: row strides must be multiples of 8 (inputs) / 4 (gradients)");
+    if (!tuned_shape(T, S)) {
+        size_t lds = 0;
+        if (dtype == VTX_BF16) {
+            VTX_CHECK(lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0, VTX_ERR_SHAPE, "attention_bwd: gradient row strides must be multiples of 8");
+            if ((rc = big_prepare("attention_bwd", attn_bwd_big_kernel<bf16_t>, T, S, true, &lds))) return rc;
+            hipLaunchKernelGGL((attn_bwd_big_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, (const bf16_t*)dout,
+                               (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv);
+        } else {
+            if ((rc = big_prepare("attention_bwd", attn_bwd_big_kernel<float>, T, S, true, &lds))) return rc;
+            hipLaunchKernelGGL((attn_bwd_big_kernel<float>), grid, block, lds, (hipStream_t)stream, a, (const float*)dout,
+                               (float*)dq, (float*)dk, (float*)dv, lddq, lddk, lddv);
+        }
+        VTX_LAUNCH_CHECK();
+        return VTX_OK;
+    }
+    if (dtype == VTX_BF16) {
         VTX_KLAUNCH("attention_bwd", 10.0 * B * heads * T * S * 64, 2.0 * B * heads * 64 * (3.0 * T + 4.0 * S), attn_bwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 2)), dim3(128), 0, (hipStream_t)stream, a,
                            (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, B * heads);
     }
