@@ -185,7 +185,40 @@ FAMILY_OF = {   # HBM-bound kernel -> family reported under roofline.families
 
 
 def _display_name(rec_name):
-    return rec_name[len("family:"):] if rec_name.startswith("family:") else _kernel_name(rec_name)
+    """The FAMILY-level name of a profile class: the launch family of a VTX_KLAUNCH site ("family:<name>|<kernel>|[T = ...]"),
+    the kernel name of a contraction instantiation."""
+    return rec_name[len("family:"):].split("|")[0] if rec_name.startswith("family:") else _kernel_name(rec_name)
+
+
+def _instantiation_name(rec_name):
+    """The single kernel instantiation a profile class stands for, as close to rocprofv3's spelling as the class name allows:
+    'family:bn_bwd_apply|(bn_bwd_apply_fused_kernel<T, UNR, true>)|[T = unsigned short, UNR = 2]' ->
+    'bn_bwd_apply_fused_kernel<bf16, 2, true>'."""
+    if not rec_name.startswith("family:"):
+        return _kernel_name(rec_name)
+    import re
+    parts = rec_name[len("family:"):].split("|")
+    if len(parts) < 2 or not parts[1].strip():
+        return parts[0]
+    kern = parts[1].strip()
+    while kern.startswith("(") and kern.endswith(")"):
+        kern = kern[1:-1].strip()
+    binds = {}
+    if len(parts) > 2 and parts[2].startswith("["):
+        body, depth, cur, items = parts[2].strip()[1:-1], 0, "", []
+        for ch in body:
+            depth += ch == "<"; depth -= ch == ">"
+            if ch == "," and depth == 0:
+                items.append(cur); cur = ""
+            else:
+                cur += ch
+        items.append(cur)
+        for it in items:
+            if "=" in it:
+                k, v = it.split("=", 1)
+                binds[k.strip()] = v.strip()
+    kern = re.sub(r"\b[A-Za-z_][A-Za-z_0-9]*\b", lambda m: binds.get(m.group(0), m.group(0)), kern)
+    return kern.replace("vtxg::", "").replace("unsigned short", "bf16").replace("bf16_t", "bf16")
 
 
 def merge_classes(recs):
@@ -200,39 +233,78 @@ def merge_classes(recs):
     return out
 
 
+def dominant_class(recs):
+    """The profile class (= ONE kernel instantiation at one launch site) with the largest summed time: the row a
+    `rocprofv3 --kernel-trace --stats` summary of the same step lists first."""
+    return max(recs, key=lambda r: r["seconds"])
+
+
+def _roof_entry(flops, bytes_, seconds, peak_tf):
+    tf = flops / seconds / 1e12
+    tbs = bytes_ / seconds / 1e12
+    return tf, tbs, tf / peak_tf, tbs / PEAK_HBM_TBS
+
+
+def roofline_violations(roof):
+    """Every fraction of a roofline object that exceeds 1: a physically impossible entry means the ACCOUNTING (algorithmic
+    FLOPs / bytes of a launch) is wrong, whatever the cause (round 5: the optimizer counted padded chunks and reported 1.14)."""
+    bad = []
+    def walk(o, path):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k in ("frac", "mfma_frac", "hbm_frac") and isinstance(v, (int, float)) and v > 1.0:
+                    bad.append(f"{'.'.join(path + [k])} = {v}")
+                else:
+                    walk(v, path + [str(k)])
+    walk(roof, ["roofline"])
+    return bad
+
+
 def step_roofline(recs, dtype, workload_tag, focused=None, survey_steps=1, focused_steps=None):
     """Roofline of the step's dominant kernel, measured LIVE: HIP events attached to every launch of the step function
     the timed region runs (`recs` = ops.profile_stop() of `survey_steps` fully timed steps).  The dominant kernel is the
-    one with the largest summed time; achieved = its algorithmic FLOPs (or bytes) / its summed launch time; the binding
-    roof is whichever fraction is larger."""
+    single kernel INSTANTIATION (profile class) with the largest summed time -- what a kernel-trace summary of the step lists
+    first, flattering or not; achieved = its algorithmic FLOPs (or bytes) / its summed launch time; the binding roof is
+    whichever fraction is larger.  `dominant_family` keeps the family-merged pick of rounds 1-5 as a secondary key."""
     if not recs:
         return None
     peak_tf = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     by_name = merge_classes(recs)
-    total = sum(r["seconds"] for r in by_name.values())
-    dom = max(by_name.values(), key=lambda r: r["seconds"])
-    share = dom["seconds"] / total
+    total = sum(r["seconds"] for r in recs)
+    drec = dominant_class(recs)
+    share = drec["seconds"] / total
+    fam_name = _display_name(drec["name"])
+    inst_name = _instantiation_name(drec["name"])
+    dom = dict(drec)
     if focused is not None:
         dom = dict(dom, launches=focused["launches"], seconds=focused["seconds"], flops=focused["flops"], bytes=focused["bytes"])
-    tf = dom["flops"] / dom["seconds"] / 1e12
-    tbs = dom["bytes"] / dom["seconds"] / 1e12
-    f_mfma, f_hbm = tf / peak_tf, tbs / PEAK_HBM_TBS
+    tf, tbs, f_mfma, f_hbm = _roof_entry(dom["flops"], dom["bytes"], dom["seconds"], peak_tf)
     bound = "mfma" if f_mfma >= f_hbm else "hbm"
     default_workload = workload_tag is not None          # a workload with a PMC table of its own (TABLED_WORKLOADS)
     table, table_source = load_traffic_table(traffic_table_path(workload_tag)) if default_workload else ({}, None)
-    per_step = dom["launches"] / focused_steps if (focused is not None and focused_steps) else None
-    traffic, instantiation = lookup_traffic(table, dom["name"], len(dom["cls"]) if focused is not None else 1, per_step)
+    steps_timed = focused_steps if (focused is not None and focused_steps) else survey_steps
+    per_step = dom["launches"] / steps_timed
+    traffic, instantiation = lookup_traffic(table, fam_name, len(by_name[fam_name]["cls"]), per_step)
     if default_workload and table_source and traffic is None:
-        print(f"bench.py: ERROR -- {os.path.basename(traffic_table_path(workload_tag))} has no entry for the dominant kernel {dom['name']!r}; "
+        print(f"bench.py: ERROR -- {os.path.basename(traffic_table_path(workload_tag))} has no entry for the dominant kernel {inst_name!r}; "
               "reporting traffic = null", file=sys.stderr)
-    out = {"bound": bound, "kernel": instantiation or dom["name"],
+    out = {"bound": bound, "kernel": inst_name, "kernel_in_traffic_table": instantiation or fam_name,
            "achieved": round(tf if bound == "mfma" else tbs * 1e3, 2), "peak": peak_tf if bound == "mfma" else PEAK_HBM_TBS * 1e3,
            "unit": "TFLOP/s" if bound == "mfma" else "GB/s", "frac": round(max(f_mfma, f_hbm), 4),
            "traffic": traffic, "traffic_unit": "bytes/launch",
            "traffic_source": (table_source if traffic is not None else None),
-           "launches": dom["launches"], "avg_launch_us": round(dom["seconds"] / dom["launches"] * 1e6, 1),
+           "launches": dom["launches"], "launches_per_step": round(per_step, 2), "avg_launch_us": round(dom["seconds"] / dom["launches"] * 1e6, 1),
            "flops_per_launch": dom["flops"] / dom["launches"], "algorithmic_bytes": dom["bytes"] / dom["launches"],
-           "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4), "share_of_kernel_time": round(share, 3)}
+           "mfma_frac": round(f_mfma, 4), "hbm_frac": round(f_hbm, 4), "share_of_kernel_time": round(share, 3),
+           "selection": "the single kernel instantiation (profile class) with the largest summed time in one fully timed step, side streams off"}
+    # the family-merged pick of rounds 1-5 (all instantiations of a launch family summed), survey step's own times
+    fdom = max(by_name.values(), key=lambda r: r["seconds"])
+    ftf, ftbs, ff_mfma, ff_hbm = _roof_entry(fdom["flops"], fdom["bytes"], fdom["seconds"], peak_tf)
+    out["dominant_family"] = {"family": fdom["name"], "instantiations": len(fdom["cls"]), "launches_per_step": fdom["launches"] // survey_steps,
+                              "ms_per_step": round(fdom["seconds"] / survey_steps * 1e3, 3), "TFLOP/s": round(ftf, 1), "GB/s": round(ftbs * 1e3, 1),
+                              "mfma_frac": round(ff_mfma, 4), "hbm_frac": round(ff_hbm, 4),
+                              "bound": "mfma" if ff_mfma >= ff_hbm else "hbm", "frac": round(max(ff_mfma, ff_hbm), 4),
+                              "share_of_kernel_time": round(fdom["seconds"] / total, 3)}
     # every HBM-bound kernel, and families
     hbm, fam = {}, {}
     for r in by_name.values():
@@ -253,9 +325,8 @@ def step_roofline(recs, dtype, workload_tag, focused=None, survey_steps=1, focus
                              "TFLOP/s": round(r["flops"] / r["seconds"] / 1e12, 1), "mfma_frac": round(r["flops"] / r["seconds"] / 1e12 / peak_tf, 4),
                              "GB/s": round(r["bytes"] / r["seconds"] / 1e9, 1), "hbm_frac": round(r["bytes"] / r["seconds"] / 1e12 / PEAK_HBM_TBS, 4)}
     out["mfma_kernels"] = dict(sorted(mk.items(), key=lambda kv: -kv[1]["ms_per_step"]))
-    # The largest SINGLE contraction instantiation by summed time, whatever the family-merged headline above points at: a
-    # round cannot "improve" the headline fraction by shrinking a worse kernel below a better one.
-    # Times are the survey step's (every launch timed, side streams off); traffic from the PMC table when it has this class.
+    # The largest SINGLE contraction instantiation by summed time (round 4's gauge; equal to the headline whenever the step's
+    # largest kernel is a contraction).  Times are the survey step's (every launch timed, side streams off).
     if mk:
         dk, dv = max(mk.items(), key=lambda kv: kv[1]["ms_per_step"])
         dtraffic = table.get(dk) if table else None
@@ -275,6 +346,7 @@ def step_roofline(recs, dtype, workload_tag, focused=None, survey_steps=1, focus
                          "frac": round(model_s / (total / survey_steps), 4),
                          "note": "sum over all launches of one step of max(algorithmic FLOPs / MFMA peak, algorithmic bytes / 8 TB/s) "
                                  "against the sum of their measured durations (side streams off)"}
+    out["step_model_frac"] = out["step_model"]["frac"]
     return out
 
 
@@ -445,7 +517,12 @@ def main(argv=None, device=None, backend=None):
     gstep, launch_mode, launch_fallback = None, "eager", None
     want = a.launch
     if want == "auto":
-        want = "replay" if (dev.type == "cuda" and not a.roofline_live) else "eager"
+        # Launch replay is the default only where it has EXECUTED on hardware: the single-process GPU run.  The recorded list can
+        # carry the bucket all-reduces (tests: gloo x 2, RCCL x 1), but RCCL x N has never run it and a mismatched collective is
+        # a hang, not an exception -- the first multi-GPU record is not bet on it.  Opt in with
+        # VIRTEX_AMD_REPLAY_DP=1; the gain at bs 256 is 0.005 ms per step.
+        replay_ok = world == 1 or os.environ.get("VIRTEX_AMD_REPLAY_DP", "0") == "1"
+        want = "replay" if (dev.type == "cuda" and not a.roofline_live and replay_ok) else "eager"
     if want == "graph" and world > 1:
         want = "eager"               # the hipGraph of the step is single-process; launch replay carries the all-reduces (round 5)
     if want in ("replay", "graph") and not a.roofline_live:
@@ -507,6 +584,7 @@ def main(argv=None, device=None, backend=None):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = loss.item()
+    seen = vd.ranks_seen(dev if dev.type == "cuda" else None)      # did the transport connect N ranks?  (all-reduce of a one)
     # the part of the gradient exchange the backward pass did not hide (events around finish()'s wait), per rank
     comm_exposed = buckets.comm_exposed_ms(last=a.steps)
     if world > 1:
@@ -536,10 +614,8 @@ def main(argv=None, device=None, backend=None):
         if prof:
             survey = ops.profile_stop()
             dom_cls = -1
-            if survey:          # dominant kernel by NAME; the focused pass times its largest class
-                by_name = merge_classes(survey)
-                dom = max(by_name.values(), key=lambda r: r["seconds"])
-                dom_cls = max((r for r in survey if r["cls"] in dom["cls"]), key=lambda r: r["seconds"])["cls"]
+            if survey:          # the single kernel instantiation with the largest summed time; the focused pass times it alone
+                dom_cls = dominant_class(survey)["cls"]
             ops.profile_start(only_class=dom_cls)
         for i in range(a.roofline_steps):
             step(i)
@@ -561,6 +637,10 @@ def main(argv=None, device=None, backend=None):
 
     # ---- fidelity leg (every rank: the engine's finish() is collective; rank 0 reports): the bf16 step against the
     # fp32 step on the batch the timed region used
+    # DDP broadcasts rank 0's buffers before EVERY forward (reference: scripts/pretrain_virtex.py:123, broadcast_buffers=True);
+    # this engine never does inside the step (BatchNorm running statistics are not read by a training forward), so they are
+    # made rank-0's HERE, where they start to matter: before anything validation-like reads them.
+    vd.broadcast_buffers(model)
     fid = None
     if a.dtype == "bf16" and not a.no_fidelity:
         from virtex_amd import fidelity
@@ -597,11 +677,14 @@ def main(argv=None, device=None, backend=None):
                                             "blocked on the full HIP queue, so a value near ms_per_step means 'host not the limit' "
                                             "(un-blocked cost: profiles/r04_launch_replay_configs_2_4_5.txt)"},
         }
+        if world > 1 or vd.active():
+            rec["data_parallel"] = dict(vd.transport_description(), ranks_seen=seen, launch=launch_mode,
+                                        buffers_broadcast_before_validation=True)
         if comm_exposed is not None:
-            rec["data_parallel"] = {"comm_exposed_ms_per_rank": comm_exposed, "payload": buckets.payload,
+            rec.setdefault("data_parallel", {}).update({"comm_exposed_ms_per_rank": comm_exposed, "payload": buckets.payload,
                                     "buckets_mb": [round((e - s0) * 4 / 2 ** 20, 1) for (s0, e, _) in buckets.buckets],
                                     "note": "GPU time the compute stream waited in GradientBuckets.finish() for the outstanding "
-                                            "all-reduces, mean over the timed steps"}
+                                            "all-reduces, mean over the timed steps"})
         if gflop:
             tf = ips * gflop / 1e3
             rec["step_mfma"] = {"gflop_per_image": gflop, "achieved_tflops": round(tf, 1),
@@ -621,6 +704,14 @@ def main(argv=None, device=None, backend=None):
                     if concurrent:
                         c = concurrent[0]
                         rec["roofline"]["concurrent_avg_launch_us"] = round(c["seconds"] / c["launches"] * 1e6, 1)
+            if rec.get("roofline"):
+                # the two step-level fractions next to the kernel's, and the consistency check: no
+                # fraction of the object may exceed 1
+                rec["roofline"]["step_mfma_frac"] = rec.get("step_mfma", {}).get("frac")
+                bad = roofline_violations(rec["roofline"])
+                rec["roofline"]["consistency"] = "ok: no fraction above 1" if not bad else {"violations": bad}
+                if bad:
+                    print("bench.py: ERROR -- physically impossible roofline fractions (accounting defect): " + "; ".join(bad), file=sys.stderr)
         if fid is not None:
             rec["fidelity"] = fid
         from virtex_amd.modules import visual_backbones as vbm

@@ -392,7 +392,8 @@ int vtx_dropout_bwd(int dtype, const void* dx, void* dy, long n, float p_drop, u
 int vtx_optim_chunk_elems(void);
 int vtx_sumsq(const float* x, long n, float* partials /*>=1024 floats*/, float* out /*[1]*/, void* stream);
 int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float* slow, const long long* chunk_off,
-                           const int* chunk_len, const int* chunk_seg, int nchunks, const float* seg_lr,
+                           const int* chunk_len, const int* chunk_seg, int nchunks,
+                           long n_elems /* sum of chunk_len: the profiler's byte count only (<= 0: unknown) */, const float* seg_lr,
                            const float* seg_wd, float lr_mult, float momentum, float grad_scale,
                            const float* sumsq, float max_norm, int do_lookahead, float alpha, void* stream);
 /* The same step with the two per-step scalars in DEVICE memory -- sched[0] = LR multiplier (reference:
@@ -401,7 +402,7 @@ int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float* slow, cons
  * arguments.  vtx_set_dropout_epoch registers a device word that every dropout-carrying kernel mixes into its seed for
  * the same reason (NULL switches it off). */
 int vtx_sgd_lookahead_step_dev(float* p, const float* g, float* m, float* slow, const long long* chunk_off,
-                               const int* chunk_len, const int* chunk_seg, int nchunks, const float* seg_lr,
+                               const int* chunk_len, const int* chunk_seg, int nchunks, long n_elems, const float* seg_lr,
                                const float* seg_wd, const float* sched /*[2], device*/, float momentum, float grad_scale,
                                const float* sumsq, float max_norm, float alpha, void* stream);
 int vtx_set_dropout_epoch(const void* dev_u32);

@@ -244,6 +244,9 @@ inline hipemu_f32x16 hipemu_mfma_32x32x2_f32(float a, float b, hipemu_f32x16 c) 
 #define __builtin_amdgcn_wave_barrier() do { int z_ = 0; (void)hipemu::wave_exchange(&z_, sizeof(z_)); } while (0)
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+enum { hipDeviceAttributeMaxSharedMemoryPerBlock = 1 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, int attr, int) { *v = attr == hipDeviceAttributeMaxSharedMemoryPerBlock ? 160 * 1024 : 0; return hipSuccess; }   /* the emulated part is gfx950 */
 // events: the emulator runs launches synchronously, so an event is just a host timestamp
 #include <chrono>
 struct hipemuEvent { double t; };

@@ -192,6 +192,12 @@ def test_oversubscribed_huffman_table_is_refused(backend):
     big[j + 5:j + 9] = bytes([0xFF, 0xFF, 0xFF, 0xFF])   # 65535 x 65535
     with pytest.raises(_lib.VtxError, match="pixel"):
         vj.jpeg_info(bytes(big))
+    # a stream that ENDS with an empty SOS segment (FF DA 00 02) after a valid frame header: the component count would be read
+    # one byte past the buffer (Python bytes hide it behind their trailing NUL, an mmap / numpy buffer does not)
+    ok = _encode(_image(16, 16, np.random.default_rng(5)), quality=75)
+    k = ok.find(b"\xff\xda")
+    with pytest.raises(_lib.VtxError, match="empty SOS"):
+        vj.jpeg_info(ok[:k] + b"\xff\xda\x00\x02")
 
 
 def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path):
@@ -234,6 +240,10 @@ def test_host_decoder_survives_mutated_streams_under_address_sanitizer(tmp_path)
     grey = str(tmp_path / "e.jpg")
     Image.fromarray(_image(20, 28, rng)[:, :, 0].copy()).save(grey, "JPEG", quality=80)
     seeds.append(grey)
+    sos = str(tmp_path / "g.jpg")                         # ends in an empty SOS segment: exact-size buffer, one byte short of s[0]
+    blob = open(seeds[0], "rb").read()
+    open(sos, "wb").write(blob[:blob.find(b"\xff\xda")] + b"\xff\xda\x00\x02")
+    seeds.append(sos)
     probe = subprocess.run([exe, "1"] + seeds[:1], capture_output=True, text=True, timeout=120)
     if probe.returncode != 0 and "ERROR: AddressSanitizer" not in probe.stderr and "runtime error" not in probe.stderr:
         pytest.skip("the sanitizer runtime does not start in this environment: " + probe.stderr[-200:])

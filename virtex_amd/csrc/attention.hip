@@ -12,6 +12,8 @@
 // (:255-256, -inf at j >= caption_length[b]); cross-attention over the 7x7 grid gets none.
 // Q/K/V/O are addressed in place inside the packed projection outputs ([rows][ld] with a
 // per-head column offset), so no head split / merge copies exist.
+#include <atomic>
+
 #include "vtx_common.h"
 
 namespace {
@@ -650,16 +652,38 @@ static int check(const char* who, int dtype, int B, int heads, int T, int S, int
     return VTX_OK;
 }
 // the tuned kernels take T <= 32, S <= 56; anything else runs on the general kernels while its tiles fit the 160 KiB of LDS
-constexpr size_t BIG_LDS_MAX = 160 * 1024;
+// (the limit is the DEVICE's: hipDeviceAttributeMaxSharedMemoryPerBlock of the current device, 160 KiB on gfx950 -- read once;
+// a part with a smaller LDS refuses the shape here with the sizes in the message instead of failing the launch)
+static size_t big_lds_max() {
+    static std::atomic<long> cached{-1};
+    long v = cached.load(std::memory_order_relaxed);
+    if (v < 0) {
+        int dev = 0, lim = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lim <= 0) {
+            (void)hipGetLastError();
+            lim = 64 * 1024;                  // what every gfx9 part has
+        }
+        v = lim;
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return (size_t)v;
+}
 static bool tuned_shape(int T, int S) { return T <= TMAX && S <= SMAX; }
-template <class K> static int big_prepare(const char* who, K kern, int T, int S, bool bwd, size_t* lds) {
+// `reserved`: the largest dynamic-LDS size already granted to this kernel instantiation (one static per call site): the
+// attribute is set only when a launch needs more than any launch before it, not on every call
+template <class K> static int big_prepare(const char* who, K kern, int T, int S, bool bwd, size_t* lds, std::atomic<long>& reserved) {
     *lds = big_lds_bytes(T, S, bwd);
-    VTX_CHECK(*lds <= BIG_LDS_MAX, VTX_ERR_SHAPE, "%s: T=%d queries x S=%d keys need %zu bytes of LDS (limit %zu): beyond the "
-              "tuned envelope (T <= %d, S <= %d) the tiles of one (batch, head) must fit one workgroup", who, T, S, *lds, BIG_LDS_MAX, TMAX, SMAX);
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds) != hipSuccess) {
-        (void)hipGetLastError();
-        vtx_set_error("%s: cannot reserve %zu bytes of LDS", who, *lds);
-        return VTX_ERR_LAUNCH;
+    const size_t lim = big_lds_max();
+    VTX_CHECK(*lds <= lim, VTX_ERR_SHAPE, "%s: T=%d queries x S=%d keys need %zu bytes of LDS (limit %zu): beyond the "
+              "tuned envelope (T <= %d, S <= %d) the tiles of one (batch, head) must fit one workgroup", who, T, S, *lds, lim, TMAX, SMAX);
+    if ((long)*lds > reserved.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds) != hipSuccess) {
+            (void)hipGetLastError();
+            vtx_set_error("%s: cannot reserve %zu bytes of LDS", who, *lds);
+            return VTX_ERR_LAUNCH;
+        }
+        long prev = reserved.load(std::memory_order_relaxed);
+        while (prev < (long)*lds && !reserved.compare_exchange_weak(prev, (long)*lds)) {}
     }
     return VTX_OK;
 }
@@ -678,21 +702,26 @@ extern "C" int vtx_attention_fwd(int dtype, const void* q, long ldq, const void*
     dim3 grid(B * heads), block(256);
     if (dtype == VTX_BF16)
         VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, VTX_ERR_SHAPE, "attention_fwd: row strides must be multiples of 8");
+    // algorithmic work of one call (the roofline accounting of bench.py): QK^T and PV = 2 x 2 T S 64 FLOP per (batch, head);
+    // q, o (T rows) and k, v (S rows) of 64 elements each
+    const double fl_fwd = 4.0 * B * heads * T * S * 64, by_fwd = (double)B * heads * 64 * (2.0 * T + 2.0 * S);
     if (!tuned_shape(T, S)) {
         size_t lds = 0;
         if (dtype == VTX_BF16) {
             VTX_CHECK(ldo % 8 == 0, VTX_ERR_SHAPE, "attention_fwd: row strides must be multiples of 8");
-            if ((rc = big_prepare("attention_fwd", attn_fwd_big_kernel<bf16_t>, T, S, false, &lds))) return rc;
-            hipLaunchKernelGGL((attn_fwd_big_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, (bf16_t*)o);
+            static std::atomic<long> reserved{0};
+            if ((rc = big_prepare("attention_fwd", attn_fwd_big_kernel<bf16_t>, T, S, false, &lds, reserved))) return rc;
+            VTX_KLAUNCH("attention_fwd", fl_fwd, 2.0 * by_fwd, (attn_fwd_big_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, (bf16_t*)o);
         } else {
-            if ((rc = big_prepare("attention_fwd", attn_fwd_big_kernel<float>, T, S, false, &lds))) return rc;
-            hipLaunchKernelGGL((attn_fwd_big_kernel<float>), grid, block, lds, (hipStream_t)stream, a, (float*)o);
+            static std::atomic<long> reserved{0};
+            if ((rc = big_prepare("attention_fwd", attn_fwd_big_kernel<float>, T, S, false, &lds, reserved))) return rc;
+            VTX_KLAUNCH("attention_fwd", fl_fwd, 4.0 * by_fwd, (attn_fwd_big_kernel<float>), grid, block, lds, (hipStream_t)stream, a, (float*)o);
         }
         VTX_LAUNCH_CHECK();
         return VTX_OK;
     }
     if (dtype == VTX_BF16) {
-        VTX_KLAUNCH("attention_fwd", 4.0 * B * heads * T * S * 64, 2.0 * B * heads * 64 * (2.0 * T + 2.0 * S), attn_fwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 4)), block, 0, (hipStream_t)stream, a, (bf16_t*)o, B * heads);
+        VTX_KLAUNCH("attention_fwd", fl_fwd, 2.0 * by_fwd, attn_fwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 4)), block, 0, (hipStream_t)stream, a, (bf16_t*)o, B * heads);
     }
     else hipLaunchKernelGGL((attn_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, a, (float*)o);
     VTX_LAUNCH_CHECK();
@@ -713,23 +742,27 @@ extern "C" int vtx_attention_bwd(int dtype, const void* q, long ldq, const void*
     if (dtype == VTX_BF16)
         VTX_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0,
                   VTX_ERR_SHAPE, "attention_bwd: row strides must be multiples of 8 (inputs) / 4 (gradients)");
+    // scores recomputed + dP, dQ, dK, dV = 5 contractions of 2 T S 64 FLOP; q, dout, dq (T rows), k, v, dk, dv (S rows)
+    const double fl_bwd = 10.0 * B * heads * T * S * 64, by_bwd = (double)B * heads * 64 * (3.0 * T + 4.0 * S);
     if (!tuned_shape(T, S)) {
         size_t lds = 0;
         if (dtype == VTX_BF16) {
             VTX_CHECK(lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0, VTX_ERR_SHAPE, "attention_bwd: gradient row strides must be multiples of 8");
-            if ((rc = big_prepare("attention_bwd", attn_bwd_big_kernel<bf16_t>, T, S, true, &lds))) return rc;
-            hipLaunchKernelGGL((attn_bwd_big_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, (const bf16_t*)dout,
+            static std::atomic<long> reserved{0};
+            if ((rc = big_prepare("attention_bwd", attn_bwd_big_kernel<bf16_t>, T, S, true, &lds, reserved))) return rc;
+            VTX_KLAUNCH("attention_bwd", fl_bwd, 2.0 * by_bwd, (attn_bwd_big_kernel<bf16_t>), grid, block, lds, (hipStream_t)stream, a, (const bf16_t*)dout,
                                (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv);
         } else {
-            if ((rc = big_prepare("attention_bwd", attn_bwd_big_kernel<float>, T, S, true, &lds))) return rc;
-            hipLaunchKernelGGL((attn_bwd_big_kernel<float>), grid, block, lds, (hipStream_t)stream, a, (const float*)dout,
+            static std::atomic<long> reserved{0};
+            if ((rc = big_prepare("attention_bwd", attn_bwd_big_kernel<float>, T, S, true, &lds, reserved))) return rc;
+            VTX_KLAUNCH("attention_bwd", fl_bwd, 4.0 * by_bwd, (attn_bwd_big_kernel<float>), grid, block, lds, (hipStream_t)stream, a, (const float*)dout,
                                (float*)dq, (float*)dk, (float*)dv, lddq, lddk, lddv);
         }
         VTX_LAUNCH_CHECK();
         return VTX_OK;
     }
     if (dtype == VTX_BF16) {
-        VTX_KLAUNCH("attention_bwd", 10.0 * B * heads * T * S * 64, 2.0 * B * heads * 64 * (3.0 * T + 4.0 * S), attn_bwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 2)), dim3(128), 0, (hipStream_t)stream, a,
+        VTX_KLAUNCH("attention_bwd", fl_bwd, 2.0 * by_bwd, attn_bwd_mfma_kernel, dim3(vtx_cdiv(B * heads, 2)), dim3(128), 0, (hipStream_t)stream, a,
                            (const bf16_t*)dout, (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, B * heads);
     }
     else

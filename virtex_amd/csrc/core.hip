@@ -132,6 +132,13 @@ int vtx_prof_register(const char* pretty) {
     g_prof_classes.push_back(c);
     return (int)g_prof_classes.size() - 1;
 }
+int vtx_prof_register_family(const char* family, const char* kernel_expr, const char* enclosing) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const char* br = enclosing ? strchr(enclosing, '[') : nullptr;      // "[T = unsigned short, UNR = 2]" of a templated launcher
+    ProfClass c; c.name = std::string(family) + "|" + (kernel_expr ? kernel_expr : "") + "|" + (br ? br : "");
+    g_prof_classes.push_back(c);
+    return (int)g_prof_classes.size() - 1;
+}
 void vtx_prof_events(int cls, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r{prof_event(), prof_event(), cls, flops, bytes};

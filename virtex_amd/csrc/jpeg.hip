@@ -188,6 +188,7 @@ int parse(const unsigned char* d, long n, Parsed& P) {
             if (sl >= 12 && memcmp(s, "Adobe", 5) == 0 && s[11] == 0 && P.ncomp == 3) { vtx_set_error("jpeg: Adobe RGB streams are not taken"); return VTX_ERR_SHAPE; }
         } else if (m == 0xDA) {                                                     // SOS
             if (!have_sof) { vtx_set_error("jpeg: SOS before SOF"); return VTX_ERR_ARG; }
+            if (sl < 1) { vtx_set_error("jpeg: empty SOS segment"); return VTX_ERR_ARG; }   // (a stream ending in FF DA 00 02: s == d + n, s[0] is past the buffer)
             const int ns = s[0];
             if (ns != P.ncomp || sl < 1 + 2 * ns + 3) { vtx_set_error("jpeg: non-interleaved scans are not taken"); return VTX_ERR_SHAPE; }
             for (int k = 0; k < ns; ++k) {

@@ -93,14 +93,19 @@ extern "C" int vtx_sumsq(const float* x, long n, float* partials, float* out, vo
 
 static int sgd_lookahead_launch(float* p, const float* g, float* m, float* slow,
                                const long long* chunk_off, const int* chunk_len, const int* chunk_seg,
-                               int nchunks, const float* seg_lr, const float* seg_wd, float lr_mult,
+                               int nchunks, long n_elems, const float* seg_lr, const float* seg_wd, float lr_mult,
                                float momentum, float grad_scale, const float* sumsq, float max_norm,
                                int do_lookahead, float alpha, const float* sched, void* stream) {
     VTX_CHECK(p && g && m && slow && chunk_off && chunk_len && chunk_seg && seg_lr && seg_wd, VTX_ERR_ARG,
               "sgd_lookahead_step: null pointer");
     VTX_CHECK(max_norm <= 0.f || sumsq, VTX_ERR_ARG, "sgd_lookahead_step: clipping needs the sum of squares");
     if (nchunks <= 0) return VTX_OK;
-    VTX_KLAUNCH("optimizer_step", 0, 4.0 * CHUNK * (double)nchunks * (do_lookahead ? 7 : 5), sgd_lookahead_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, slow, chunk_off,
+    // algorithmic bytes: the REAL element count (chunks are padded to CHUNK only in the table, never in memory) x (g read, p and m
+    // read + written = 5 words; the Lookahead synchronisation adds slow read + written).  With the schedule on the device the
+    // host does not know the phase: the 4-of-5 ordinary steps' 5 words are counted (a lower bound, so a fraction above 1 cannot
+    // come from the accounting -- round 5 counted CHUNK x nchunks x 7 and reported 1.14 of the HBM peak)
+    const double prof_elems = n_elems > 0 ? (double)n_elems : (double)CHUNK * nchunks;
+    VTX_KLAUNCH("optimizer_step", 0, 4.0 * prof_elems * ((do_lookahead && !sched) ? 7 : 5), sgd_lookahead_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, slow, chunk_off,
                        chunk_len, chunk_seg, seg_lr, seg_wd, lr_mult, momentum, grad_scale, sumsq, max_norm,
                        do_lookahead, alpha, sched);
     VTX_LAUNCH_CHECK();
@@ -109,10 +114,10 @@ static int sgd_lookahead_launch(float* p, const float* g, float* m, float* slow,
 
 extern "C" int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float* slow,
                                       const long long* chunk_off, const int* chunk_len, const int* chunk_seg,
-                                      int nchunks, const float* seg_lr, const float* seg_wd, float lr_mult,
+                                      int nchunks, long n_elems, const float* seg_lr, const float* seg_wd, float lr_mult,
                                       float momentum, float grad_scale, const float* sumsq, float max_norm,
                                       int do_lookahead, float alpha, void* stream) {
-    return sgd_lookahead_launch(p, g, m, slow, chunk_off, chunk_len, chunk_seg, nchunks, seg_lr, seg_wd, lr_mult, momentum, grad_scale,
+    return sgd_lookahead_launch(p, g, m, slow, chunk_off, chunk_len, chunk_seg, nchunks, n_elems, seg_lr, seg_wd, lr_mult, momentum, grad_scale,
                                 sumsq, max_norm, do_lookahead, alpha, nullptr, stream);
 }
 
@@ -121,10 +126,10 @@ extern "C" int vtx_sgd_lookahead_step(float* p, const float* g, float* m, float*
 // needs (virtex_amd/graph.py keeps the step counter, the schedule and this pair on the device).
 extern "C" int vtx_sgd_lookahead_step_dev(float* p, const float* g, float* m, float* slow,
                                           const long long* chunk_off, const int* chunk_len, const int* chunk_seg,
-                                          int nchunks, const float* seg_lr, const float* seg_wd, const float* sched,
+                                          int nchunks, long n_elems, const float* seg_lr, const float* seg_wd, const float* sched,
                                           float momentum, float grad_scale, const float* sumsq, float max_norm,
                                           float alpha, void* stream) {
     VTX_CHECK(sched, VTX_ERR_ARG, "sgd_lookahead_step_dev: null schedule pointer");
-    return sgd_lookahead_launch(p, g, m, slow, chunk_off, chunk_len, chunk_seg, nchunks, seg_lr, seg_wd, 0.f, momentum, grad_scale,
+    return sgd_lookahead_launch(p, g, m, slow, chunk_off, chunk_len, chunk_seg, nchunks, n_elems, seg_lr, seg_wd, 0.f, momentum, grad_scale,
                                 sumsq, max_norm, 1, alpha, sched, stream);
 }

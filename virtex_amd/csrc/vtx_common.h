@@ -34,18 +34,21 @@ static inline int vtx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // Optional per-launch timing (vtx_profile_start / vtx_profile_stop in core.hip): while profiling is on a launch
 // carries a begin and an end HIP event (hipExtLaunchKernel: the dispatch's own timestamps, what rocprofv3 reports)
 // and its algorithmic FLOPs / HBM bytes are summed per class.  Contraction kernels register one class per
-// template instantiation (gemm_kernel.h); every other kernel goes through VTX_KLAUNCH with a family name.
+// template instantiation (gemm_kernel.h); every other kernel goes through VTX_KLAUNCH with a family name -- one class per
+// launch site AND instantiation of the enclosing launcher, registered as "family:<name>|<kernel expression>|[T = ..., ...]"
+// so that bench.py can name the single kernel instantiation a class stands for (its headline is the largest one).
 // ---------------------------------------------------------------------------------------
 namespace vtxg {
 extern int g_vtx_prof_on, g_vtx_prof_only;
 int vtx_prof_register(const char* pretty_name);
+int vtx_prof_register_family(const char* family, const char* kernel_expr, const char* enclosing_pretty);
 void vtx_prof_events(int cls, double flops, double bytes, hipEvent_t* start, hipEvent_t* stop);
 }
 #define VTX_KLAUNCH(fam, flops_, bytes_, kern, grid, block, shmem, st, ...)                                      \
     do {                                                                                                         \
         bool vtx_done_ = false;                                                                                  \
         if (vtxg::g_vtx_prof_on) {                                                                               \
-            static const int vtx_cls_ = vtxg::vtx_prof_register("family:" fam);                                  \
+            static const int vtx_cls_ = vtxg::vtx_prof_register_family("family:" fam, #kern, __PRETTY_FUNCTION__);  \
             if (vtxg::g_vtx_prof_only < 0 || vtxg::g_vtx_prof_only == vtx_cls_) {                                \
                 hipEvent_t vtx_e0_, vtx_e1_;                                                                     \
                 vtxg::vtx_prof_events(vtx_cls_, (double)(flops_), (double)(bytes_), &vtx_e0_, &vtx_e1_);         \

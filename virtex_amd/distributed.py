@@ -72,8 +72,36 @@ def init_process_group(backend: Optional[str] = None) -> int:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+        # A rank that never arrives at a collective must become an ERROR, not an endless wait: every collective of this
+        # process group carries a deadline (default 180 s, VIRTEX_AMD_COLLECTIVE_TIMEOUT_S; torch's own default is 600 s for
+        # nccl and 1800 s for gloo).  With nccl = RCCL the watchdog thread aborts the communicator and raises / tears the
+        # process down with the reason on stderr; gloo raises in the waiting thread.
+        import datetime
+        deadline = datetime.timedelta(seconds=float(os.environ.get("VIRTEX_AMD_COLLECTIVE_TIMEOUT_S", "180")))
+        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world, timeout=deadline)
     return local_rank
+
+
+def ranks_seen(device=None) -> int:
+    """All-reduce (SUM) of a one: how many ranks the process group's transport really connects.  1 without a group."""
+    if not active():
+        return 1
+    one = torch.ones(1, dtype=torch.float32, device=device if device is not None else
+                     (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    return int(round(one.item()))
+
+
+def transport_description() -> dict:
+    """Backend of the process group and, for nccl (= RCCL on ROCm), the library version torch was built against."""
+    out = {"backend": dist.get_backend() if active() else None, "world_size": world_size()}
+    if out["backend"] == "nccl":
+        try:
+            out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:          # a build without the binding: say so instead of guessing
+            out["rccl_version"] = f"unavailable ({type(e).__name__})"
+        out["hip"] = getattr(torch.version, "hip", None)
+    return out
 
 
 def _free_port() -> int:

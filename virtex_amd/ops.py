@@ -798,19 +798,20 @@ def sumsq(x, partials, out):
 
 
 def sgd_lookahead_step(p, g, m, slow, chunk_off, chunk_len, chunk_seg, seg_lr, seg_wd, lr_mult, momentum,
-                       grad_scale, sumsq_buf, max_norm, do_lookahead, alpha):
+                       grad_scale, sumsq_buf, max_norm, do_lookahead, alpha, n_elems=0):
+    """n_elems: sum of chunk_len (the profiler's algorithmic byte count; 0 = unknown)"""
     call("vtx_sgd_lookahead_step", ptr(p), ptr(g), ptr(m), ptr(slow), ptr(chunk_off), ptr(chunk_len),
-         ptr(chunk_seg), c_int(chunk_off.numel()), ptr(seg_lr), ptr(seg_wd), c_float(lr_mult), c_float(momentum),
+         ptr(chunk_seg), c_int(chunk_off.numel()), c_long(int(n_elems)), ptr(seg_lr), ptr(seg_wd), c_float(lr_mult), c_float(momentum),
          c_float(grad_scale), ptr(sumsq_buf), c_float(max_norm if max_norm else 0.0),
          c_int(1 if do_lookahead else 0), c_float(alpha), stream_ptr(p))
 
 
 def sgd_lookahead_step_dev(p, g, m, slow, chunk_off, chunk_len, chunk_seg, seg_lr, seg_wd, sched, momentum, grad_scale,
-                           sumsq_buf, max_norm, alpha):
+                           sumsq_buf, max_norm, alpha, n_elems=0):
     """sched: fp32[2] on the device = {LR multiplier, Lookahead-sync flag} of this step (graph-capturable form)"""
     _chk(sched, "sched", torch.float32)
     call("vtx_sgd_lookahead_step_dev", ptr(p), ptr(g), ptr(m), ptr(slow), ptr(chunk_off), ptr(chunk_len),
-         ptr(chunk_seg), c_int(chunk_off.numel()), ptr(seg_lr), ptr(seg_wd), ptr(sched), c_float(momentum),
+         ptr(chunk_seg), c_int(chunk_off.numel()), c_long(int(n_elems)), ptr(seg_lr), ptr(seg_wd), ptr(sched), c_float(momentum),
          c_float(grad_scale), ptr(sumsq_buf), c_float(max_norm if max_norm else 0.0), c_float(alpha), stream_ptr(p))
 
 

@@ -13,6 +13,7 @@ synchronisation happens inside ``step()``.  State dicts of both are indexed in `
 order -- the order the reference's OptimizerFactory builds its one-tensor param groups in
 (virtex/factories.py:529-533) -- so checkpoints interchange with the reference's Lookahead(SGD).
 """
+import ctypes
 import math
 import re
 import weakref
@@ -24,33 +25,47 @@ from .streams import branch_stream, wgrad_stream
 
 NO_DECAY = r".*textual.(embedding|transformer).*(norm.*|bias)"
 
-# ---- the device word every dropout kernel mixes into its seed (vtx_set_dropout_epoch): one per device, reference-counted.
-# The C side keeps ONE process-global pointer (one process drives one GPU: DESIGN.md 7), so a registration for a second
-# device while the first is held is refused instead of silently re-pointing the first device's kernels.
-_epoch_words = {}     # device -> tensor (kept for the life of the process: 4 bytes; the registered address never dangles)
-_epoch_refs = {}      # device -> number of optimizers with an enabled device schedule
+# ---- the device word every dropout kernel mixes into its seed (vtx_set_dropout_epoch): one per (loaded library, device),
+# reference-counted.  The C side keeps ONE pointer per loaded library (one process drives one GPU: DESIGN.md 7), so a
+# registration for a second device through the SAME library while the first is held is refused instead of silently re-pointing
+# the first device's kernels.  Two libraries in one process (the HIP build and the tests' emulator build) have independent
+# globals and therefore independent registrations: the key carries the library handle.
+_epoch_words = {}     # (library handle, device) -> tensor (kept for the life of the process: 4 bytes; the address never dangles)
+_epoch_refs = {}      # (library handle, device) -> number of optimizers with an enabled device schedule
+# Every optimizer on the device-side schedule advances the word once per step of ITS OWN (N optimizers stepping in one process
+# give N increments per iteration).  That is deliberate: a launch recording bakes its optimizer's increment into the recorded
+# list, so "one owner advances" would silently stop the masks of a replay whose optimizer is not the owner, or freeze them when
+# the owner is released.  The masks only have to CHANGE from step to step and be equal between the forward and the backward
+# of one step, which any monotone word gives.
+
+
+def _epoch_key(device):
+    from . import _lib
+    handle = _lib.lib()
+    return (handle._handle, torch.device(device)), handle
 
 
 def _epoch_acquire(device, ops):
-    held = [d for d, n in _epoch_refs.items() if n > 0 and d != device]
+    key, handle = _epoch_key(device)
+    held = [k for k, n in _epoch_refs.items() if n > 0 and k[0] == key[0] and k[1] != key[1]]
     if held:
-        raise RuntimeError(f"a device dropout epoch is registered for {held[0]}; the library holds one registration per "
+        raise RuntimeError(f"a device dropout epoch is registered for {held[0][1]}; the library holds one registration per "
                            f"process (one process per GPU) -- disable that optimizer's device schedule first")
-    word = _epoch_words.get(device)
+    word = _epoch_words.get(key)
     if word is None:
-        word = _epoch_words[device] = torch.zeros(1, dtype=torch.int32, device=device)
-    if _epoch_refs.get(device, 0) == 0:
+        word = _epoch_words[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    if _epoch_refs.get(key, 0) == 0:
         ops.set_dropout_epoch(word)
-    _epoch_refs[device] = _epoch_refs.get(device, 0) + 1
-    return word
+    _epoch_refs[key] = _epoch_refs.get(key, 0) + 1
+    return word, key, handle
 
 
-def _epoch_release(device, ops):
-    n = _epoch_refs.get(device, 0) - 1
-    _epoch_refs[device] = max(n, 0)
+def _epoch_release(key, handle):
+    n = _epoch_refs.get(key, 0) - 1
+    _epoch_refs[key] = max(n, 0)
     if n == 0:
         try:
-            ops.set_dropout_epoch(None)
+            handle.vtx_set_dropout_epoch(ctypes.c_void_p(0))     # on the library that holds the registration
         except Exception:        # interpreter shutdown: the library may already be gone
             pass
 
@@ -205,6 +220,7 @@ class FusedPretrainOptimizer:
                 for c0 in range(0, n, chunk):
                     offs.append(off + c0); lens.append(min(chunk, n - c0)); segs.append(si)
                 off += n
+        self.n_elems = int(sum(lens))
         self.chunk_off = torch.tensor(offs, dtype=torch.int64, device=dev)
         self.chunk_len = torch.tensor(lens, dtype=torch.int32, device=dev)
         self.chunk_seg = torch.tensor(segs, dtype=torch.int32, device=dev)
@@ -245,7 +261,7 @@ class FusedPretrainOptimizer:
         mult = lr_multiplier(self.step_idx, self.total_steps, self.warmup_steps)
         self.ops.sgd_lookahead_step(self.flat_p, g, self.flat_m, self.flat_slow, self.chunk_off, self.chunk_len,
                                     self.chunk_seg, self.seg_lr, self.seg_wd, mult, self.momentum, grad_scale,
-                                    self.sumsq, self.clip_norm, look, self.alpha)
+                                    self.sumsq, self.clip_norm, look, self.alpha, n_elems=self.n_elems)
         # the kernel wrote the parameters behind torch's back: bump their version counters so that everything
         # keyed on them (the eval-mode folded weights, autograd's saved-tensor checks) sees the update
         for p in self.buckets.params:
@@ -266,8 +282,9 @@ class FusedPretrainOptimizer:
         self.dev = {"step": torch.tensor([float(self.step_idx)], dtype=torch.float32, device=d),
                     "kc": torch.tensor([float(self.kc)], dtype=torch.float32, device=d),
                     "sched": torch.zeros(2, dtype=torch.float32, device=d),
-                    "epoch": _epoch_acquire(d, self.ops)}
-        self._epoch_release = weakref.finalize(self, _epoch_release, d, self.ops)
+                    "epoch": None}
+        self.dev["epoch"], key, handle = _epoch_acquire(d, self.ops)
+        self._epoch_release = weakref.finalize(self, _epoch_release, key, handle)
 
     def disable_device_schedule(self):
         if self.dev is None:
@@ -299,7 +316,7 @@ class FusedPretrainOptimizer:
         sched[1:2].copy_(look)
         self.ops.sgd_lookahead_step_dev(self.flat_p, g, self.flat_m, self.flat_slow, self.chunk_off, self.chunk_len,
                                         self.chunk_seg, self.seg_lr, self.seg_wd, sched, self.momentum, grad_scale,
-                                        self.sumsq, self.clip_norm, self.alpha)
+                                        self.sumsq, self.clip_norm, self.alpha, n_elems=self.n_elems)
         st.add_(1.0)
         dv["epoch"].add_(1)
         capturing = self.flat_p.is_cuda and torch.cuda.is_current_stream_capturing()

@@ -375,7 +375,33 @@ class StepReplay:
         return ts
 
     def _validate(self):
-        """Recording on batch X, comparison on batch Y: a recorded launch that runs too early (a stream dependency the
+        """The local comparison, then the verdict of ALL ranks.  Whatever happens locally -- a mismatch, but also an exception
+        on the way (out of memory while cloning the state, a failing restore) -- this rank still arrives at the verdict
+        collective and contributes "no": a rank that left early would fall back to the eager step and issue bucket all-reduces
+        while its peers sit in the one-element MIN all-reduce (mismatched collectives: a hang or silent corruption)."""
+        err, bad = None, []
+        try:
+            bad = self._validate_local()
+        except Exception as e:                               # reported after the collective
+            err, bad = e, [f"{type(e).__name__}: {e}"]
+        # Data parallel: every rank validated on its own batch, and every rank must take the same decision -- a rank that alone
+        # falls back to the eager step issues a different number of gradient exchanges than its peers and the job hangs.  The
+        # verdict is therefore the minimum over the ranks (one more collective, at the same point of every rank's sequence).
+        peers_ok = True
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            dev = next(self.model.parameters()).device
+            flag = torch.tensor([0.0 if bad else 1.0], device=dev if dev.type == "cuda" else "cpu")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            peers_ok = bool(flag.item() > 0.5)
+        if err is not None:
+            raise RuntimeError(f"StepReplay: validation could not be completed on this rank ({bad[0]})") from err
+        if bad:
+            raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step: " + "; ".join(bad[:4]))
+        if not peers_ok:
+            raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step on another rank")
+
+    def _validate_local(self):
+        """-> list of differences (empty = the recording reproduces the eager step).  Recording on batch X, comparison on batch Y: a recorded launch that runs too early (a stream dependency the
         recording lost) reads what the recording left in its buffers -- X-values -- and that shows only when the reference
         values come from a different batch."""
         from .modules.textual_heads import dropout_seed_state
@@ -428,16 +454,4 @@ class StepReplay:
         for k, v in self.static.items():
             v.copy_(restored_batch[k])
         restore()
-        # Data parallel: every rank validated on its own batch, and every rank must take the same decision -- a rank that alone
-        # falls back to the eager step issues a different number of gradient exchanges than its peers and the job hangs.  The
-        # verdict is therefore the minimum over the ranks (one more collective, at the same point of every rank's sequence).
-        peers_ok = True
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            dev = next(self.model.parameters()).device
-            flag = torch.tensor([0.0 if bad else 1.0], device=dev if dev.type == "cuda" else "cpu")
-            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-            peers_ok = bool(flag.item() > 0.5)
-        if bad:
-            raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step: " + "; ".join(bad[:4]))
-        if not peers_ok:
-            raise RuntimeError("StepReplay: the replayed step does not reproduce the eager step on another rank")
+        return bad
