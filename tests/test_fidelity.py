@@ -29,8 +29,8 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 STATES = ("reference_init", "random_bn3x0.2")
 
 
-def _oracle(state):
-    om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, randomize=(state != "reference_init"))
+def _oracle(state, **kw):
+    om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, randomize=(state != "reference_init"), **kw)
     if state == "random_bn3x0.2":
         with torch.no_grad():
             for n, p in om.named_parameters():
@@ -50,8 +50,8 @@ def _oracle_grads(om, batch, autocast=None):
     return out["loss"].item(), {n: p.grad.detach().clone() for n, p in om.named_parameters()}
 
 
-def _hip(om, dtype, dev):
-    m = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=dtype)
+def _hip(om, dtype, dev, **kw):
+    m = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=dtype, **kw)
     m.load_state_dict(om.state_dict())
     return m.to(dev).train()
 
@@ -120,6 +120,55 @@ def test_bf16_step_against_fp32_step_b32_calibrated_on_autocast(state):
     assert ob["median_rel"] <= 1.25 * cb["median_rel"], (ob, cb)
     assert ob["max_rel"] <= 1.5 * cb["max_rel"], (ob, cb)
     assert ob["min_cos"] >= cb["min_cos"] - 0.03, (ob, cb)
+    assert ours["text"]["max_rel"] <= max(1e-2, 1.5 * cal["text"]["max_rel"]), (ours["text"], cal["text"])
+    assert ours["text"]["min_cos"] >= 0.995
+
+
+# BASELINE.json configs 4 and 5: the depth ablation (configs/depth_ablations/bicaptioning_R_50_L4_H1024.yaml:1-5) and ResNet-101
+# (configs/backbone_ablations/bicaptioning_R_101_L1_H1024.yaml:1-5) with the width ablation's head
+# (configs/width_ablations/bicaptioning_R_50_L1_H2048.yaml:1-5).  Both are BENCHMARKED in bf16 (profiles/r0N_bench_config{4,5}.json)
+# and run kernels the default configuration does not: config 4's dominant 64-deep 128x128 text GEMM, config 5's 32-head
+# attention and the R-101 shapes through the bf16 BatchNorm epilogues.
+OTHER_CONFIGS = {"config4": dict(visual="torchvision::resnet50", textual="transdec_postnorm::L4_H1024_A16_F4096"),
+                 "config5": dict(visual="torchvision::resnet101", textual="transdec_postnorm::L1_H2048_A32_F8192")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("state", STATES)
+@pytest.mark.parametrize("config", sorted(OTHER_CONFIGS))
+def test_bf16_step_of_baseline_configs_4_and_5_against_the_oracle(config, state):
+    """The bf16 HIP step of BASELINE configs 4 / 5 DIRECTLY against the fp32 CPU oracle at B = 16, 224 x 224 (loss, every
+    text-side and every backbone gradient), with the autocast-calibrated rule of the default configuration's test above:
+    ours may not be further from the oracle's fp32 gradients than `torch.autocast(bfloat16)` of the oracle itself is
+    (measured in place; it must itself be a signal).  The fp32 HIP step of the same weights pins the path to the oracle
+    on the same batch (loss 1e-5, text gradients 1e-3)."""
+    dev = select("gpu")
+    kw = OTHER_CONFIGS[config]
+    om = _oracle(state, **kw)
+    batch = synth.synthetic_batch(16, image_size=224, seed=3, ragged=True)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    l32, g32 = _oracle_grads(om, batch)
+    lac, gac = _oracle_grads(copy.deepcopy(om), batch, autocast=torch.bfloat16)
+    cal = fidelity.summarize(fidelity.gradient_distance(gac, g32))       # PyTorch's own bf16 AMP of the reference
+    lh32, gh32 = fidelity.run_grads(_hip(om, torch.float32, dev, **kw), dbatch)
+    lh16, gh16 = fidelity.run_grads(_hip(om, torch.bfloat16, dev, **kw), dbatch)
+    ours = fidelity.summarize(fidelity.gradient_distance(gh16, g32))     # bf16 HIP against the ORACLE's fp32 gradients
+    pin = fidelity.summarize(fidelity.gradient_distance(gh32, g32))      # fp32 HIP against the oracle
+    _dump(f"fidelity_bf16_b16_{config}_{state}.json", {"autocast_bf16_vs_fp32_oracle": cal, "hip_bf16_vs_fp32_oracle": ours,
+                                                       "hip_fp32_vs_fp32_oracle": pin,
+                                                       "loss": {"oracle": l32, "autocast": lac, "hip_fp32": lh32, "hip_bf16": lh16}})
+    assert abs(lh32 - l32) < 1e-5 * abs(l32)
+    assert abs(lh16 - l32) <= max(2e-4 * abs(l32), 2.0 * abs(lac - l32))
+    assert pin["text"]["max_rel"] < 1e-3 and pin["backbone"]["median_rel"] < 3e-2
+    ob, cb = ours["backbone"], cal["backbone"]
+    assert ob["tensors"] == cb["tensors"]
+    # the calibration must be a signal before it may serve as a bound (measured on the oracle alone: reference initialisation
+    # 0.163 / 0.979 and 0.175 / 0.977; randomised BatchNorm state 0.358 / 0.873 and, for the 101-layer backbone, 0.603 / 0.682)
+    floor = 0.95 if state == "reference_init" else (0.80 if config == "config4" else 0.55)
+    assert cb["min_cos"] >= floor, cb
+    assert ob["median_rel"] <= 1.25 * cb["median_rel"], (ob, cb)
+    assert ob["max_rel"] <= 1.5 * cb["max_rel"], (ob, cb)
+    assert ob["min_cos"] >= cb["min_cos"] - (0.03 if state == "reference_init" else 0.06), (ob, cb)
     assert ours["text"]["max_rel"] <= max(1e-2, 1.5 * cal["text"]["max_rel"]), (ours["text"], cal["text"])
     assert ours["text"]["min_cos"] >= 0.995
 

@@ -880,3 +880,89 @@ def test_fused_conv3_backward_leaves_the_step_unchanged(backend):
     for n, v in rels.items():
         if "cnn" not in n:
             assert v < 1e-5 or "embedding" in n, (n, v)                           # nothing upstream of the backbone moves
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ONE Bottleneck, forward + backward with a supplied upstream gradient, fp32, against the fp64 oracle at a FLAT 1e-3
+# (VERDICT round 5, item 1b).  The whole-backbone gradients are held to a calibrated rule (`backbone_rule`) because 53
+# BatchNorm backward projections amplify rounding until the reference's own fp32 differs from its fp64 by ~2 %; a single
+# block is short enough for that argument not to apply, so here the north-star bound itself is asserted: output, input
+# gradient, the three (four) weight gradients, every BatchNorm gamma / beta gradient and the running statistics.
+# Block = torchvision Bottleneck v1.5, reached from /root/reference/virtex/modules/visual_backbones.py:68-74.
+# ----------------------------------------------------------------------------------------------------------------------
+BOTTLENECK_CASES = {   # name: (stage, block, channels in, [(backend, batch, height)])
+    "stage1_block0_downsample": (1, 0, 64, {"emu": (2, 8), "gpu": (8, 56)}),
+    "stage1_block1_identity": (1, 1, 256, {"emu": (2, 8), "gpu": (8, 56)}),
+    "stage4_block0_downsample_stride2": (4, 0, 1024, {"gpu": (8, 14)}),
+    "stage4_block1_identity": (4, 1, 2048, {"gpu": (8, 7)}),
+    "stage2_block0_downsample_stride2": (2, 0, 256, {"emu": (2, 8)}),
+}
+
+
+def _single_bottleneck(case, backend, dtype):
+    import copy
+    stage, blk, cin, sizes = BOTTLENECK_CASES[case]
+    if backend not in sizes:
+        pytest.skip(f"{case} is not run on {backend}")
+    dev = select(backend)
+    B, H = sizes[backend]
+    oracle_model = synth.seeded_model(port.build_model, seed=0, dropout=0.0, textual="transdec_postnorm::L1_H128_A2_F256",
+                                      vocab_size=304).train()
+    model = vf.build_bicaptioning_model(textual="transdec_postnorm::L1_H128_A2_F256", vocab_size=304, dropout=0.0,
+                                        compute_dtype=dtype)
+    model.load_state_dict(oracle_model.state_dict())
+    model = model.to(dev).train()
+    g = torch.Generator().manual_seed(100 * stage + blk)
+    x = torch.relu(torch.randn(B, cin, H, H, generator=g))                  # a block's input is a ReLU output
+    oblk = getattr(oracle_model.visual.cnn, f"layer{stage}")[blk]
+    o64 = copy.deepcopy(oblk).double().train()
+    o32 = copy.deepcopy(oblk).train()
+    x64 = x.double().requires_grad_(True)
+    y64 = o64(x64)
+    up = torch.randn(y64.shape, generator=g)                                # the supplied upstream gradient
+    y64.backward(up.double())
+    x32 = x.clone().requires_grad_(True)
+    y32 = o32(x32)
+    y32.backward(up)
+    xd = x.to(dev).requires_grad_(True)
+    model.zero_grad(set_to_none=True)
+    y = model.visual.forward_blocks(xd, stage, blk, 1)
+    assert y.shape == y64.shape
+    y.backward(up.to(dev))
+    mine = getattr(model.visual.cnn, f"layer{stage}")[blk]
+    rows = [("output", rel_err(y.detach().float().cpu(), y64.detach()), rel_err(y32.detach(), y64.detach())),
+            ("input_gradient", rel_err(xd.grad.float().cpu(), x64.grad), rel_err(x32.grad, x64.grad))]
+    for (n, p), (_, q64), (_, q32) in zip(mine.named_parameters(), o64.named_parameters(), o32.named_parameters()):
+        assert p.grad is not None, n
+        rows.append((n, rel_err(p.grad.float().cpu(), q64.grad), rel_err(q32.grad, q64.grad)))
+    bufs = [(n, rel_err(b.float().cpu(), b64)) for (n, b), (_, b64) in zip(mine.named_buffers(), o64.named_buffers())
+            if b.dtype.is_floating_point]
+    counters = [(n, int(b), int(b64)) for (n, b), (_, b64) in zip(mine.named_buffers(), o64.named_buffers())
+                if not b.dtype.is_floating_point]
+    return rows, bufs, counters
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", sorted(BOTTLENECK_CASES))
+def test_single_bottleneck_fp32_flat_1e3(backend, case):
+    rows, bufs, counters = _single_bottleneck(case, backend, torch.float32)
+    if backend == "gpu":
+        _dump_rows(f"parity_fp32_bottleneck_{case}.json", {"bound": 1e-3, "worst": max(rows, key=lambda r: r[1])}, rows)
+    for n, mine, ref in rows:
+        assert mine < 1e-3, (case, n, mine, "the reference's own fp32 vs fp64:", ref)       # flat: no calibration
+    for n, e in bufs:
+        assert e < 1e-4, (case, n, e)
+    for n, a, b in counters:
+        assert a == b, (case, n, a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["stage1_block1_identity", "stage4_block0_downsample_stride2"])
+def test_single_bottleneck_bf16_gpu(case):
+    """The benchmarked precision through the same entry point (fused BatchNorm epilogues, bit masks): bf16 storage bounds."""
+    rows, bufs, _ = _single_bottleneck(case, "gpu", torch.bfloat16)
+    _dump_rows(f"parity_bf16_bottleneck_{case}.json", {"bound": 3e-2, "worst": max(rows, key=lambda r: r[1])}, rows)
+    for n, mine, _ in rows:
+        assert mine < 3e-2, (case, n, mine)
+    for n, e in bufs:
+        assert e < 1e-2, (case, n, e)

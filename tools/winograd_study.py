@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""Winograd F(2x2, 3x3) for the stride-1 3x3 convolutions at 14x14 / 7x7: costed once, on paper and on the oracle
+(`north_star` names "direct/Winograd 3x3 convs", SURVEY 7.1 step 7 schedules it).
+
+    python tools/winograd_study.py [--batch 16] > profiles/r06_winograd_estimate.txt        (CPU only, ~2 min)
+
+Three parts:
+  1. arithmetic: MFMA work saved against the transform work and bytes added, per layer class at bs 256, with this build's
+     measured direct-convolution times (profiles/r05_kernel_stats_serial.txt / r04_gen3_per_shape_lean_epilogue.txt);
+  2. numerics of ONE layer: a bf16 Winograd convolution (fp32 transforms, transformed operands U = G g G^T and V = B^T d B rounded
+     to bf16 for the MFMA, fp32 accumulation, fp32 output transform) against the direct bf16-operand / fp32-accumulate
+     convolution the kernels run today, on post-ReLU activations and Kaiming weights of the real shapes;
+  3. fidelity of the STEP on the oracle: `torch.autocast(bfloat16)` of the reference model with the 14x14 / 7x7 stride-1 3x3
+     convolutions (forward and input gradient) replaced by that Winograd emulation, against the fp32 oracle -- next to plain
+     autocast against the fp32 oracle (the calibration band of tests/test_fidelity.py: ours may not exceed 1.25x its median).
+No HIP involved: the question is whether the ALGORITHM fits the precision budget and the time budget before a kernel is written.
+"""
+import argparse
+import copy
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# F(2x2, 3x3) matrices (Lavin & Gray 2016)
+BT = torch.tensor([[1., 0., -1., 0.], [0., 1., 1., 0.], [0., -1., 1., 0.], [0., 1., 0., -1.]])
+G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]])
+AT = torch.tensor([[1., 1., 1., 0.], [0., 1., -1., -1.]])
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def winograd_conv3x3(x, w, round_operands=True):
+    """x (N,C,H,W) fp32 (already bf16-valued), w (K,C,3,3): stride 1, padding 1, H and W even.  Returns fp32 (N,K,H,W)."""
+    N, C, H, W = x.shape
+    K = w.shape[0]
+    xp = F.pad(x, (1, 1, 1, 1))
+    # 4x4 input tiles at stride 2: (N, C, H/2, W/2, 4, 4)
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)
+    V = torch.einsum("ij,ncthjk,lk->ncthil", BT, d, BT)              # B^T d B
+    U = torch.einsum("ij,kcjl,ml->kcim", G, w, G)                    # G g G^T
+    if round_operands:
+        V, U = bf16_round(V), bf16_round(U)
+    M = torch.einsum("ncthil,kcil->nkthil", V, U)                    # 16 independent contractions over c (fp32 accumulate)
+    Y = torch.einsum("ij,nkthjl,ml->nkthim", AT, M, AT)              # A^T M A -> (N, K, H/2, W/2, 2, 2)
+    return Y.permute(0, 1, 2, 4, 3, 5).reshape(N, K, H, W)
+
+
+class WinogradConvFn(torch.autograd.Function):
+    """forward and input gradient through the Winograd emulation (the input gradient of a stride-1 / pad-1 3x3 convolution is
+    the same convolution with the taps flipped and the channel roles swapped), weight gradient direct (it is not a 3x3
+    convolution over the image: Winograd does not apply)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xb, wb = bf16_round(x.float()), bf16_round(w.float())
+        ctx.save_for_backward(xb, wb)
+        return bf16_round(winograd_conv3x3(xb, wb)).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        dyb = bf16_round(dy.float())
+        wflip = wb.flip(2, 3).transpose(0, 1).contiguous()
+        dx = bf16_round(winograd_conv3x3(dyb, wflip))
+        dw = torch.nn.grad.conv2d_weight(xb, wb.shape, dyb, stride=1, padding=1)
+        return dx.to(dy.dtype), dw.to(dy.dtype)
+
+
+class WinogradConv(torch.nn.Module):
+    def __init__(self, conv):
+        super().__init__()
+        self.weight = conv.weight
+
+    def forward(self, x):
+        return WinogradConvFn.apply(x, self.weight)
+
+
+def swap_in_winograd(model, sizes=(14, 7), image=224):
+    """Replace conv2 (stride 1) of the Bottlenecks whose feature map is `sizes` pixels wide.  Returns how many."""
+    n = 0
+    cnn = model.visual.cnn
+    side = {1: image // 4, 2: image // 8, 3: image // 16, 4: image // 32}
+    for s in range(1, 5):
+        for blk in getattr(cnn, f"layer{s}"):
+            if blk.conv2.stride[0] == 1 and side[s] in sizes and side[s] % 2 == 0:
+                blk.conv2 = WinogradConv(blk.conv2)
+                n += 1
+    return n
+
+
+def part1():
+    print("== 1. arithmetic at bs 256 (bf16, MI355X; direct-convolution times are this build's measured ones) ==")
+    print("F(2x2,3x3): 16 multiplies per 2x2 outputs per (c, k) instead of 36 -> MFMA work / 2.25; as GEMMs: 16 products")
+    print("[P/4 tiles x C] x [C x K], one per transform position.  Transforms: input B^T d B = 32 add/sub per 4x4 tile and channel")
+    print("(8 VALU per input element of the tile, shared by all K), output A^T M A = 24 add per tile and OUTPUT channel on the")
+    print("fp32 accumulators (6 VALU per output element, not shared by anything).")
+    print()
+    rows = [  # name, P (pixels at bs 256), C, K, launches fwd+dgrad per step (ResNet-50), measured us per launch (direct)
+        ("256->256 @14x14", 256 * 14 * 14, 256, 256, 2 * 5, 60.0),
+        ("512->512 @7x7", 256 * 7 * 7, 512, 512, 2 * 2, 72.0),
+    ]
+    print(f"{'layer':18s} {'launches':>8s} {'direct GFLOP':>12s} {'direct us':>9s} {'wino GFLOP':>10s} {'MFMA us @ same eff.':>20s} "
+          f"{'out-transform VALU us':>22s} {'in-transform VALU us':>21s} {'V bytes if in HBM':>18s}")
+    tot_direct = tot_wino = 0.0
+    for name, P, C, K, launches, us in rows:
+        gf = 2.0 * 9 * P * C * K / 1e9
+        gw = gf / 2.25
+        eff = (gf / us) / 2.5                                 # GFLOP / us = PFLOP/s; fraction of 2.5 PF the direct layer reaches
+        mfma_us = gw / (2.5 * eff)
+        # VALU: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s (fp32 adds, no packed credit: the data are fp32 accumulators)
+        valu = 256 * 4 * 16 * 2.4e9
+        out_us = 6.0 * P * K / valu * 1e6 * 1.5                # + cvt/pack/moves: x1.5
+        in_us = 8.0 * P * C / valu * 1e6 * 1.5
+        vbytes = 4.0 * P * C * 2                                # 16 values per 4 input pixels, bf16
+        t_w = mfma_us + out_us + in_us
+        tot_direct += launches * us
+        tot_wino += launches * t_w
+        print(f"{name:18s} {launches:8d} {gf:12.1f} {us:9.1f} {gw:10.1f} {mfma_us:20.1f} {out_us:22.1f} {in_us:21.1f} {vbytes / 1e6:15.0f} MB")
+    print()
+    print(f"sum over the {sum(r[4] for r in rows)} launches: direct {tot_direct / 1e3:.2f} ms, Winograd (MFMA at the direct kernel's efficiency + "
+          f"transform VALU serialised with it, transforms fused so that V never reaches HBM) {tot_wino / 1e3:.2f} ms")
+    print(f"  -> UPPER bound of the gain: {(tot_direct - tot_wino) / 1e3:.2f} ms of the 22.8 ms step, before what a Winograd kernel loses that this")
+    print("     model does not price: (a) the 16 products have K = C = 256 / 512 only, i.e. 4-8 K tiles of 64 per output tile, where the")
+    print("     generation-3 kernel spends 4 400 of ~13 000 cycles in its prologue (pick_gen3's own model); (b) the A operand can no longer")
+    print("     arrive by LDS-DMA -- B^T d B needs the 4x4 patch in registers, so the loader is the register-staged form (global -> VGPR ->")
+    print("     transform -> ds_write) that cdna_hip_programming.md's staging table prices at 11-17 % (2-deep register ring) to 2.6x")
+    print("     (synchronous) slower than LDS-DMA for an MFMA-bound tile, and that this library left in round 2; (c) the output")
+    print("     transform needs the 16 accumulator tiles of one 2x2 output block in ONE lane or an LDS exchange: 16 x the accumulator")
+    print("     registers per output, i.e. tiles of 64x64 outputs at most under 128 accumulator VGPRs, a quarter of today's 256x128;")
+    print("     (d) the weight gradient (a third of the layer's backward work) does not benefit at all.")
+    print("     At 28x28 / 56x56 the layers are HBM-leaning (0.5-0.6 of the HBM roof, 0.15-0.25 of MFMA): fewer MACs buy nothing there.")
+    print()
+
+
+def part2():
+    print("== 2. numerics of one layer: bf16 Winograd against the direct bf16-operand convolution (both fp32 accumulate) ==")
+    torch.manual_seed(0)
+    for name, C, H in (("256->256 @14x14", 256, 14), ("512->512 @7x7 (padded to 8x8 for the even-size tiling)", 512, 8)):
+        x = bf16_round(torch.relu(torch.randn(8, C, H, H)))
+        w = bf16_round(torch.randn(C, C, 3, 3) * (2.0 / (C * 9)) ** 0.5)
+        ref64 = F.conv2d(x.double(), w.double(), padding=1)
+        direct = F.conv2d(x, w, padding=1)
+        wino = winograd_conv3x3(x, w, round_operands=True)
+        wino_exact = winograd_conv3x3(x, w, round_operands=False)
+        rel = lambda a: ((a.double() - ref64).norm() / ref64.norm()).item()
+        print(f"{name}: relative L2 error against the fp64 convolution of the same bf16 operands")
+        print(f"    direct, fp32 accumulate                      {rel(direct):.2e}")
+        print(f"    Winograd, fp32 transforms, operands NOT rounded {rel(wino_exact):.2e}")
+        print(f"    Winograd, U and V rounded to bf16 (MFMA inputs) {rel(wino):.2e}")
+        print(f"    (the bf16 STORAGE rounding of the output, which both forms pay afterwards: {rel(bf16_round(direct)):.2e})")
+    print()
+
+
+def part3(batch):
+    print(f"== 3. fidelity of the step on the oracle (B = {batch}, 224x224, reference initialisation, dropout off) ==")
+    from oracle import bicaptioning as port, synth
+    from virtex_amd import fidelity
+    om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, randomize=False).train()
+    b = synth.synthetic_batch(batch, image_size=224, seed=3, ragged=True)
+
+    def grads(m, ac):
+        m.zero_grad(set_to_none=True)
+        if ac:
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = m(b)
+        else:
+            out = m(b)
+        out["loss"].backward()
+        return out["loss"].item(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    t0 = time.time()
+    l32, g32 = grads(om, False)
+    lac, gac = grads(copy.deepcopy(om), True)
+    mw = copy.deepcopy(om)
+    n = swap_in_winograd(mw)
+    lw, gw = grads(mw, True)
+    # parameter names are unchanged by the swap (the wrapper holds the same Parameter under `conv2.weight`)
+    plain = fidelity.summarize(fidelity.gradient_distance(gac, g32))
+    wino = fidelity.summarize(fidelity.gradient_distance(gw, g32))
+    print(f"({time.time() - t0:.0f} s on the CPU)  {n} convolutions replaced (stride-1 3x3 at 14x14; 7x7 maps are odd-sized: F(2x2) tiles need")
+    print("  an 8x8 padded map there, +31 % MFMA work at 7x7 -- priced in part 1's note, not emulated)")
+    print(f"loss: fp32 {l32:.6f}   autocast bf16 {lac:.6f}   autocast bf16 + Winograd {lw:.6f}")
+    print(f"backbone gradients vs the fp32 oracle, plain autocast bf16     : {plain['backbone']}")
+    print(f"backbone gradients vs the fp32 oracle, autocast bf16 + Winograd: {wino['backbone']}")
+    print(f"text gradients, plain / Winograd: max rel {plain['text']['max_rel']} / {wino['text']['max_rel']}")
+    ratio = wino["backbone"]["median_rel"] / plain["backbone"]["median_rel"]
+    print(f"median ratio Winograd / plain = {ratio:.3f}   (tests/test_fidelity.py allows this build 1.25x the plain-autocast median; it measures")
+    print("  1.01x today, so whatever Winograd adds comes out of a 24 % margin)")
+    print()
+    return ratio
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--skip-step", action="store_true")
+    a = ap.parse_args()
+    torch.set_num_threads(os.cpu_count() or 1)
+    print("# Winograd F(2x2,3x3) for the stride-1 3x3 convolutions at 14x14 / 7x7 -- estimate (tools/winograd_study.py)")
+    print()
+    part1()
+    part2()
+    if not a.skip_step:
+        part3(a.batch)
+
+
+if __name__ == "__main__":
+    main()

@@ -251,6 +251,62 @@ class TorchvisionVisualBackbone(VisualBackbone):
             params += [u.conv.weight, u.bn.weight, u.bn.bias]
         return _ResNetFn.apply(image, self, *params)
 
+    def forward_blocks(self, x: torch.Tensor, stage: int, first: int = 0, count: int = None) -> torch.Tensor:
+        """Bottlenecks [first, first + count) of `cnn.layer{stage}` on a (B,C,h,w) activation (training mode): what
+        `cnn.layer{stage}[first:first+count](x)` is on the reference's torchvision tree.  Differentiable wrt `x` and the
+        blocks' parameters; logical NCHW in and out, NHWC in memory."""
+        if not self.cnn.training:
+            raise RuntimeError("forward_blocks runs the training-mode schedule (batch statistics)")
+        depth = [len(getattr(self.cnn, f"layer{s}")) for s in range(1, 5)]
+        if not 1 <= stage <= 4:
+            raise ValueError(f"stage must be 1..4, got {stage}")
+        count = depth[stage - 1] - first if count is None else count
+        if first < 0 or count < 1 or first + count > depth[stage - 1]:
+            raise ValueError(f"layer{stage} has {depth[stage - 1]} Bottlenecks; asked for [{first}, {first + count})")
+        lo = sum(depth[:stage - 1]) + first
+        blocks = self._units()[1][lo:lo + count]
+        params = []
+        for u in (u for blk in blocks for u in blk if u is not None):
+            params += [u.conv.weight, u.bn.weight, u.bn.bias]
+        return _BlocksFn.apply(x, self, lo, lo + count, *params)
+
+
+class _BlocksFn(torch.autograd.Function):
+    """Bottlenecks [lo, hi) of the backbone on a (B,C,h,w) activation: the same _forward_blocks / _backward_blocks the whole
+    ResNet runs, with an autograd edge on the INPUT as well (the image has none), so that a block's forward and backward can
+    be held against the oracle in isolation (tests/test_model_parity.py::test_single_bottleneck_*)."""
+
+    @staticmethod
+    def forward(ctx, x, module, lo, hi, *params):
+        dt = module.compute_dtype
+        blocks = module._units()[1][lo:hi]
+        module._stats_epoch += 1
+        need_grad = x.requires_grad or any(p.requires_grad for p in params)
+        cur = x.permute(0, 2, 3, 1)
+        if cur.dtype != dt or not cur.is_contiguous():
+            cur = cur.to(dt).contiguous()
+        rec = {}
+        out = _forward_blocks(rec, blocks, cur, dt, need_grad, x.device)
+        ctx.module, ctx.rec, ctx.blocks, ctx.in_dtype = module, rec, blocks, x.dtype
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    @traced_backward
+    def backward(ctx, dout):
+        dt = ctx.module.compute_dtype
+        dcur = dout.permute(0, 2, 3, 1)
+        if dcur.dtype != dt or not dcur.is_contiguous():
+            dcur = dcur.to(dt).contiguous()
+        dev = dcur.device
+        grads = {}
+        dx = _backward_blocks(ctx.rec, ctx.blocks, dcur, dt, dev, grads)
+        branch_stream.join(dev)
+        wgrad_stream.join(dev)
+        out = [dx.permute(0, 3, 1, 2).to(ctx.in_dtype), None, None, None]
+        for u in (u for blk in ctx.blocks for u in blk if u is not None):
+            out += grads[u]
+        return tuple(out)
+
 
 def _stem_packed(image) -> bool:
     w = image.shape[2] if image.dtype == torch.uint8 else image.shape[-1]
@@ -385,6 +441,172 @@ class _Saved:
     __slots__ = ("a", "x", "y", "mean", "rstd", "wt", "bits")
 
 
+def _run_unit(rec, u: _Unit, a, relu, dt, need_grad, residual=None):
+    """conv -> train-mode BatchNorm (-> ReLU / residual join) of one unit; what backward needs goes into rec[u]."""
+    bn = u.bn
+    w, wt = _prep_weight(u, dt, need_wt=need_grad)
+    # the conv epilogue also produces the batch statistics (taken against the running mean)
+    x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean if FUSE_BN_STATS else None)
+    bits = None
+    if residual is not None and relu and need_grad and RELU_BITS and FUSE_BN_BWD and dt == torch.bfloat16:
+        y, mean, rstd, bits = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                         bn.num_batches_tracked, eps=bn.eps,
+                                         momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
+                                         residual=residual, stats=stats, want_bits=True)
+    else:
+        y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, eps=bn.eps,
+                                   momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
+                                   residual=residual, stats=stats)
+    s = _Saved()
+    s.a, s.x, s.y, s.mean, s.rstd, s.wt, s.bits = a, x, y, mean, rstd, wt, bits
+    rec[u] = s
+    return y
+
+
+def _forward_blocks(rec, blocks, cur, dt, need_grad, dev):
+    """The Bottlenecks `blocks` (torchvision Bottleneck v1.5, reached from the reference's forward walk
+    virtex/modules/visual_backbones.py:68-74) on the NHWC activation `cur`."""
+    for bi, (u1, u2, u3, ud) in enumerate(blocks):
+        inp = cur
+        if ud is not None:
+            # projection shortcut (1x1 conv + BN) on the branch stream, under the main branch's convolutions
+            br = branch_stream(dev, inp)
+            with br:
+                skip = _run_unit(rec, ud, inp, False, dt, need_grad)
+            t = _run_unit(rec, u1, inp, True, dt, need_grad)
+            t = _run_unit(rec, u2, t, True, dt, need_grad)
+            br.wait(skip)
+        else:
+            t = _run_unit(rec, u1, inp, True, dt, need_grad)
+            t = _run_unit(rec, u2, t, True, dt, need_grad)
+            skip = inp
+        cur = _run_unit(rec, u3, t, True, dt, need_grad, residual=skip)
+        # A block whose conv3 backward will run as the fused streaming kernel (conv3_bwd.hip) recomputes conv3's input
+        # a3 = relu(bn2(x2)) from x2 inside that kernel: a3 is not kept for backward (103 MB per stage-1 block at bs 256).
+        # The decision is the one _backward_blocks takes (same flags, same shapes); it then finds rec[u3].a is None.
+        s3 = rec[u3]
+        if (need_grad and bi + 1 < len(blocks) and FUSE_BN_BWD and FUSE_CONV3_BWD and dt == torch.bfloat16 and u3.is_gemm
+                and u3.cin_pad == u3.cin and s3.wt is not None and ops.conv3_bwd_fused_supported(cur, s3.wt.view(u3.cin, u3.cout))):
+            s3.a = None
+            rec[u2].y = None
+    return cur
+
+
+def _backward_blocks(rec, blocks, dcur, dt, dev, grads):
+    """Backward of the Bottlenecks `blocks` (last to first) from the gradient `dcur` (NHWC, compute dtype) wrt the last block's
+    output; fills grads[unit] = [dW, dgamma, dbeta] (None where the kernel accumulated into the parameter's own gradient
+    buffer) and returns the gradient wrt the first block's input."""
+    def bn_back(u: _Unit, s: _Saved, dy, masked, want_dz=False, residual=False):
+        sg, sb = gradsink.target(u.bn.weight), gradsink.target(u.bn.bias)
+        dg = sg if sg is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+        db = sb if sb is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+        # BN directly followed by ReLU: the mask is recomputed from x (one tensor less to read);
+        # BN + residual + ReLU: the mask is the saved block output
+        out = ops.bn_bwd(s.x, dy, s.y if (masked and residual) else None, u.bn.weight.detach(), s.mean, s.rstd,
+                         dg, db, want_dz=want_dz,
+                         relu_beta=u.bn.bias.detach() if (masked and not residual) else None)
+        grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
+        return out
+
+    def bn_back_fused(u: _Unit, s: _Saved, dz, st):
+        """dz is already masked and its sums are in `st` (emitted by the kernel that produced it)."""
+        sg, sb = gradsink.target(u.bn.weight), gradsink.target(u.bn.bias)
+        dg = sg if sg is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+        db = sb if sb is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
+        out = ops.bn_bwd_fused(s.x, dz, u.bn.weight.detach(), s.mean, s.rstd, dg, db, st)
+        grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
+        return out
+
+    def relu_bn(u: _Unit, s: _Saved):
+        """The fusion descriptor of an interior BatchNorm+ReLU: mask recomputed from its input."""
+        return ops.BnBwd(s.x, s.mean, s.rstd, gamma=u.bn.weight.detach(), beta=u.bn.bias.detach()) if fuse else None
+
+    def conv3_back_fused(u3: _Unit, u2: _Unit, s3: _Saved, s2: _Saved, dz, st):
+        """bn3 backward + conv3 input gradient (+ bn2 mask / sums) + conv3 weight gradient in ONE launch; the partial
+        weight gradients are folded into the parameter's gradient on the weight-gradient stream."""
+        sg, sb = gradsink.target(u3.bn.weight), gradsink.target(u3.bn.bias)
+        dg = sg if sg is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
+        db = sb if sb is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
+        dy2, st2, parts, nparts = ops.conv3_bwd_fused(dz, s3.x, u3.bn.weight.detach(), s3.mean, s3.rstd, dg, db, st,
+                                                      s3.wt.view(u3.cin, u3.cout), relu_bn(u2, s2))
+        sink = gradsink.target(u3.conv.weight, (u3.cout, 1, 1, u3.cin))
+        dw = sink if sink is not None else torch.zeros(u3.cout, 1, 1, u3.cin, dtype=torch.float32, device=dev)
+        with wgrad_stream(dev, parts):
+            ops.partials_reduce_acc(parts, nparts, dw.view(u3.cout, u3.cin))
+        grads[u3] = [None if sink is not None else dw.permute(0, 3, 1, 2), None if sg is not None else dg,
+                     None if sb is not None else db]
+        return dy2, st2
+
+    fuse = FUSE_BN_BWD and dt == torch.bfloat16
+    st3 = None                  # sums for this block's bn3, when the next block's conv1 input gradient emitted them
+    for bi in reversed(range(len(blocks))):
+        (u1, u2, u3, ud) = blocks[bi]
+        s1, s2, s3 = rec[u1], rec[u2], rec[u3]
+        fused3 = (fuse and FUSE_CONV3_BWD and st3 is not None and u3.is_gemm and u3.cin_pad == u3.cin
+                  and s3.wt is not None and ops.conv3_bwd_fused_supported(dcur, s3.wt.view(u3.cin, u3.cout)))
+        if s3.a is None and not fused3:
+            raise RuntimeError("the forward pass dropped conv3's input for the fused conv3 backward, which this backward pass "
+                               "does not take: FUSE_BN_BWD / FUSE_CONV3_BWD / vtx_set_switch('conv3_bwd') were changed between "
+                               "the forward and the backward of one step")
+        if fused3:              # one kernel below does bn3's backward, conv3's input gradient and its weight gradient
+            dz, dx3 = dcur, None
+        elif st3 is not None:   # dcur IS dz: masked by (block output > 0) in the producing epilogue
+            dz = dcur
+            dx3 = bn_back_fused(u3, s3, dz, st3)
+        else:
+            dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True, residual=True)      # dz: gradient of the identity path
+        br = None
+        if ud is not None:
+            # the shortcut's backward (BN backward, weight gradient, input gradient) on the branch stream,
+            # under the main branch's three convolutions
+            sd = rec[ud]
+            br = branch_stream(dev, dz, sd.x, sd.a, sd.mean, sd.rstd)
+            with br:
+                dxd = bn_back(ud, sd, dz, False)
+                with wgrad_stream(dev, sd.a, dxd):
+                    grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
+                dskip = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape)
+        if fused3:
+            dy2, st2 = conv3_back_fused(u3, u2, s3, s2, dz, st3)
+        else:
+            with wgrad_stream(dev, s3.a, dx3):
+                grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
+            if fuse:
+                dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape, bn=relu_bn(u2, s2))
+            else:
+                dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape), None
+        dx2 = bn_back_fused(u2, s2, dy2, st2) if st2 is not None else bn_back(u2, s2, dy2, True)
+        with wgrad_stream(dev, s2.a, dx2):
+            grads[u2][0] = _conv_wgrad(u2, s2.a, dx2)
+        if fuse:
+            dy1, st1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape, bn=relu_bn(u1, s1))
+        else:
+            dy1, st1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape), None
+        dx1 = bn_back_fused(u1, s1, dy1, st1) if st1 is not None else bn_back(u1, s1, dy1, True)
+        with wgrad_stream(dev, s1.a, dx1):
+            grads[u1][0] = _conv_wgrad(u1, s1.a, dx1)
+        if br is not None:
+            br.wait(dskip)
+            join = dskip
+        else:
+            join = dz
+        # The block's input gradient (both branches joined in the epilogue).  The block input is the previous
+        # block's output relu(bn3(x3) + skip): fuse THAT bn3's backward (mask = the saved output) into this kernel.
+        if fuse and bi > 0:
+            p3 = rec[blocks[bi - 1][2]]
+            dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join,
+                                    bn=ops.BnBwd(p3.x, p3.mean, p3.rstd, ymask=p3.y, ybits=p3.bits))
+        else:
+            dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join), None
+        # this block's gradient kernels are all enqueued: let the data-parallel engine start exchanging the
+        # buckets they complete while the rest of the backbone's backward runs
+        for u in (u3, u2, u1, ud):
+            if u is not None:
+                gradsink.mark_ready([p for p, g in zip((u.conv.weight, u.bn.weight, u.bn.bias), grads[u]) if g is None])
+    return dcur
+
+
 class _ResNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, module, *params):
@@ -393,31 +615,23 @@ class _ResNetFn(torch.autograd.Function):
         stem, blocks = module._units()
         module._stats_epoch += 1
         need_grad = any(p.requires_grad for p in params)
-        units = [stem] + [u for blk in blocks for u in blk if u is not None]
         rec = {}
 
-        def run(u: _Unit, a, relu, residual=None, first=False):
+        def run_stem(u: _Unit, a):
+            """The stem on the generic 8-channel layout (odd image widths) or with the stem tail unfused."""
             bn = u.bn
-            if first and packed:
+            if packed:
                 w, wt = _stem_weight(u, dt), None
                 x, stats = _stem_conv(u, a, w, dt)
             else:
-                w, wt = _prep_weight(u, dt, need_wt=need_grad and not first)
-                # the conv epilogue also produces the batch statistics (taken against the running mean)
+                w, wt = _prep_weight(u, dt, need_wt=False)
                 x, stats = _conv_fwd(u, a, w, bn_shift=bn.running_mean if FUSE_BN_STATS else None)
-            bits = None
-            if residual is not None and relu and need_grad and RELU_BITS and FUSE_BN_BWD and dt == torch.bfloat16:
-                y, mean, rstd, bits = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                                 bn.num_batches_tracked, eps=bn.eps,
-                                                 momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
-                                                 residual=residual, stats=stats, want_bits=True)
-            else:
-                y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
-                                           bn.num_batches_tracked, eps=bn.eps,
-                                           momentum=bn.momentum if bn.momentum is not None else 0.1, relu=relu,
-                                           residual=residual, stats=stats)
+            y, mean, rstd = ops.bn_fwd(x, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                       bn.num_batches_tracked, eps=bn.eps,
+                                       momentum=bn.momentum if bn.momentum is not None else 0.1, relu=True,
+                                       residual=None, stats=stats)
             s = _Saved()
-            s.a, s.x, s.y, s.mean, s.rstd, s.wt, s.bits = a, x, y, mean, rstd, wt, bits
+            s.a, s.x, s.y, s.mean, s.rstd, s.wt, s.bits = a, x, y, mean, rstd, wt, None
             rec[u] = s
             return y
 
@@ -434,29 +648,13 @@ class _ResNetFn(torch.autograd.Function):
             rec[stem] = s0
             y = x0                                                          # only its shape is used below
         else:
-            y = run(stem, a0, True, first=True)
+            y = run_stem(stem, a0)
             pooled, argmax = ops.maxpool_fwd(y)
-        cur = pooled
-        for (u1, u2, u3, ud) in blocks:
-            inp = cur
-            if ud is not None:
-                # projection shortcut (1x1 conv + BN) on the branch stream, under the main branch's convolutions
-                br = branch_stream(dev, inp)
-                with br:
-                    skip = run(ud, inp, False)
-                t = run(u1, inp, True)
-                t = run(u2, t, True)
-                br.wait(skip)
-            else:
-                t = run(u1, inp, True)
-                t = run(u2, t, True)
-                skip = inp
-            cur = run(u3, t, True, residual=skip)
+        cur = _forward_blocks(rec, blocks, pooled, dt, need_grad, dev)
         ctx.module, ctx.rec, ctx.argmax, ctx.stem_out_shape = module, rec, argmax, y.shape
         ctx.units = (stem, blocks)
         ctx.stem_packed = packed
         ctx.nparams = len(params)
-        N, H, W, C = cur.shape
         return cur.permute(0, 3, 1, 2)  # logical NCHW, physical NHWC
 
     @staticmethod
@@ -472,109 +670,17 @@ class _ResNetFn(torch.autograd.Function):
         units = [stem] + [u for blk in blocks for u in blk if u is not None]
         grads = {}
 
-        def bn_back(u: _Unit, s: _Saved, dy, masked, want_dz=False, residual=False):
+        dcur = _backward_blocks(rec, blocks, dcur, dt, dev, grads)
+
+        def bn_back(u: _Unit, s: _Saved, dy, masked):
             sg, sb = gradsink.target(u.bn.weight), gradsink.target(u.bn.bias)
             dg = sg if sg is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
             db = sb if sb is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
-            # BN directly followed by ReLU: the mask is recomputed from x (one tensor less to read);
-            # BN + residual + ReLU: the mask is the saved block output
-            out = ops.bn_bwd(s.x, dy, s.y if (masked and residual) else None, u.bn.weight.detach(), s.mean, s.rstd,
-                             dg, db, want_dz=want_dz,
-                             relu_beta=u.bn.bias.detach() if (masked and not residual) else None)
+            out = ops.bn_bwd(s.x, dy, None, u.bn.weight.detach(), s.mean, s.rstd, dg, db,
+                             relu_beta=u.bn.bias.detach() if masked else None)
             grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
             return out
 
-        def bn_back_fused(u: _Unit, s: _Saved, dz, st):
-            """dz is already masked and its sums are in `st` (emitted by the kernel that produced it)."""
-            sg, sb = gradsink.target(u.bn.weight), gradsink.target(u.bn.bias)
-            dg = sg if sg is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
-            db = sb if sb is not None else torch.zeros(u.cout, dtype=torch.float32, device=dev)
-            out = ops.bn_bwd_fused(s.x, dz, u.bn.weight.detach(), s.mean, s.rstd, dg, db, st)
-            grads[u] = [None, None if sg is not None else dg, None if sb is not None else db]
-            return out
-
-        def relu_bn(u: _Unit, s: _Saved):
-            """The fusion descriptor of an interior BatchNorm+ReLU: mask recomputed from its input."""
-            return ops.BnBwd(s.x, s.mean, s.rstd, gamma=u.bn.weight.detach(), beta=u.bn.bias.detach()) if fuse else None
-
-        def conv3_back_fused(u3: _Unit, u2: _Unit, s3: _Saved, s2: _Saved, dz, st):
-            """bn3 backward + conv3 input gradient (+ bn2 mask / sums) + conv3 weight gradient in ONE launch; the partial
-            weight gradients are folded into the parameter's gradient on the weight-gradient stream."""
-            sg, sb = gradsink.target(u3.bn.weight), gradsink.target(u3.bn.bias)
-            dg = sg if sg is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
-            db = sb if sb is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
-            dy2, st2, parts, nparts = ops.conv3_bwd_fused(dz, s3.x, u3.bn.weight.detach(), s3.mean, s3.rstd, dg, db, st,
-                                                          s3.wt.view(u3.cin, u3.cout), relu_bn(u2, s2))
-            sink = gradsink.target(u3.conv.weight, (u3.cout, 1, 1, u3.cin))
-            dw = sink if sink is not None else torch.zeros(u3.cout, 1, 1, u3.cin, dtype=torch.float32, device=dev)
-            with wgrad_stream(dev, parts):
-                ops.partials_reduce_acc(parts, nparts, dw.view(u3.cout, u3.cin))
-            grads[u3] = [None if sink is not None else dw.permute(0, 3, 1, 2), None if sg is not None else dg,
-                         None if sb is not None else db]
-            return dy2, st2
-
-        fuse = FUSE_BN_BWD and dt == torch.bfloat16
-        st3 = None                  # sums for this block's bn3, when the next block's conv1 input gradient emitted them
-        for bi in reversed(range(len(blocks))):
-            (u1, u2, u3, ud) = blocks[bi]
-            s1, s2, s3 = rec[u1], rec[u2], rec[u3]
-            fused3 = (fuse and FUSE_CONV3_BWD and st3 is not None and u3.is_gemm and u3.cin_pad == u3.cin
-                      and s3.wt is not None and ops.conv3_bwd_fused_supported(dcur, s3.wt.view(u3.cin, u3.cout)))
-            if fused3:              # one kernel below does bn3's backward, conv3's input gradient and its weight gradient
-                dz, dx3 = dcur, None
-            elif st3 is not None:   # dcur IS dz: masked by (block output > 0) in the producing epilogue
-                dz = dcur
-                dx3 = bn_back_fused(u3, s3, dz, st3)
-            else:
-                dx3, dz = bn_back(u3, s3, dcur, True, want_dz=True, residual=True)      # dz: gradient of the identity path
-            br = None
-            if ud is not None:
-                # the shortcut's backward (BN backward, weight gradient, input gradient) on the branch stream,
-                # under the main branch's three convolutions
-                sd = rec[ud]
-                br = branch_stream(dev, dz, sd.x, sd.a, sd.mean, sd.rstd)
-                with br:
-                    dxd = bn_back(ud, sd, dz, False)
-                    with wgrad_stream(dev, sd.a, dxd):
-                        grads[ud][0] = _conv_wgrad(ud, sd.a, dxd)
-                    dskip = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape)
-            if fused3:
-                dy2, st2 = conv3_back_fused(u3, u2, s3, s2, dz, st3)
-            else:
-                with wgrad_stream(dev, s3.a, dx3):
-                    grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)
-                if fuse:
-                    dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape, bn=relu_bn(u2, s2))
-                else:
-                    dy2, st2 = _conv_dgrad(u3, dx3, s3.wt, s3.a.shape), None
-            dx2 = bn_back_fused(u2, s2, dy2, st2) if st2 is not None else bn_back(u2, s2, dy2, True)
-            with wgrad_stream(dev, s2.a, dx2):
-                grads[u2][0] = _conv_wgrad(u2, s2.a, dx2)
-            if fuse:
-                dy1, st1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape, bn=relu_bn(u1, s1))
-            else:
-                dy1, st1 = _conv_dgrad(u2, dx2, s2.wt, s2.a.shape), None
-            dx1 = bn_back_fused(u1, s1, dy1, st1) if st1 is not None else bn_back(u1, s1, dy1, True)
-            with wgrad_stream(dev, s1.a, dx1):
-                grads[u1][0] = _conv_wgrad(u1, s1.a, dx1)
-            if br is not None:
-                br.wait(dskip)
-                join = dskip
-            else:
-                join = dz
-            # The block's input gradient (both branches joined in the epilogue).  The block input is the previous
-            # block's output relu(bn3(x3) + skip): fuse THAT bn3's backward (mask = the saved output) into this kernel.
-            if fuse and bi > 0:
-                p3 = rec[blocks[bi - 1][2]]
-                dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join,
-                                        bn=ops.BnBwd(p3.x, p3.mean, p3.rstd, ymask=p3.y, ybits=p3.bits))
-            else:
-                dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join), None
-            # this block's gradient kernels are all enqueued: let the data-parallel engine start exchanging the
-            # buckets they complete while the rest of the backbone's backward runs
-            for u in (u3, u2, u1, ud):
-                if u is not None:
-                    gradsink.mark_ready([p for p, g in zip((u.conv.weight, u.bn.weight, u.bn.bias), grads[u]) if g is None])
         s0 = rec[stem]
         if FUSE_STEM_TAIL and dcur.is_contiguous():
             # max-pool backward gathered inside the stem's BatchNorm backward: this chain is the exposed end of the step
