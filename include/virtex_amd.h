@@ -144,6 +144,23 @@ int vtx_conv3_bwd_fused(int dtype, int M, int K, int N, const void* dz, const vo
                         float* dw_parts, long dw_parts_floats, int* dw_nparts, void* stream);
 int vtx_partials_reduce_acc(const float* ws, int nparts, int M, int N, float* C, long ldc, void* stream);
 
+/* ---- the BatchNorm backward of bn3 folded into conv3's weights (csrc/bn_fold.hip): no pass over the [P][K] tensors ----
+ * Same reference operators as above (aten::native_batch_norm_backward of bn3, aten::convolution_backward of the 1x1 conv3 of
+ * torchvision's Bottleneck, visual_backbones.py:68-74), for the Bottlenecks the streaming kernel does not take (stages 2-4).
+ * BatchNorm backward is affine per channel, dx3 = a0 dz + b1 x3 + c, and x3 = a3 . W3^T, so
+ *     dy2 = dz . (a0 o W3) + a3 . (W3^T diag(b1) W3) + W3^T c          dW3 = diag(a0) dz^T a3 + diag(b1) W3 (a3^T a3) + c colsum(a3)^T
+ * -- neither x3 nor dx3 is touched in backward.  vtx_bn_bwd_fold: finalize of the sums in pre_partials[pre_nparts][2][K] (as
+ * vtx_bn_bwd_fused; dgamma / dbeta ACCUMULATED) and, from wt [N][K] (conv3's weight, input-channel-major, bf16):
+ * wa = a0 o wt, wb = b1 o wt (bf16 [N][K] dense), bias[n] = sum_k c[k] wt[n][k], abc[3][K] = a0, b1, c.  The products are ordinary
+ * contractions: H = vtx_gemm_nt(wb, wt); tmp = vtx_gemm_nt(a3, H, bias); dy2 = vtx_gemm_nt_bnbwd(dz, wa, residual = tmp).
+ * vtx_wgrad_fold_combine: dw[k][n] += a0[k] T[k][n] + b1[k] WG[k][n] + c[k] s[n]  with T = dz^T a3, WG = W3 (a3^T a3) (fp32
+ * [K][N] dense), s = colsum(a3) [N]. */
+int vtx_bn_bwd_fold(const float* gamma, const float* save_mean, const float* save_rstd, const float* pre_partials,
+                    int pre_nparts, float* dgamma, float* dbeta, float* bn_workspace, int P, int K, const void* wt,
+                    long ldw, int N, void* wa, void* wb, float* bias, float* abc, void* stream);
+int vtx_wgrad_fold_combine(float* dw, long ldd, const float* T, const float* WG, const float* s, const float* abc,
+                           int K, int N, void* stream);
+
 /* ---- JPEG decode (csrc/jpeg.hip) ------------------------------------
  * Replaces cv2.imread + cv2.cvtColor(BGR2RGB) of the reference's dataset item (virtex/data/datasets/coco_captions.py:59-60):
  * libjpeg(-turbo)'s baseline decoder with default settings, bit for bit (JDCT_ISLOW, fancy upsampling, its YCbCr -> RGB

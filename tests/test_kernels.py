@@ -1480,3 +1480,67 @@ def test_conv3_backward_in_one_streaming_kernel(backend, M):
     assert rel_err(dw_f.cpu(), dx3_t.t() @ torch.relu(xh2 * gamma2 + beta2)) < 1e-2
     # the sums describe the STORED gradient
     assert rel_err(sums(st2)[0], dy2.double().cpu().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("M,K,N", [(384, 256, 64), (520, 512, 128)])
+def test_bn_backward_folded_into_conv3(backend, M, K, N):
+    """csrc/bn_fold.hip: bn3's backward folded into conv3's weights -- dy2 = dz (a0 o W3) + a3 (W3^T diag(b1) W3) + W3^T c and
+    dW3 = diag(a0) dz^T a3 + diag(b1) W3 (a3^T a3) + c colsum(a3)^T, with x3 = a3 W3^T -- against (1) the fp64 evaluation of the
+    BatchNorm-backward formulas on the same bf16 operands and (2) the launches it replaces (bn_bwd_fused -> gemm_nt_bnbwd /
+    gemm_tn_acc): the folded form may not be further from (1) than twice the pass form is (both round to bf16, in different
+    places), and the BatchNorm parameter gradients are bit-identical (same finalize)."""
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(M + K)
+    a3 = torch.relu(0.9 * torch.randn(M, N, generator=g) + 0.2).to(dt)                              # conv3's input: a ReLU output
+    w3 = (torch.randn(K, N, generator=g) * (2.0 / N) ** 0.5).to(dt)                                  # conv3's weight (cout, cin)
+    wt = w3.t().contiguous()                                                                        # (cin, cout): the input-gradient operand
+    x3 = (a3.float() @ w3.float().t()).to(dt)                                                       # as the forward pass stored it
+    dz = (torch.randn(M, K, generator=g) * (torch.rand(M, K, generator=g) > 0.4)).to(dt)            # masked upstream gradient
+    x2 = (0.9 * torch.randn(M, N, generator=g) + 0.2).to(dt)
+    gamma3 = 0.5 + torch.rand(K, generator=g); gamma2 = 0.5 + torch.rand(N, generator=g); beta2 = 0.3 * torch.randn(N, generator=g)
+    mean3 = x3.float().mean(0); rstd3 = (x3.float().var(0, unbiased=False) + 1e-5).rsqrt()
+    mean2 = x2.float().mean(0); rstd2 = (x2.float().var(0, unbiased=False) + 1e-5).rsqrt()
+    xh3 = (x3.double() - mean3.double()) * rstd3.double()
+    s1 = dz.double().sum(0); s2 = (dz.double() * xh3).sum(0)
+    parts3 = torch.stack([s1, s2]).float().view(1, 2, K).contiguous()
+    # (1) fp64 reference of the formulas
+    dx3 = (gamma3 * rstd3).double() * (dz.double() - s1 / M - xh3 * s2 / M)
+    keep = ((x2.double() - mean2.double()) * rstd2.double() * gamma2.double() + beta2.double()) > 0
+    dy2_ref = torch.where(keep, dx3 @ w3.double(), torch.zeros((), dtype=torch.float64))
+    dw_ref = dx3.t() @ a3.double()
+    to = lambda t: t.to(dev)                                                                        # noqa: E731
+    bn2 = lambda: ops.BnBwd(to(x2), to(mean2), to(rstd2), gamma=to(gamma2), beta=to(beta2))         # noqa: E731
+    # (2) the pass form
+    dg_p, db_p = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+    dx3_p = ops.bn_bwd_fused(to(x3), to(dz), to(gamma3), to(mean3), to(rstd3), dg_p, db_p, ops.BnStats(to(parts3), 1, None))
+    dy2_p, st_p = ops.gemm_nt_bnbwd(dx3_p, to(wt), bn2())
+    dw_p = torch.zeros(K, N, device=dev)
+    ops.gemm_tn_acc(dx3_p, to(a3), dw_p)
+    # (3) the folded form, as modules/visual_backbones.py::conv3_back_folded issues it
+    dg_f, db_f = torch.zeros(K, device=dev), torch.zeros(K, device=dev)
+    wa, wb, bias, abc = ops.bn_bwd_fold(to(wt), to(gamma3), to(mean3), to(rstd3), dg_f, db_f, ops.BnStats(to(parts3), 1, None), M)
+    h = ops.gemm_nt(wb, to(wt))
+    tmp = ops.gemm_nt(to(a3), h, bias=bias)
+    dy2_f, st_f = ops.gemm_nt_bnbwd(to(dz), wa, bn2(), residual=tmp)
+    t = torch.zeros(K, N, device=dev); gram = torch.zeros(N, N, device=dev); csum = torch.zeros(N, device=dev)
+    ops.gemm_tn_acc(to(dz), to(a3), t)
+    ops.gemm_tn_acc(to(a3), to(a3), gram)
+    ops.colsum_acc(to(a3), csum)
+    wg = ops.gemm_nt(to(w3.float()), gram)
+    dw_f = torch.zeros(K, N, device=dev)
+    ops.wgrad_fold_combine(dw_f, t, wg, csum, abc)
+    assert torch.equal(dg_f.cpu(), dg_p.cpu()) and torch.equal(db_f.cpu(), db_p.cpu())
+    # the coefficients: dx3 = a0 dz + b1 x3 + c reproduces the formula
+    a0, b1, c = (v.double().cpu() for v in abc)
+    assert rel_err(a0 * dz.double() + b1 * x3.double() + c, dx3) < 1e-5
+    e_pass, e_fold = rel_err(dy2_p.double().cpu(), dy2_ref), rel_err(dy2_f.double().cpu(), dy2_ref)
+    assert e_pass < 1e-2 and e_fold < max(2.0 * e_pass, 1e-2), (e_pass, e_fold)
+    w_pass, w_fold = rel_err(dw_p.double().cpu(), dw_ref), rel_err(dw_f.double().cpu(), dw_ref)
+    assert w_pass < 1e-2 and w_fold < max(2.0 * w_pass, 1e-2), (w_pass, w_fold)
+    print(f"[bn fold M={M} K={K} N={N}] input gradient vs fp64: pass form {e_pass:.2e}, folded {e_fold:.2e}; "
+          f"weight gradient: pass form {w_pass:.2e}, folded {w_fold:.2e}")
+    sums = lambda st: st.parts[: st.strips * 2 * N].view(st.strips, 2, N).double().cpu().sum(0)     # noqa: E731
+    assert rel_err(sums(st_f)[0], dy2_f.double().cpu().sum(0)) < 1e-5                               # the sums describe the STORED gradient
+    assert rel_err(sums(st_f)[0], sums(st_p)[0]) < 2e-2 and rel_err(sums(st_f)[1], sums(st_p)[1]) < 2e-2

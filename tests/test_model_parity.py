@@ -922,7 +922,12 @@ def _single_bottleneck(case, backend, dtype):
     up = torch.randn(y64.shape, generator=g)                                # the supplied upstream gradient
     y64.backward(up.double())
     x32 = x.clone().requires_grad_(True)
-    y32 = o32(x32)
+    if dtype == torch.bfloat16:       # the comparison column = PyTorch's own bf16 AMP of the reference block (calibration of the bf16 bound)
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            y32 = o32(x32)
+        y32 = y32.float()
+    else:
+        y32 = o32(x32)
     y32.backward(up)
     xd = x.to(dev).requires_grad_(True)
     model.zero_grad(set_to_none=True)
@@ -959,10 +964,75 @@ def test_single_bottleneck_fp32_flat_1e3(backend, case):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["stage1_block1_identity", "stage4_block0_downsample_stride2"])
 def test_single_bottleneck_bf16_gpu(case):
-    """The benchmarked precision through the same entry point (fused BatchNorm epilogues, bit masks): bf16 storage bounds."""
+    """The benchmarked precision through the same entry point (fused BatchNorm epilogues, bit masks).  A 16-bit forward flips
+    the ReLU masks of the elements within its rounding distance of zero, and a flipped element moves its gradient by 100 %: the
+    block's gradients sit 5-10 % from the fp64 oracle in ANY bf16 implementation (first hardware run: 0.03-0.10).  The bound is
+    therefore measured in place, like tests/test_fidelity.py does for the whole step: the same block of the reference under
+    `torch.autocast(bfloat16)` against the same fp64 oracle, per tensor; ours may not be further away than 1.5x that (output:
+    bf16 storage rounding)."""
     rows, bufs, _ = _single_bottleneck(case, "gpu", torch.bfloat16)
-    _dump_rows(f"parity_bf16_bottleneck_{case}.json", {"bound": 3e-2, "worst": max(rows, key=lambda r: r[1])}, rows)
-    for n, mine, _ in rows:
-        assert mine < 3e-2, (case, n, mine)
+    _dump_rows(f"parity_bf16_bottleneck_{case}.json", {"bound": "1.5 x torch.autocast(bfloat16) of the reference block, per tensor",
+                                                     "worst": max(rows, key=lambda r: r[1] / max(r[2], 1e-30))}, rows)
+    assert rows[0][0] == "output" and rows[0][1] < 1e-2, rows[0]
+    cal_med = sorted(r[2] for r in rows[1:])[len(rows[1:]) // 2]
+    assert 1e-2 < cal_med < 0.3, ("the calibration is not a usable signal", cal_med)
+    for n, mine, cal in rows[1:]:
+        assert mine <= 1.5 * max(cal, cal_med), (case, n, mine, cal, cal_med)
     for n, e in bufs:
         assert e < 1e-2, (case, n, e)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_bn3_backward_folded_into_conv3_in_the_block_schedule(backend, monkeypatch):
+    """Two identity Bottlenecks of stage 2 in bf16 through the backbone's own schedule: the first one's bn3 backward arrives with
+    its sums from the second one's input-gradient epilogue and is FOLDED into conv3's weights (csrc/bn_fold.hip,
+    _backward_blocks::conv3_back_folded) instead of applied in a pass.  Both schedules against the fp64 oracle: the folded one
+    may not be further away than the pass form beyond bf16 rounding, and every gradient of the two agrees to bf16 accuracy."""
+    import copy
+    from virtex_amd import ops
+    from virtex_amd.modules import visual_backbones as vbm
+    dev = select(backend)
+    B, H = (2, 8) if backend == "emu" else (16, 28)
+    oracle_model = synth.seeded_model(port.build_model, seed=0, dropout=0.0, textual="transdec_postnorm::L1_H128_A2_F256",
+                                      vocab_size=304).train()
+    model = vf.build_bicaptioning_model(textual="transdec_postnorm::L1_H128_A2_F256", vocab_size=304, dropout=0.0,
+                                        compute_dtype=torch.bfloat16)
+    model.load_state_dict(oracle_model.state_dict())
+    model = model.to(dev).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.relu(torch.randn(B, 512, H, H, generator=g))
+    up = torch.randn(B, 512, H, H, generator=g)
+    o64 = copy.deepcopy(oracle_model.visual.cnn.layer2[1:3]).double().train()
+    x64 = x.double().requires_grad_(True)
+    o64(x64).backward(up.double())
+    ref = {"input_gradient": x64.grad}
+    ref.update({n: p.grad for n, p in o64.named_parameters()})
+    calls = []
+    real = ops.bn_bwd_fold
+    monkeypatch.setattr(ops, "bn_bwd_fold", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    state = copy.deepcopy(model.state_dict())
+
+    def run(fold):
+        monkeypatch.setattr(vbm, "FUSE_BN3_FOLD", fold)
+        model.load_state_dict(state)                                    # the same BatchNorm buffers for both runs
+        model.zero_grad(set_to_none=True)
+        xd = x.to(dev).requires_grad_(True)
+        model.visual.forward_blocks(xd, 2, 1, 2).backward(up.to(dev))
+        out = {"input_gradient": xd.grad.float().cpu()}
+        for i in (1, 2):
+            out.update({f"{i}.{n}": p.grad.float().cpu() for n, p in model.visual.cnn.layer2[i].named_parameters()})
+        return out
+    plain = run(False)
+    assert not calls
+    folded = run(True)
+    assert len(calls) == 1                                              # the first block's bn3; the last block has no sums to fold
+    worst = ("", 0.0)
+    for n, r in ref.items():
+        e_plain, e_fold = rel_err(plain[n], r), rel_err(folded[n], r)
+        assert e_fold <= max(1.5 * e_plain, 2e-2), (n, e_plain, e_fold)
+        assert rel_err(folded[n], plain[n]) < 5e-2, (n, rel_err(folded[n], plain[n]))
+        if e_fold / max(e_plain, 1e-30) > worst[1]:
+            worst = (n, e_fold / max(e_plain, 1e-30))
+    if backend == "gpu":
+        _dump_rows("parity_bf16_bn3_fold_stage2.json", {"worst_ratio_folded_over_pass": worst},
+                   [(n, rel_err(plain[n], r), rel_err(folded[n], r)) for n, r in ref.items()])

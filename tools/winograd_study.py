@@ -159,11 +159,19 @@ def part2():
     print()
 
 
-def part3(batch):
-    print(f"== 3. fidelity of the step on the oracle (B = {batch}, 224x224, reference initialisation, dropout off) ==")
+def part3(batch, state):
+    print(f"== 3. fidelity of the step on the oracle (B = {batch}, 224x224, {state}, dropout off) ==")
     from oracle import bicaptioning as port, synth
     from virtex_amd import fidelity
-    om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, randomize=False).train()
+    # the two states of tests/test_fidelity.py.  At the reference initialisation bn3.weight = 0 (zero_init_residual): the residual
+    # branch -- conv2 included -- does not reach the loss, so only the randomised state can show what Winograd's rounding does
+    om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, randomize=(state != "reference_init"))
+    if state == "random_bn3x0.2":
+        with torch.no_grad():
+            for n, p in om.named_parameters():
+                if n.endswith("bn3.weight"):
+                    p.mul_(0.2)
+    om.train()
     b = synth.synthetic_batch(batch, image_size=224, seed=3, ragged=True)
 
     def grads(m, ac):
@@ -209,7 +217,14 @@ def main():
     part1()
     part2()
     if not a.skip_step:
-        part3(a.batch)
+        ratios = [part3(a.batch, state) for state in ("reference_init", "random_bn3x0.2")]
+        print("== conclusion ==")
+        print(f"Precision is NOT what rules Winograd out: one layer's output carries 3.5e-3 of extra rounding (2x the bf16 storage rounding it")
+        print(f"pays anyway), and the step's backbone gradients move by x{max(ratios):.3f} of the plain-autocast distance -- inside the 1.25x band.")
+        print("Time is: the whole prize is <= 0.41 ms (1.8 % of the step) with the MFMA phase as efficient as today's direct kernels and both")
+        print("transforms free of staging cost, against a kernel that loses LDS-DMA for its A operand, runs 16 short-K products and holds a")
+        print("quarter of today's output tile per block (notes (a)-(d) above); the stride-1 3x3 layers at 28x28 / 56x56 are HBM-leaning and gain")
+        print("nothing.  Verdict: not built.  The direct implicit-GEMM kernels stay the 3x3 path; this estimate is recorded once in DESIGN.md 6.")
 
 
 if __name__ == "__main__":

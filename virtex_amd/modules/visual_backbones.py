@@ -59,6 +59,11 @@ RELU_BITS = os.environ.get("VIRTEX_AMD_RELU_BITS", "1") != "0"
 # the gradient is loaded, conv3's input gradient with bn2's fused backward epilogue, conv3's weight gradient as per-workgroup
 # partials -- the 411-MB gradient wrt conv3's output (written by one pass, re-read by two kernels) never exists.
 FUSE_CONV3_BWD = os.environ.get("VIRTEX_AMD_FUSE_CONV3_BWD", "1") != "0"
+# bn3's backward FOLDED INTO conv3's WEIGHTS for the Bottlenecks the streaming kernel does not take (stages 2-4; csrc/bn_fold.hip):
+# BatchNorm backward is affine per channel and conv3's output is a linear image of conv3's input, so conv3's input gradient and
+# weight gradient can be written with the gradient wrt bn3's OUTPUT, conv3's input and two small matrices -- the pass "read x3,
+# read dz, write dx3" over the block's largest tensors disappears and x3 is not read in backward at all.
+FUSE_BN3_FOLD = os.environ.get("VIRTEX_AMD_BN3_FOLD", "1") != "0"
 # the stem convolution's epilogue emits the BatchNorm statistics (streaming kernel, stem.hip)
 STEM_STATS = os.environ.get("VIRTEX_AMD_STEM_STATS", "1") != "0"
 
@@ -538,6 +543,36 @@ def _backward_blocks(rec, blocks, dcur, dt, dev, grads):
                      None if sb is not None else db]
         return dy2, st2
 
+    def conv3_back_folded(u3: _Unit, u2: _Unit, s3: _Saved, s2: _Saved, dz, st):
+        """bn3's backward folded into conv3's weights (csrc/bn_fold.hip): with dx3 = a0 dz + b1 x3 + c per channel and
+        x3 = a3 . W3^T,   dy2 = dz . (a0 o W3) + a3 . H + bias  (H = W3^T diag(b1) W3, bias = W3^T c)   on the compute stream and
+        dW3 = diag(a0) dz^T a3 + diag(b1) W3 (a3^T a3) + c colsum(a3)^T   on the weight-gradient stream.  No dx3, no read of x3."""
+        sg, sb = gradsink.target(u3.bn.weight), gradsink.target(u3.bn.bias)
+        dg = sg if sg is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
+        db = sb if sb is not None else torch.zeros(u3.cout, dtype=torch.float32, device=dev)
+        K, N = u3.cout, u3.cin
+        wt = s3.wt.view(N, K)
+        dz2, a3 = dz.view(-1, K), s3.a.view(-1, N)
+        P = dz2.shape[0]
+        wa, wb, bias, abc = ops.bn_bwd_fold(wt, u3.bn.weight.detach(), s3.mean, s3.rstd, dg, db, st, P)
+        h = ops.gemm_nt(wb, wt)                                        # [N][N]
+        tmp = ops.gemm_nt(a3, h, bias=bias)                            # [P][N]: the b1 x3 + c part of dx3, through W3
+        dy2, st2 = ops.gemm_nt_bnbwd(dz2, wa, relu_bn(u2, s2), residual=tmp)
+        sink = gradsink.target(u3.conv.weight, (K, 1, 1, N))
+        dw = sink if sink is not None else torch.zeros(K, 1, 1, N, dtype=torch.float32, device=dev)
+        with wgrad_stream(dev, dz2, a3, abc):
+            scratch = torch.zeros(K * N + N * N + N, dtype=torch.float32, device=dev)
+            t, gram, csum = scratch[:K * N].view(K, N), scratch[K * N:K * N + N * N].view(N, N), scratch[K * N + N * N:]
+            ops.gemm_tn_acc(dz2, a3, t)                                # dz^T a3
+            ops.gemm_tn_acc(a3, a3, gram)                              # the Gram matrix of conv3's input
+            ops.colsum_acc(a3, csum)
+            w32 = u3.conv.weight.detach().permute(0, 2, 3, 1).reshape(K, N)          # the fp32 master (stored (KO,1,1,C): a view)
+            wg = ops.gemm_nt(w32, gram)                                # W3 (a3^T a3), fp32 (gram is symmetric)
+            ops.wgrad_fold_combine(dw.view(K, N), t, wg, csum, abc)
+        grads[u3] = [None if sink is not None else dw.permute(0, 3, 1, 2), None if sg is not None else dg,
+                     None if sb is not None else db]
+        return dy2.view(*dz.shape[:-1], N), st2
+
     fuse = FUSE_BN_BWD and dt == torch.bfloat16
     st3 = None                  # sums for this block's bn3, when the next block's conv1 input gradient emitted them
     for bi in reversed(range(len(blocks))):
@@ -549,7 +584,9 @@ def _backward_blocks(rec, blocks, dcur, dt, dev, grads):
             raise RuntimeError("the forward pass dropped conv3's input for the fused conv3 backward, which this backward pass "
                                "does not take: FUSE_BN_BWD / FUSE_CONV3_BWD / vtx_set_switch('conv3_bwd') were changed between "
                                "the forward and the backward of one step")
-        if fused3:              # one kernel below does bn3's backward, conv3's input gradient and its weight gradient
+        folded3 = (fuse and FUSE_BN3_FOLD and not fused3 and st3 is not None and u3.is_gemm and u3.cin_pad == u3.cin
+                   and s3.wt is not None and u3.cout % 8 == 0 and u3.cin % 8 == 0)
+        if fused3 or folded3:   # bn3's backward happens inside conv3's backward: no dx3
             dz, dx3 = dcur, None
         elif st3 is not None:   # dcur IS dz: masked by (block output > 0) in the producing epilogue
             dz = dcur
@@ -569,6 +606,8 @@ def _backward_blocks(rec, blocks, dcur, dt, dev, grads):
                 dskip = _conv_dgrad(ud, dxd, sd.wt, sd.a.shape)
         if fused3:
             dy2, st2 = conv3_back_fused(u3, u2, s3, s2, dz, st3)
+        elif folded3:
+            dy2, st2 = conv3_back_folded(u3, u2, s3, s2, dz, st3)
         else:
             with wgrad_stream(dev, s3.a, dx3):
                 grads[u3][0] = _conv_wgrad(u3, s3.a, dx3)

@@ -359,6 +359,29 @@ def conv3_bwd_fused(dz, x3, gamma3, mean3, rstd3, dgamma3, dbeta3, stats3: "BnSt
     return dy2, BnStats(parts, d.strips, None), dw_parts, nparts
 
 
+def bn_bwd_fold(wt, gamma, mean, rstd, dgamma, dbeta, stats: "BnStats", P):
+    """BatchNorm backward of a 1x1 convolution's output folded into the convolution's weights (csrc/bn_fold.hip): the finalize of
+    `stats` (dgamma / dbeta accumulated) and, from wt [N][K] bf16: (wa = a0 o wt, wb = b1 o wt, bias [N], abc [3][K])."""
+    N, K = wt.shape
+    _chk(wt, "wt", torch.bfloat16)
+    ws = bn_workspace(wt.device, K)
+    wa, wb = torch.empty(N, K, dtype=wt.dtype, device=wt.device), torch.empty(N, K, dtype=wt.dtype, device=wt.device)
+    bias = torch.empty(N, dtype=torch.float32, device=wt.device)
+    abc = torch.empty(3, K, dtype=torch.float32, device=wt.device)
+    call("vtx_bn_bwd_fold", ptr(gamma), ptr(mean), ptr(rstd), ptr(stats.parts), c_int(stats.strips), ptr(dgamma), ptr(dbeta),
+         ptr(ws), c_int(P), c_int(K), ptr(wt), c_long(wt.stride(0)), c_int(N), ptr(wa), ptr(wb), ptr(bias), ptr(abc), stream_ptr(wt))
+    return wa, wb, bias, abc
+
+
+def wgrad_fold_combine(dw, T, WG, s, abc):
+    """dw[k][n] += a0[k] T[k][n] + b1[k] WG[k][n] + c[k] s[n]  (abc from bn_bwd_fold)."""
+    K, N = dw.shape
+    assert dw.dtype == torch.float32 and dw.stride(1) == 1 and T.shape == (K, N) and WG.shape == (K, N) and s.shape == (N,)
+    _chk(T, "T", torch.float32); _chk(WG, "WG", torch.float32); _chk(s, "s", torch.float32); _chk(abc, "abc", torch.float32)
+    call("vtx_wgrad_fold_combine", ptr(dw), c_long(dw.stride(0)), ptr(T), ptr(WG), ptr(s), ptr(abc), c_int(K), c_int(N), stream_ptr(dw))
+    return dw
+
+
 def partials_reduce_acc(parts, nparts, out):
     """out (M, N) fp32 += sum of parts[:nparts] (each (M, N) fp32)."""
     M, N = out.shape
