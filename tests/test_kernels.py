@@ -1,5 +1,7 @@
 """Per-kernel parity: HIP kernel (through the C ABI) vs the torch fp32 op it replaces.
 Runs on the CPU fiber emulator (`emu`) and on a real MI355X (`gpu`)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1544,3 +1546,61 @@ def test_bn_backward_folded_into_conv3(backend, M, K, N):
     sums = lambda st: st.parts[: st.strips * 2 * N].view(st.strips, 2, N).double().cpu().sum(0)     # noqa: E731
     assert rel_err(sums(st_f)[0], dy2_f.double().cpu().sum(0)) < 1e-5                               # the sums describe the STORED gradient
     assert rel_err(sums(st_f)[0], sums(st_p)[0]) < 2e-2 and rel_err(sums(st_f)[1], sums(st_p)[1]) < 2e-2
+
+
+def test_pixel_index_division_is_exact_below_2_30(tmp_path):
+    """vtx_fdiv30 (csrc/vtx_common.h) -- the reciprocal division behind every pixel-index decomposition of the library (block
+    prologues, scattering epilogues, pooling) -- compiled from the kernels' own header and held against integer division on 12 M
+    cases: small / real / random divisors, multiples of d and their neighbours, the old 2^24 limit, 2^30 - 1, reciprocals nudged by
+    -2 ... +2 ulp (the hardware's v_rcp_f32 is a 1-ulp instruction).  Rounds 1-5 had a one-estimate form exact below 2^24 only,
+    which capped the per-GPU batch at 334 images of 224 x 224."""
+    import subprocess
+    from virtex_amd import build as vb
+    if not os.path.exists(vb.HOST_CLANG):
+        pytest.skip("no host clang")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fdiv_check")
+    r = subprocess.run([vb.HOST_CLANG, "-x", "c++", "-O2", "-std=c++17", "-DHIPEMU=1", "-I", os.path.join(vb.EMU_DIR, "include"),
+                        "-I", vb.CSRC, "-Wno-unused-value", "-Wno-unknown-pragmas", os.path.join(root, "tests", "fuzz", "fdiv_check.cpp"),
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-500:]
+    assert int(r.stdout.split()[1]) > 10_000_000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_convolution_and_pooling_indices_beyond_2_24_pixels_gpu(dtype):
+    """Every kernel that decomposes a pixel index (3x3 forward / input gradient / weight gradient, stride 1 and 2, max-pooling
+    forward and backward) on a tensor of 600 x 168 x 168 = 16.9 M pixels (> 2^24): convolutions and pooling are independent per
+    image, so the result on the whole batch must equal the results on its two halves -- bit for bit for the per-pixel outputs,
+    to summation order for the weight gradient."""
+    dev = select("gpu")
+    N, H, C, KO = 600, 168, 8, 8
+    assert N * H * H > (1 << 24)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, H, H, C, generator=g).to(dtype).to(dev)
+    w = (torch.randn(KO, 3, 3, C, generator=g) / 8).to(dtype).to(dev)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    h1, h2 = slice(0, N // 2), slice(N // 2, N)
+    for stride in (1, 2):
+        y = ops.conv2d_fwd(x, w, stride, 1)
+        parts = torch.cat([ops.conv2d_fwd(x[h1].contiguous(), w, stride, 1), ops.conv2d_fwd(x[h2].contiguous(), w, stride, 1)])
+        assert torch.equal(y, parts), stride
+        dy = torch.randn(y.shape, generator=g).to(dtype).to(dev)
+        dx = ops.conv2d_dgrad(dy, wt, x.shape, stride, 1)
+        dparts = torch.cat([ops.conv2d_dgrad(dy[h1].contiguous(), wt, x[h1].shape, stride, 1),
+                            ops.conv2d_dgrad(dy[h2].contiguous(), wt, x[h2].shape, stride, 1)])
+        assert torch.equal(dx, dparts), stride
+        dw = ops.conv2d_wgrad(x, dy, torch.zeros(KO, 3, 3, C, device=dev), stride, 1)
+        dwp = ops.conv2d_wgrad(x[h1].contiguous(), dy[h1].contiguous(), torch.zeros(KO, 3, 3, C, device=dev), stride, 1)
+        dwp = ops.conv2d_wgrad(x[h2].contiguous(), dy[h2].contiguous(), dwp, stride, 1)
+        assert rel_err(dw.cpu(), dwp.cpu()) < (1e-4 if dtype == torch.float32 else 2e-3), stride
+    p, arg = ops.maxpool_fwd(x)
+    p1, a1 = ops.maxpool_fwd(x[h1].contiguous()); p2, a2 = ops.maxpool_fwd(x[h2].contiguous())
+    assert torch.equal(p, torch.cat([p1, p2])) and torch.equal(arg, torch.cat([a1, a2]))
+    dp = torch.randn(p.shape, generator=g).to(dtype).to(dev)
+    dxp = ops.maxpool_bwd(dp, arg, x.shape)
+    dxh = torch.cat([ops.maxpool_bwd(dp[h1].contiguous(), a1, x[h1].shape), ops.maxpool_bwd(dp[h2].contiguous(), a2, x[h2].shape)])
+    assert torch.equal(dxp, dxh)

@@ -1036,3 +1036,43 @@ def test_bn3_backward_folded_into_conv3_in_the_block_schedule(backend, monkeypat
     if backend == "gpu":
         _dump_rows("parity_bf16_bn3_fold_stage2.json", {"worst_ratio_folded_over_pass": worst},
                    [(n, rel_err(plain[n], r), rel_err(folded[n], r)) for n, r in ref.items()])
+
+
+@pytest.mark.gpu
+def test_batches_beyond_2_24_pixels_gpu():
+    """The envelope of rounds 1-5 ended at 2^24 pixels per tensor (334 images of 224 x 224: the pixel-index divisions were exact
+    below 2^24 only).  With vtx_fdiv30 it ends at 2^30.  B = 384 at 224 x 224 (20.3 M pixels in the stem's haloed input):
+    (1) eval mode is per-sample independent (BatchNorm folded into the convolutions), so the features of the whole batch must
+    equal the features of its two halves -- every forward kernel, images whose pixel indices lie above 2^24 included;
+    (2) one bf16 training step against the fp32 step of the same weights and batch (virtex_amd.fidelity), bounds of the B = 256
+    test; (3) the last images of the batch contribute to the gradient: zeroing them changes it."""
+    from virtex_amd import fidelity
+    dev = select("gpu")
+    B = 384
+    om = synth.seeded_model(port.build_model, seed=0, dropout=0.0, randomize=False)
+    batch = {k: v.to(dev) for k, v in synth.synthetic_batch(B, image_size=224, seed=3).items()}
+    for dtype in (torch.float32, torch.bfloat16):
+        m = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=dtype)
+        m.load_state_dict(om.state_dict())
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            whole = m.visual(batch["image"]).float()
+            halves = torch.cat([m.visual(batch["image"][: B // 2]), m.visual(batch["image"][B // 2:])]).float()
+        assert torch.isfinite(whole).all()
+        assert rel_err(whole.cpu(), halves.cpu()) < (1e-6 if dtype == torch.float32 else 1e-3), dtype
+        assert rel_err(whole[-8:].cpu(), halves[-8:].cpu()) < (1e-6 if dtype == torch.float32 else 1e-3)      # images above 2^24 pixels
+        del m
+    model = vf.build_bicaptioning_model(dropout=0.0, compute_dtype=torch.bfloat16)
+    model.load_state_dict(om.state_dict())
+    model = model.to(dev).train()
+    s = fidelity.bf16_vs_fp32(model, batch)
+    _dump_rows("fidelity_bf16_b384_beyond_2_24_pixels.json", s, [])
+    assert s["loss_rel"] < 2e-4
+    assert s["backbone"]["median_rel"] <= 0.25 and s["backbone"]["max_rel"] <= 0.35 and s["backbone"]["min_cos"] >= 0.95, s
+    assert s["text"]["max_rel"] <= 6e-2 and s["text"]["min_cos"] >= 0.995, s
+    _, g_all = fidelity.run_grads(model, batch)
+    cut = dict(batch, image=batch["image"].clone())
+    cut["image"][-16:] = 0.0
+    _, g_cut = fidelity.run_grads(model, cut)
+    n = "visual.cnn.conv1.weight"
+    assert rel_err(g_cut[n].cpu(), g_all[n].cpu()) > 1e-3

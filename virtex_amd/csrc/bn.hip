@@ -443,12 +443,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fused_kernel(const T* __rest
 // ---- the stem's tail: MaxPool2d(3,2,1) backward gathered on the fly inside the BatchNorm backward -------------
 // gradient wrt the pre-pool tensor at pixel (n, ih, iw): the dy of the (<= 2x2) pooling windows whose argmax is this
 // pixel (same gather as maxpool_bwd_kernel in pool.hip; first-maximum tie rule lives in the forward's argmax)
-__device__ __forceinline__ int bnpool_qdiv(int n, int d) {      // exact for 0 <= n < 2^24
-    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
-    const int r = n - q * d;
-    if (r < 0) --q; else if (r >= d) ++q;
-    return q;
-}
+__device__ __forceinline__ int bnpool_qdiv(int n, int d) { return vtx_fdiv30(n, d, __builtin_amdgcn_rcpf((float)d)); }   // exact for 0 <= n < 2^30
 // (PoolQuad, pool_windows.h: a thread owns a 2 x 2 quad of input pixels = exactly four pooling windows; everything it needs is
 // requested before anything is used)
 // reduce: s1 = sum dz, s2 = sum dz*xhat with dz = pool-gathered gradient masked by relu(xhat*gamma+beta) > 0
@@ -863,7 +858,7 @@ extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, c
     VTX_CHECK(Pl < (1L << 31), VTX_ERR_SHAPE, "bn_bwd_maxpool: too many pixels");
     const int P = (int)Pl;
     const long NQl = (long)N * ((H + 1) / 2) * ((W + 1) / 2);            // 2 x 2 quads of input pixels: one per thread and trip
-    VTX_CHECK(NQl < (1L << 24), VTX_ERR_SHAPE, "bn_bwd_maxpool: more than 2^24 pixel quads is not supported");
+    VTX_CHECK(NQl < VTX_PIXEL_LIMIT, VTX_ERR_SHAPE, "bn_bwd_maxpool: more than 2^30 pixel quads is not supported");
     const int NQ = (int)NQl;
     hipStream_t st = (hipStream_t)stream;
     int* tickets = reinterpret_cast<int*>(workspace); (void)tickets;
@@ -911,7 +906,7 @@ extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, 
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "bn_fwd_maxpool: bad dtype %d", dtype);
     const int vec = dtype == VTX_BF16 ? 8 : 4;
     VTX_CHECK(N > 0 && H > 0 && W > 0 && bn_shape_ok(C, vec), VTX_ERR_SHAPE, "bn_fwd_maxpool: C=%d must be vec*2^k", C);
-    VTX_CHECK((long)N * H * W < (1L << 24), VTX_ERR_SHAPE, "bn_fwd_maxpool: more than 2^24 pixels is not supported");
+    VTX_CHECK((long)N * H * W < VTX_PIXEL_LIMIT, VTX_ERR_SHAPE, "bn_fwd_maxpool: more than 2^30 pixels is not supported");
     hipStream_t st = (hipStream_t)stream;
     int* tickets = reinterpret_cast<int*>(workspace); (void)tickets;
     workspace += VTX_BN_WS_HEADER;

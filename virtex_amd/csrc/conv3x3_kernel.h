@@ -175,7 +175,7 @@ inline int conv3x3_shared_try(const void* a_ptr, int Nimg, int H, int W, int CH,
     // measured per layer at bs 256 (profiles/r03_conv3x3_shared.txt): 64->64 @56x56 118 -> 101 us forward, 114 -> 107 input gradient;
     // 128->128 @28x28 81 -> 79 / 79 -> 78; 256->256 @14x14 68 -> 75 and 512->512 @7x7 67 -> 96 (few tiles, short pipelines):
     // the kernel takes the large images only
-    if (Ml >= (1L << 24) || Ml < (g_vtx_sw_conv3x3_shared >= 2 ? 1 : 100000) || ((double)Ml * CH + 2.0 * (W + 1) * CH) * 2 >= VTX_BUF_LIMIT) return 0;
+    if (Ml >= VTX_PIXEL_LIMIT || Ml < (g_vtx_sw_conv3x3_shared >= 2 ? 1 : 100000) || ((double)Ml * CH + 2.0 * (W + 1) * CH) * 2 >= VTX_BUF_LIMIT) return 0;
     const int M = (int)Ml;
     Conv3x3Geo g{Nimg, H, W, CH, M};
     EP ep = ep_in;

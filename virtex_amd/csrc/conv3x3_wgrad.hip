@@ -40,12 +40,7 @@ constexpr uint32_t W3_OOB = 0x80000000u;
 
 // 16-byte chunk permutation of a k-major row of 64 elements (gemm_kernel.h swz_mc<64>): keyed on bits 1 and 3 of the row index
 __device__ __forceinline__ int w3_swz(int chunk, int k) { return chunk ^ ((((k >> 1) & 1) << 1) | (((k >> 3) & 1) << 2)); }
-__device__ __forceinline__ int w3_qdiv(int n, int d, float inv) {   // exact floor(n / d) for 0 <= n < 2^24
-    int q = (int)((float)n * inv);
-    const int r = n - q * d;
-    if (r < 0) --q; else if (r >= d) ++q;
-    return q;
-}
+__device__ __forceinline__ int w3_qdiv(int n, int d, float inv) { return vtx_fdiv30(n, d, inv); }   // exact floor(n / d) for 0 <= n < 2^30
 
 struct W3Geo { int N, H, W, C, KO, Hp, Wp, P; float inv_img, inv_wp; };
 
@@ -231,7 +226,7 @@ int vtx_conv3x3_wgrad_try(int N, int H, int W, int C, int KO, int R, int S, int 
     const int Hp = H + 2, Wp = W + 2;
     const long P = (long)N * Hp * Wp;
     const int lead = ((Wp + 1 + 31) / 32) * 32, nl = 2 * lead / 32;
-    if (P >= (1L << 24) || W3_RING / 32 < nl + W3_PF + 4 || Wp < 9 || Hp < 5) return 0;   // ring margins for two steps per barrier (W <= 61);
+    if (P >= VTX_PIXEL_LIMIT || W3_RING / 32 < nl + W3_PF + 4 || Wp < 9 || Hp < 5) return 0;   // ring margins for two steps per barrier (W <= 61);
                                                                                          // the loader carries at most ONE image per 32-position step (<= 4 rows of >= 9): Hp >= 5
     // by image size (switch value 1): the padding positions are multiplied as zeros -- +7 % MFMA work at 56x56, +15 % at
     // 28x28, +31 % at 14x14, +65 % at 7x7, where the implicit-GEMM kernel (whose operands then fit the caches) wins

@@ -30,8 +30,8 @@ static inline int make_geo(const char* who, int dtype, int N, int H, int W, int 
     VTX_CHECK(g->OH > 0 && g->OW > 0, VTX_ERR_SHAPE, "%s: empty output", who);
     g->inv_ow = 1.0f / (float)g->OW;
     g->inv_ohow = 1.0f / (float)(g->OH * g->OW);
-    VTX_CHECK((long)N * H * W < (1L << 24) && (long)N * g->OH * g->OW < (1L << 24), VTX_ERR_SHAPE,
-              "%s: more than 2^24 pixels per tensor is not supported", who);
+    VTX_CHECK((long)N * H * W < VTX_PIXEL_LIMIT && (long)N * g->OH * g->OW < VTX_PIXEL_LIMIT, VTX_ERR_SHAPE,
+              "%s: more than 2^30 pixels per tensor is not supported", who);
     return VTX_OK;
 }
 

@@ -53,13 +53,8 @@ template <> struct Mma<float> {
 __device__ __forceinline__ uint4 ld16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint4 zero16() { return make_uint4(0u, 0u, 0u, 0u); }
 
-// q = n / d for 0 <= n < 2^24 (exact after one correction step); inv = 1.0f / d
-__device__ __forceinline__ int fdiv(int n, int d, float inv) {
-    int q = (int)((float)n * inv);
-    int r = n - q * d;
-    if (r < 0) --q; else if (r >= d) ++q;
-    return q;
-}
+// q = n / d for 0 <= n < 2^30 (vtx_common.h: two float estimates + one correction step); inv = 1.0f / d
+__device__ __forceinline__ int fdiv(int n, int d, float inv) { return vtx_fdiv30(n, d, inv); }
 
 // ------------------------------------------------------------------ buffer addressing (generation-2 kernel)
 // The DMA kernel addresses every operand through a BUFFER DESCRIPTOR (buffer_load_dwordx4 ... offen lds):
@@ -78,7 +73,7 @@ struct BufView { const void* base; uint32_t bytes; };
 constexpr uint32_t VTX_OOB = 0x80000000u;          // voffset of a lane that must read zeros (>= every accepted size)
 constexpr double VTX_BUF_LIMIT = 2.0e9;            // bytes
 
-// q = n / d for 0 <= n < 2^24 through the hardware reciprocal (one v_rcp_f32 + the correction step of fdiv): the block
+// q = n / d for 0 <= n < 2^30 through the hardware reciprocal (one v_rcp_f32 + fdiv): the block
 // prologues and the scattering epilogue decompose a few row indices each; a generic 32-bit division is ~25 instructions
 __device__ __forceinline__ int qdiv(int n, int d) { return fdiv(n, d, __builtin_amdgcn_rcpf((float)d)); }
 

@@ -8,14 +8,9 @@
 namespace {
 
 // Thread layout of both kernels: tx = channel vector (fixed for the thread's life), ty = pixel; a block covers
-// TY = 256 / TX pixels per trip.  Pixel indices stay below 2^24 (32-bit reciprocal division, two per pixel); the eight
+// TY = 256 / TX pixels per trip.  Pixel indices stay below 2^30 (reciprocal division, two per pixel); the eight
 // argmax bytes of a vector travel as ONE 8-byte access.
-__device__ __forceinline__ int pool_qdiv(int n, int d) {      // exact for 0 <= n < 2^24
-    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
-    const int r = n - q * d;
-    if (r < 0) --q; else if (r >= d) ++q;
-    return q;
-}
+__device__ __forceinline__ int pool_qdiv(int n, int d) { return vtx_fdiv30(n, d, __builtin_amdgcn_rcpf((float)d)); }   // exact for 0 <= n < 2^30
 template <int VEC> struct ArgPack;
 template <> struct ArgPack<8> {
     typedef uint2 W;
@@ -115,7 +110,7 @@ extern "C" int vtx_maxpool3x3s2_fwd(int dtype, const void* x, void* y, uint8_t* 
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "maxpool_fwd: bad dtype");
     VTX_CHECK(N > 0 && H > 0 && W > 0 && C % vec == 0, VTX_ERR_SHAPE, "maxpool_fwd: bad shape");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    VTX_CHECK((long)N * H * W < (1L << 24), VTX_ERR_SHAPE, "maxpool_fwd: more than 2^24 pixels is not supported");
+    VTX_CHECK((long)N * H * W < VTX_PIXEL_LIMIT, VTX_ERR_SHAPE, "maxpool_fwd: more than 2^30 pixels is not supported");
     const PoolGrid pg = grid_for(N * OH * OW, C / vec);
     if (dtype == VTX_BF16)
         VTX_KLAUNCH("maxpool_fwd", 0, 2.0 * N * H * W * C + 3.0 * N * OH * OW * C, (maxpool_fwd_kernel<bf16_t>), dim3(pg.gx, pg.gy), dim3(256), 0, (hipStream_t)stream,
@@ -134,7 +129,7 @@ extern "C" int vtx_maxpool3x3s2_bwd(int dtype, const void* dy, const uint8_t* ar
     VTX_CHECK(dtype == VTX_BF16 || dtype == VTX_F32, VTX_ERR_DTYPE, "maxpool_bwd: bad dtype");
     VTX_CHECK(N > 0 && H > 0 && W > 0 && C % vec == 0, VTX_ERR_SHAPE, "maxpool_bwd: bad shape");
     const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-    VTX_CHECK((long)N * H * W < (1L << 24), VTX_ERR_SHAPE, "maxpool_bwd: more than 2^24 pixels is not supported");
+    VTX_CHECK((long)N * H * W < VTX_PIXEL_LIMIT, VTX_ERR_SHAPE, "maxpool_bwd: more than 2^30 pixels is not supported");
     const PoolGrid pg = grid_for(N * H * W, C / vec);
     if (dtype == VTX_BF16)
         VTX_KLAUNCH("maxpool_bwd", 0, 2.0 * N * H * W * C + 3.0 * N * OH * OW * C, (maxpool_bwd_kernel<bf16_t>), dim3(pg.gx, pg.gy), dim3(256), 0, (hipStream_t)stream,

@@ -34,12 +34,7 @@ constexpr int ST_ROWB = ST_N * 2 + 16;                   // strip row: 64 channe
 // (the permutation of the contraction kernel's 32-deep images: gemm_kernel.h swz_slot)
 __device__ __forceinline__ int st_wslot(int kh, int n, int s) { return (kh * ST_N + n) * 4 + (s ^ ((0x78 >> (2 * ((n >> 2) & 3))) & 3)); }
 
-__device__ __forceinline__ int st_qdiv(int n, int d) {   // exact n / d for 0 <= n < 2^24, d > 0
-    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
-    const int r = n - q * d;
-    if (r < 0) --q; else if (r >= d) ++q;
-    return q;
-}
+__device__ __forceinline__ int st_qdiv(int n, int d) { return vtx_fdiv30(n, d, __builtin_amdgcn_rcpf((float)d)); }   // exact n / d for 0 <= n < 2^30, d > 0
 
 __global__ __launch_bounds__(64 * ST_WAVES, 4) void stem_stream_fwd_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, bf16_t* __restrict__ Y, const float* __restrict__ shift,
@@ -164,7 +159,7 @@ int vtx_stem_stream_try(int N, int H, int W, int C, int KO, int R, int S, int st
     const int OH = (H - R) / 2 + 1, OW = (W - S) / 2 + 1;
     if (OH <= 0 || OW <= 0) return 0;
     const long Ml = (long)N * OH * OW;
-    if (Ml < 256 || Ml >= (1L << 24)) return 0;
+    if (Ml < 256 || Ml >= VTX_PIXEL_LIMIT) return 0;
     const int M = (int)Ml;
     const size_t lds = (size_t)ST_KH * ST_N * 32 * 2 + (size_t)ST_WAVES * 16 * ST_ROWB;    // 28 + 18 KiB
     const int nstrips = (M + 15) / 16;

@@ -31,6 +31,27 @@ void vtx_set_error(const char* fmt, ...);
 static inline int vtx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------
+// floor(n / d) for 0 <= n < 2^30, 1 <= d < 2^24, through a float reciprocal `inv` = 1 / d good to 2 ulp (v_rcp_f32, or a
+// correctly rounded host value): what every pixel-index decomposition of the library uses (block prologues, scattering
+// epilogues, pooling) -- a generic 32-bit division is ~25 instructions, this is 13.  (float)n keeps 24 bits, so the first
+// estimate is off by up to n 2^-21 / d + 1 (<= 725 for n < 2^30); its remainder is small enough to be exact in float, the second
+// estimate (on the remainder) lands within 1 of the quotient, one correction step finishes.  Rounds 1-5 had the one-estimate
+// form, exact below 2^24 only: tensors of more than 16.7 M pixels (334 images of 224 x 224 per GPU) were refused.
+// VTX_PIXEL_LIMIT is what the host entry points check.
+// ---------------------------------------------------------------------------------------
+constexpr long VTX_PIXEL_LIMIT = 1L << 30;
+#if defined(__HIPCC__) || defined(HIPEMU)
+__device__ __forceinline__ int vtx_fdiv30(int n, int d, float inv) {
+    int q = (int)((float)n * inv);
+    int r = n - q * d;
+    q += (int)((float)r * inv);
+    r = n - q * d;
+    if (r < 0) --q; else if (r >= d) ++q;
+    return q;
+}
+#endif
+
+// ---------------------------------------------------------------------------------------
 // Optional per-launch timing (vtx_profile_start / vtx_profile_stop in core.hip): while profiling is on a launch
 // carries a begin and an end HIP event (hipExtLaunchKernel: the dispatch's own timestamps, what rocprofv3 reports)
 // and its algorithmic FLOPs / HBM bytes are summed per class.  Contraction kernels register one class per

@@ -69,7 +69,7 @@ c_long = _lib.ctypes.c_long
 
 
 _stat_ws = {}
-STAT_WS_FLOATS = 8 * 1024 * 1024
+STAT_WS_FLOATS = 32 * 1024 * 1024      # 128 MB: the epilogue partials [rows / 64 + 4][2][N] of a 1.6 M-row x 256-channel tensor (56 x 56 at 512 images per GPU)
 
 
 def stat_workspace(device):
