@@ -129,6 +129,25 @@ def load_traffic_table(path=None):
     return table, f"{rel} ({t.get('source')}; {t.get('rule')})"
 
 
+BEST_BATCH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "best_batch.json")
+
+
+def load_best_batch():
+    """`config.best_batch`: the per-GPU batch size at which THIS build measured its highest images/sec (tools/round_end.sh runs the
+    same command at 320 / 384 / 512 images per GPU and writes profiles/best_batch.json with the hash of the kernel sources).  The
+    headline stays BASELINE's bs = 256; this key says what the hardware gives when the batch is free.
+    None when the file is missing or was measured on other kernel sources."""
+    try:
+        with open(BEST_BATCH) as fh:
+            b = json.load(fh)
+        from virtex_amd.build import csrc_hash
+        if b.get("csrc_sha256") != csrc_hash():
+            return {"stale": "profiles/best_batch.json was measured on other kernel sources", "batch": b.get("batch"), "value": b.get("value")}
+        return {k: b[k] for k in ("batch", "value", "ms_per_step", "source", "others") if k in b}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def lookup_traffic(table, name, n_classes, launches_per_step):
     """HBM bytes per launch of the kernel the focused pass timed.  A launch family of ONE instantiation: the family's entry.
     A family of several (bn_bwd_apply: the flat kernel at two unrolls, the pooled one): the focused pass timed the largest
@@ -668,6 +687,7 @@ def main(argv=None, device=None, backend=None):
                        "parallelism": f"dp{world}", "final_loss": round(final_loss, 4), "launch": launch_mode,
                        "eager_ms_per_step": (round(eager_ms, 3) if eager_ms is not None else (round(elapsed / a.steps * 1e3, 3) if launch_mode == "eager" else None)),
                        "launch_fallback_reason": launch_fallback,
+                       "best_batch": (load_best_batch() if (world == 1 and not injected) else None),
                        # peak of torch's allocator over the whole run: under launch replay this is the validation's peak (two recordings
                        # of a step pinned at once + an eager step), the steady state holds one recording
                        "peak_memory_gb": (round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2) if dev.type == "cuda" else None),

@@ -62,8 +62,13 @@ FUSE_CONV3_BWD = os.environ.get("VIRTEX_AMD_FUSE_CONV3_BWD", "1") != "0"
 # bn3's backward FOLDED INTO conv3's WEIGHTS for the Bottlenecks the streaming kernel does not take (stages 2-4; csrc/bn_fold.hip):
 # BatchNorm backward is affine per channel and conv3's output is a linear image of conv3's input, so conv3's input gradient and
 # weight gradient can be written with the gradient wrt bn3's OUTPUT, conv3's input and two small matrices -- the pass "read x3,
-# read dz, write dx3" over the block's largest tensors disappears and x3 is not read in backward at all.
-FUSE_BN3_FOLD = os.environ.get("VIRTEX_AMD_BN3_FOLD", "1") != "0"
+# read dz, write dx3" over the block's largest tensors disappears and x3 is not read in backward at all.  Round 6: built, parity
+# green (the folded weight gradient is 15x closer to fp64 than the pass form's), and measured SLOWER: the 12 apply passes it
+# removes cost 0.74 ms per step, the launches it adds 1.59 ms -- on the compute stream the [N][N] matrix H (one or four tiles: a
+# latency-bound 26-us launch) and the [P][N] x [N][N] product (31 us) cost what the passes cost, and the Gram matrix / column sums /
+# fp32 W3 G / combine on the weight-gradient stream are pure additions: 23.03 vs 22.61 ms per step, serial 25.55 vs 24.80
+# (profiles/r06_bn3_fold_rejected.txt).  OFF; kept with its tests as the measured answer.
+FUSE_BN3_FOLD = os.environ.get("VIRTEX_AMD_BN3_FOLD", "0") != "0"
 # the stem convolution's epilogue emits the BatchNorm statistics (streaming kernel, stem.hip)
 STEM_STATS = os.environ.get("VIRTEX_AMD_STEM_STATS", "1") != "0"
 
