@@ -126,6 +126,40 @@ def test_device_augmentation_matches_the_pipeline_restatement(backend, dtype):
     assert torch.equal(packed[:, 3:-3, 3:-3, :3], out[..., :3]) and packed[:, :3].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_crop_window_flip_and_normalize_are_pinned_exactly(backend):
+    """The part of the image pipeline that needs NO third-party arithmetic to define: with a crop window
+    of the output size the bilinear resize is the identity (source coordinate = destination, weight 0), so what remains of
+    albumentations' RandomResizedCrop / CenterCrop -> T.HorizontalFlip (cv2.flip(img, 1): column reversal) -> alb.Normalize
+    (img.astype(float32) - 255 mean) * (1 / (255 std)) (virtex/data/transforms.py:5-35, 85-97, virtex/factories.py:132-154) is
+    exact array arithmetic: window placement to the pixel, the flip, and Normalize to fp32 rounding.  (What stays unpinned until
+    cv2 / albumentations are installable: the fixed-point weights of cv2.resize when the window is NOT the output size, and
+    ColorJitter's uint8 tables -- oracle/augment.py restates their published formulas)"""
+    dev = select(backend)
+    g = torch.Generator().manual_seed(11)
+    N, Hs, Ws, size = 6, 41, 53, 24
+    imgs = torch.randint(0, 256, (N, Hs, Ws, 3), generator=g, dtype=torch.uint8)
+    windows = [(0, 0, size, size), (Ws - size, Hs - size, size, size), (7, 3, size, size), (13, 17, size, size), (29, 0, size, size),
+               vdata.center_crop_window(Hs, Ws, min(Hs, Ws), size)]                  # SmallestMaxSize(short side) = no resize, then CenterCrop
+    assert windows[-1] == ((Ws - size) // 2, (Hs - size) // 2, size, size)          # albumentations' CenterCrop: floor of the half margin
+    flips = [False, True, True, False, True, False]
+    out = vdata.augment_batch(imgs.to(dev), windows, flips, None, size=size, dtype=torch.float32, packed=False)
+    mean = np.array(aug_oracle.MEAN, dtype=np.float32) * np.float32(255.0)
+    inv = np.float32(1.0) / (np.array(aug_oracle.STD, dtype=np.float32) * np.float32(255.0))
+    for n, ((x0, y0, cw, ch), flip) in enumerate(zip(windows, flips)):
+        crop = imgs[n, y0:y0 + ch, x0:x0 + cw].numpy()
+        if flip:
+            crop = crop[:, ::-1]
+        want = (crop.astype(np.float32) - mean) * inv                               # albumentations.augmentations.functional.normalize
+        got = out[n, :, :, :3].cpu().numpy()
+        # the pixel values themselves, exactly (a wrong window or flip is off by whole counts)
+        assert np.array_equal(np.rint(got / inv + mean).astype(np.int64), crop.astype(np.int64)), n
+        assert np.abs(got - want).max() <= 4e-7 * np.abs(want).max() + 1e-7, (n, np.abs(got - want).max())
+    # bf16 output = the fp32 value rounded once
+    out16 = vdata.augment_batch(imgs.to(dev), windows, flips, None, size=size, dtype=torch.bfloat16, packed=False)
+    assert torch.equal(out16[..., :3].cpu(), out[..., :3].cpu().to(torch.bfloat16))
+
+
 def test_crop_and_jitter_samplers_follow_the_reference_defaults():
     rng = random.Random(3)
     areas, ratios = [], []

@@ -17,6 +17,12 @@ cd $R
 [ -n "$SKIP_PMC" ] || python tools/pmc_traffic.py gpurun_out/pmc_fetch.txt gpurun_out/pmc_write.txt --json gpurun_out/traffic_table.json > gpurun_out/pmc_traffic.txt 2>&1
 [ -n "$SKIP_PMC" ] || cp gpurun_out/traffic_table.json profiles/traffic_table.json
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+# round 6: the same command beyond the old 2^24-pixel envelope -> profiles/best_batch.json (bench.py's config.best_batch)
+for B in 320 384 512; do
+  python bench.py --batch $B --no-cpu-baseline --no-roofline > gpurun_out/bench_b$B.json 2> gpurun_out/bench_b$B.err
+done
+python tools/best_batch.py gpurun_out/bench_default.json gpurun_out/bench_b320.json gpurun_out/bench_b384.json gpurun_out/bench_b512.json > gpurun_out/best_batch.json && cp gpurun_out/best_batch.json profiles/best_batch.json
+python bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 10 --warmup 5 | python -c "import sys, json; r = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('config.best_batch as the bench line reports it:', r['config']['best_batch'])" > gpurun_out/best_batch_check.txt 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_kt -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --steps 9 --warmup 3 > $R/gpurun_out/prof_kt.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ks -- python $R/bench.py --no-cpu-baseline --no-fidelity --serial-streams --steps 9 --warmup 3 > $R/gpurun_out/prof_ks.log 2>&1
@@ -42,8 +48,9 @@ for C in 4 5; do
   cp gpurun_out/traffic_table_config$C.json profiles/traffic_table_config$C.json
   rm -rf gpurun_out/prof_fetch$C gpurun_out/prof_write$C
 done
-python bench.py --no-cpu-baseline --no-fidelity $C4 > gpurun_out/bench_config4.json 2> gpurun_out/bench_config4.err
-python bench.py --no-cpu-baseline --no-fidelity $C5 > gpurun_out/bench_config5.json 2> gpurun_out/bench_config5.err
+# (round 6: WITH the fidelity leg -- the bf16 step against the fp32 step on the timed batch of these two configurations)
+python bench.py --no-cpu-baseline $C4 > gpurun_out/bench_config4.json 2> gpurun_out/bench_config4.err
+python bench.py --no-cpu-baseline $C5 > gpurun_out/bench_config5.json 2> gpurun_out/bench_config5.err
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_c4 -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --serial-streams --steps 9 --warmup 3 $C4 > $R/gpurun_out/prof_c4.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_c5 -- python $R/bench.py --no-cpu-baseline --no-fidelity --no-roofline --serial-streams --steps 9 --warmup 3 $C5 > $R/gpurun_out/prof_c5.log 2>&1
@@ -55,8 +62,6 @@ find gpurun_out -name "*.db" -delete; rm -rf gpurun_out/prof_c4 gpurun_out/prof_
 [ -n "$SKIP_STOCK" ] || timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 > gpurun_out/bench_stock_pytorch_baseline.json 2> gpurun_out/bench_stock_pytorch_baseline.err
 [ -n "$SKIP_STOCK" ] || timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 $C4 > gpurun_out/bench_stock_pytorch_baseline_config4.json 2> gpurun_out/bench_stock_pytorch_baseline_config4.err
 [ -n "$SKIP_STOCK" ] || timeout 420 python bench.py --no-cpu-baseline --no-fidelity --no-roofline --stock-pytorch-baseline --steps 20 --warmup 10 $C5 > gpurun_out/bench_stock_pytorch_baseline_config5.json 2> gpurun_out/bench_stock_pytorch_baseline_config5.err
-# round 5: the pre-norm decoder product on the default shape (same step, the other TextualHeadFactory key)
-python bench.py --no-cpu-baseline --no-fidelity --no-roofline --textual transdec_prenorm::L1_H1024_A16_F4096 > gpurun_out/bench_prenorm.json 2> gpurun_out/bench_prenorm.err
 # round 5: the fused conv3 backward against the launches it replaces; JPEG decode throughput of the input pipeline
 timeout 300 python tools/bench_conv3_bwd.py > gpurun_out/conv3_bwd.txt 2>&1
 timeout 300 python tools/bench_jpeg.py > gpurun_out/bench_jpeg.txt 2>&1
