@@ -144,6 +144,18 @@ int vtx_conv3_bwd_fused(int dtype, int M, int K, int N, const void* dz, const vo
                         float* dw_parts, long dw_parts_floats, int* dw_nparts, void* stream);
 int vtx_partials_reduce_acc(const float* ws, int nparts, int M, int N, float* C, long ldc, void* stream);
 
+/* ---- split-K reductions of several weight gradients in ONE launch (csrc/gemm.hip, round 6) ----
+ * vtx_gemm_tn_acc / vtx_conv2d_wgrad with more than one K slice write fp32 partial tiles into the caller's workspace and fold them
+ * into the gradient with a reduce launch each (the reduction half of aten::convolution_backward / aten::mm for the weight
+ * gradients of pretrain_virtex.py:154).  Between vtx_splitk_batch_begin() and vtx_splitk_batch_end(stream) -- same thread, same
+ * stream, same workspace pointer for every call in between -- the workspace is carved into consecutive regions and the reductions
+ * are deferred to ONE launch at _end (or earlier when the workspace is three quarters full / eight are pending): the same sums in
+ * the same order, bit-identical gradients.  The gradients are complete only after _end: call it before anything reads them
+ * (the data-parallel engine's bucket announcement, the optimizer). */
+int vtx_splitk_batch_begin(void);
+int vtx_splitk_batch_flush(void* stream);   /* the pending reductions now; the batch stays open (a result is read inside a batch) */
+int vtx_splitk_batch_end(void* stream);
+
 /* ---- the BatchNorm backward of bn3 folded into conv3's weights (csrc/bn_fold.hip): no pass over the [P][K] tensors ----
  * Same reference operators as above (aten::native_batch_norm_backward of bn3, aten::convolution_backward of the 1x1 conv3 of
  * torchvision's Bottleneck, visual_backbones.py:68-74), for the Bottlenecks the streaming kernel does not take (stages 2-4).

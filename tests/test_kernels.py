@@ -1604,3 +1604,50 @@ def test_convolution_and_pooling_indices_beyond_2_24_pixels_gpu(dtype):
     dxp = ops.maxpool_bwd(dp, arg, x.shape)
     dxh = torch.cat([ops.maxpool_bwd(dp[h1].contiguous(), a1, x[h1].shape), ops.maxpool_bwd(dp[h2].contiguous(), a2, x[h2].shape)])
     assert torch.equal(dxp, dxh)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_splitk_reductions_of_several_weight_gradients_in_one_launch(backend):
+    """ops.splitk_batch (vtx_splitk_batch_begin / _end): the split-K reductions of the contractions issued inside a batch are
+    deferred to ONE launch -- the same sums in the same order, so the gradients are BIT-identical to the immediate form, also
+    for an accumulation onto a non-zero gradient, a contraction that needs no reduction (one slice) in the middle, more than
+    eight pending reductions (the batch flushes itself) and a caller-owned partial buffer (never deferred)."""
+    dev = select(backend)
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(21)
+    shapes = [(640, 64, 96, 5), (512, 128, 64, 4), (384, 32, 200, 1), (768, 96, 32, 6)] + [(256, 16 + 8 * i, 24, 2) for i in range(9)]
+    a = [torch.randn(K, M, generator=g).to(dt).to(dev) for K, M, N, S in shapes]
+    b = [torch.randn(K, N, generator=g).to(dt).to(dev) for K, M, N, S in shapes]
+    init = [torch.randn(M, N, generator=g).to(dev) for K, M, N, S in shapes]
+    x = torch.randn(2, 9, 9, 16, generator=g).to(dt).to(dev); dy = torch.randn(2, 9, 9, 32, generator=g).to(dt).to(dev)
+    parts = torch.randn(3, 24, 16, generator=g).to(dev)
+
+    def run(batched):
+        outs = [t.clone() for t in init]
+        dw = torch.zeros(32, 3, 3, 16, device=dev)
+        pr = torch.ones(24, 16, device=dev)
+        ops.profile_start()
+        sk = ops.splitk_batch(dev)
+        if batched:
+            sk.begin()
+        for (K, M, N, S), ai, bi, o in zip(shapes, a, b, outs):
+            ops.gemm_tn_acc(ai, bi, o, split_k=S)
+        ops.conv2d_wgrad(x, dy, dw, 1, 1, split_k=3)
+        ops.partials_reduce_acc(parts, 3, pr)
+        sk.end()
+        launches = sum(r["launches"] for r in ops.profile_stop() if r["name"].startswith("family:splitk_reduce"))
+        return outs + [dw, pr], launches
+    saved = ops.splitk_batch.enabled
+    try:
+        ops.splitk_batch.enabled = True
+        plain, n_plain = run(False)
+        batch, n_batch = run(True)
+    finally:
+        ops.splitk_batch.enabled = saved
+    for p, q in zip(plain, batch):
+        assert torch.equal(p.cpu(), q.cpu())
+    n_reduced = sum(1 for s in shapes if s[3] > 1) + 1                   # + the convolution's
+    assert n_plain == n_reduced + 1                                        # + the caller-owned partials
+    assert n_batch == 2 + 1, n_batch                                       # 13 deferred = one self-flush at eight + the flush at end(); + the partials
+    ref = init[0].cpu().double() + a[0].double().cpu().t() @ b[0].double().cpu()
+    assert rel_err(batch[0].cpu(), ref) < 1e-5

@@ -1024,6 +1024,7 @@ def test_bn3_backward_folded_into_conv3_in_the_block_schedule(backend, monkeypat
         return out
     plain = run(False)
     assert not calls
+    monkeypatch.setattr(ops.splitk_batch, "enabled", True)              # ... and inside a reduction batch: the fold READS two split-K results
     folded = run(True)
     assert len(calls) == 1                                              # the first block's bn3; the last block has no sums to fold
     worst = ("", 0.0)

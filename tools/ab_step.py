@@ -52,7 +52,8 @@ def main():
     class _Switch:                      # `sw.NAME=v`: vtx_set_switch of the library loaded at that moment; `lib=PATH`: which library
         pass
     default_lib = os.environ.get("VIRTEX_AMD_LIB", _lib.DEFAULT_LIB)
-    mods = {"models": models, "textual": textual_heads}
+    from virtex_amd import ops as _ops
+    mods = {"models": models, "textual": textual_heads, "splitk": _ops.splitk_batch}      # `splitk.enabled=0`: one reduce launch per weight gradient
     variants = []
     for v in a.variants:
         name, _, flags = v.partition(":")

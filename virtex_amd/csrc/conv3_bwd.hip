@@ -39,7 +39,7 @@ extern int g_vtx_sw_conv3_bwd;
 // bn.hip: [compaction +] bn_bwd_finalize of `parts` -> coef[3][C] inside `workspace`, dgamma / dbeta accumulated
 int vtx_bn_bwd_finalize_only(const float* gamma, const float* save_rstd, const float* pre_partials, int pre_nparts, float* dgamma,
                              float* dbeta, float* workspace, int P, int C, hipStream_t st, const float** coef_out);
-void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
+void vtx_splitk_reduce_now(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
 
 #ifndef VTX_CB_ABL
 #define VTX_CB_ABL 0       // measurement builds only (tools/r05_s5.sh): 1 no weight gradient, 2 no input-gradient MFMAs, 4 no epilogue,
@@ -383,7 +383,7 @@ extern "C" int vtx_conv3_bwd_fused(int dtype, int M, int K, int N, const void* d
 // (the split-K reduction of the weight-gradient GEMMs, exported so that the caller can put it on its weight-gradient stream).
 extern "C" int vtx_partials_reduce_acc(const float* ws, int nparts, int M, int N, float* C, long ldc, void* stream) {
     VTX_CHECK(ws && C && nparts > 0 && M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0, VTX_ERR_ARG, "partials_reduce_acc: bad arguments");
-    vtx_splitk_reduce(ws, nparts, M, N, C, ldc, (hipStream_t)stream);
+    vtx_splitk_reduce_now(ws, nparts, M, N, C, ldc, (hipStream_t)stream);     // caller-owned partials: never deferred into a reduction batch
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

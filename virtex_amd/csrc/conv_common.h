@@ -40,3 +40,4 @@ static inline int make_geo(const char* who, int dtype, int N, int H, int W, int 
 int vtx_pick_split_k(int M, int N, int K, int bk, long ws_floats, int gather = 0);
 vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
+float* vtx_splitk_region(float* ws, long ws_floats, long* cap, hipStream_t st);      // gemm.hip: the part of the workspace a contraction may use now

@@ -36,6 +36,7 @@ extern "C" int vtx_conv2d_wgrad(int dtype, int N, int H, int W, int C, int KO, i
     ConvGeo g;
     int rc = make_geo("conv2d_wgrad", dtype, N, H, W, C, KO, R, S, stride, pad, &g);
     if (rc) return rc;
+    workspace = vtx_splitk_region(workspace, workspace ? workspace_floats : 0, &workspace_floats, (hipStream_t)stream);   // inside a reduction batch: the free part
     if (dtype == VTX_BF16 && split_k <= 0) {             // 3x3 / stride 1: the streaming kernel (conv3x3_wgrad.hip)
         const int r = vtx_conv3x3_wgrad_try(N, H, W, C, KO, R, S, stride, pad, x, dy, dw, workspace, workspace_floats, (hipStream_t)stream);
         if (r < 0) return r;

@@ -87,6 +87,7 @@ int vtx_check_bn_bwd(const char* who, const VtxBnBwdFusion* f, int M, int N) {
 
 vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws);
 void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st);
+float* vtx_splitk_region(float* ws, long ws_floats, long* cap, hipStream_t st);
 
 // Split-K policy for the weight-gradient GEMMs: enough slices to give every CU ~2 blocks, never fewer than 8 K-steps per slice, bounded by the workspace
 // ([slices][M][N] fp32 partial sums).
@@ -120,13 +121,12 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4
 // convolutions of stage 1: K = 802,816) would otherwise be a handful of threads walking a serial chain of
 // dependent loads.  Each group sums its slices four loads at a time; LDS folds the groups.
 template <int G>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long MN, int N,
-                                                            float* __restrict__ C, long ldc) {
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ ws, int S, long MN, int N, float* __restrict__ C, long ldc,
+                                                   int block, int nblocks, float4* red) {
     constexpr int COLS = 256 / G;
-    __shared__ float4 red[G > 1 ? 256 : 1];
     const int col = threadIdx.x % COLS, grp = threadIdx.x / COLS;
     const long nv = MN / 4;
-    for (long i0 = (long)blockIdx.x * COLS; i0 < nv; i0 += (long)gridDim.x * COLS) {
+    for (long i0 = (long)block * COLS; i0 < nv; i0 += (long)nblocks * COLS) {
         const long i = i0 + col;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < nv) {
@@ -156,6 +156,70 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
     }
 }
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, long MN, int N,
+                                                            float* __restrict__ C, long ldc) {
+    __shared__ float4 red[G > 1 ? 256 : 1];
+    splitk_reduce_body<G>(ws, S, MN, N, C, ldc, blockIdx.x, gridDim.x, red);
+}
+
+// ---- several reductions in ONE launch (round 6).  The weight gradients of one Bottleneck are three or four split-K
+// contractions, each followed by its own 7-10 us reduce launch (68 per step); between vtx_splitk_batch_begin() and
+// vtx_splitk_batch_end(stream) the library carves the split-K workspace into consecutive regions (every contraction keeps its
+// partial tiles alive) and defers the reductions: ONE launch folds them all -- the same sums in the same order (bit-identical
+// results), block ranges per reduction from a small table passed by value.
+constexpr int VTX_SPLITK_BATCH_MAX = 8;
+struct SplitKBatchEntry { const float* ws; float* C; long MN, ldc; int S, N, G, first_block; };
+struct SplitKBatchArgs { SplitKBatchEntry e[VTX_SPLITK_BATCH_MAX]; int n; };
+__global__ __launch_bounds__(256) void splitk_reduce_batched_kernel(SplitKBatchArgs a) {
+    __shared__ float4 red[256];
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < VTX_SPLITK_BATCH_MAX; ++j)
+        if (j < a.n && (int)blockIdx.x >= a.e[j].first_block) k = j;
+    const SplitKBatchEntry& e = a.e[k];
+    const int nb = (k + 1 < a.n ? a.e[k + 1].first_block : (int)gridDim.x) - e.first_block, b = (int)blockIdx.x - e.first_block;
+    if (e.G == 1) splitk_reduce_body<1>(e.ws, e.S, e.MN, e.N, e.C, e.ldc, b, nb, red);
+    else if (e.G == 4) splitk_reduce_body<4>(e.ws, e.S, e.MN, e.N, e.C, e.ldc, b, nb, red);
+    else splitk_reduce_body<16>(e.ws, e.S, e.MN, e.N, e.C, e.ldc, b, nb, red);
+}
+
+struct SplitKBatchState {
+    bool on = false;
+    float* base = nullptr;       // the workspace the regions are carved from (one per (device, stream): the caller's)
+    long used = 0;               // floats of it that hold partial tiles of pending reductions
+    SplitKBatchArgs args{};
+    double bytes = 0;
+    hipStream_t stream = nullptr; // the stream the pending contractions were issued on: their reduction goes there, whatever happens
+};
+thread_local SplitKBatchState t_batch;
+
+void splitk_plan(long MN, int S, int* G_out, long* blocks_out) {
+    const long nv = MN / 4;
+    // widen over the slices until the launch has ~1k blocks (or the slices run out)
+    int G = 1;
+    while (G < 16 && G * 4 <= S && (nv * G + 255) / 256 < 1024) G *= 4;
+    long g = (nv * G + 255) / 256;
+    if (g > 4096) g = 4096;
+    *G_out = G; *blocks_out = g;
+}
+
+int splitk_batch_flush() {
+    SplitKBatchState& b = t_batch;
+    hipStream_t st = b.stream;
+    if (b.args.n > 0) {
+        int total = 0;
+        for (int j = 0; j < b.args.n; ++j) {
+            int G; long g;
+            splitk_plan(b.args.e[j].MN, b.args.e[j].S, &G, &g);
+            b.args.e[j].G = G; b.args.e[j].first_block = total; total += (int)g;
+        }
+        VTX_KLAUNCH("splitk_reduce", 0, b.bytes, splitk_reduce_batched_kernel, dim3(total), dim3(256), 0, st, b.args);
+    }
+    b.args.n = 0; b.used = 0; b.bytes = 0;
+    VTX_LAUNCH_CHECK();
+    return VTX_OK;
+}
 }  // namespace
 
 vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M, int N, int split_k, float* ws) {
@@ -167,16 +231,61 @@ vtxg::EpiStore<float> vtx_splitk_epilogue(float* C, long ldc, float alpha, int M
     return EpiStore<float>{C, ldc, nullptr, C, ldc, nullptr, ACT_NONE, alpha, make_dropout(0.f, 0), M, N, 0};
 }
 
-void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st) {
-    const long MN = (long)M * N, nv = MN / 4;
-    // widen over the slices until the launch has ~1k blocks (or the slices run out)
-    int G = 1;
-    while (G < 16 && G * 4 <= S && (nv * G + 255) / 256 < 1024) G *= 4;
-    long g = (nv * G + 255) / 256;
-    if (g > 4096) g = 4096;
+void vtx_splitk_reduce_now(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st) {
+    const long MN = (long)M * N;
+    int G; long g;
+    splitk_plan(MN, S, &G, &g);
     if (G == 1) VTX_KLAUNCH("splitk_reduce", 0, 4.0 * MN * (S + 2), splitk_reduce_kernel<1>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
     else if (G == 4) VTX_KLAUNCH("splitk_reduce", 0, 4.0 * MN * (S + 2), splitk_reduce_kernel<4>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
     else VTX_KLAUNCH("splitk_reduce", 0, 4.0 * MN * (S + 2), splitk_reduce_kernel<16>, dim3((int)g), dim3(256), 0, st, ws, S, MN, N, C, ldc);
+}
+
+// Inside a batch (vtx_splitk_batch_begin ... _end) a reduction whose partial tiles sit in the region vtx_splitk_region handed
+// out is DEFERRED to the batch's single launch; anything else (a caller-owned partial buffer that may be freed before the
+// flush: vtx_partials_reduce_acc) runs at once.
+void vtx_splitk_reduce(const float* ws, int S, int M, int N, float* C, long ldc, hipStream_t st) {
+    SplitKBatchState& b = t_batch;
+    const long MN = (long)M * N;
+    if (b.on && b.base && ws == b.base + b.used && MN % 4 == 0) {
+        SplitKBatchEntry& e = b.args.e[b.args.n++];
+        e.ws = ws; e.C = C; e.MN = MN; e.ldc = ldc; e.S = S; e.N = N; e.G = 1; e.first_block = 0;
+        b.used += (((long)S * MN + 1023) / 1024) * 1024;
+        b.bytes += 4.0 * MN * (S + 2);
+        b.stream = st;
+        if (b.args.n == VTX_SPLITK_BATCH_MAX) (void)splitk_batch_flush();
+        return;
+    }
+    vtx_splitk_reduce_now(ws, S, M, N, C, ldc, st);
+}
+
+// The workspace a split-K contraction may use right now: all of it outside a batch; inside one, what the pending reductions
+// leave free (a batch that has eaten three quarters of the workspace is flushed first, so that the slice policy keeps room).
+float* vtx_splitk_region(float* ws, long ws_floats, long* cap, hipStream_t st) {
+    SplitKBatchState& b = t_batch;
+    if (!ws) { *cap = 0; return ws; }
+    if (!b.on) { *cap = ws_floats; return ws; }
+    // another workspace or another stream (a contraction on the branch stream between two on the weight-gradient stream): what is
+    // pending goes out on ITS stream first -- a batch never mixes streams
+    if (b.base != ws || (b.args.n > 0 && b.stream != st)) { (void)splitk_batch_flush(); b.base = ws; }
+    if (ws_floats - b.used < ws_floats / 4) (void)splitk_batch_flush();
+    *cap = ws_floats - b.used;
+    return ws + b.used;
+}
+
+// (a batch that was begun and never ended -- an exception between the two in the caller -- belongs to a step that died: its
+// pending entries are dropped, not launched; batches do not nest)
+extern "C" int vtx_splitk_batch_begin(void) {
+    SplitKBatchState& b = t_batch;
+    b.on = true; b.base = nullptr; b.used = 0; b.args.n = 0; b.bytes = 0; b.stream = nullptr;
+    return VTX_OK;
+}
+// pending reductions NOW, the batch stays open: for a caller that reads a gradient (or any split-K result) in the middle of a batch
+extern "C" int vtx_splitk_batch_flush(void* stream) { (void)stream; return splitk_batch_flush(); }
+extern "C" int vtx_splitk_batch_end(void* stream) {
+    (void)stream;                 // the pending reductions go to the stream their contractions ran on (normally this one)
+    const int rc = splitk_batch_flush();
+    t_batch.on = false; t_batch.base = nullptr;
+    return rc;
 }
 
 extern "C" int vtx_gemm_nt(int dtype, int M, int N, int K, const void* A, long lda, const void* B,
@@ -214,7 +323,8 @@ extern "C" int vtx_gemm_tn_acc(int dtype, int M, int N, int K, const void* A, lo
     VTX_CHECK(aligned16(A) && aligned16(B), VTX_ERR_SHAPE, "gemm_tn_acc: operands must be 16-byte aligned");
     VTX_CHECK(N % 4 == 0 && ldc % 4 == 0 && aligned16(C), VTX_ERR_SHAPE, "gemm_tn_acc: N and ldc must be multiples of 4, C 16-byte aligned");
     if (K == 0) return VTX_OK;
-    const long wsf = workspace ? workspace_floats : 0;
+    long wsf = workspace ? workspace_floats : 0;
+    workspace = vtx_splitk_region(workspace, wsf, &wsf, (hipStream_t)stream);
     if (split_k <= 0) split_k = vtx_pick_split_k(M, N, K, 4 * vec, wsf);
     else {
         const int nkt = vtx_cdiv(K, 4 * vec);

@@ -386,6 +386,9 @@ class _DecoderFn(torch.autograd.Function):
             (Win, bin_, Wo, bo, g1, b1, Win2, bin2, Wo2, bo2, g2, b2, W1, bf1, W2, bf2, g3, b3) = L["P"]
             PP = ctx.layer_params[li]     # the nn.Parameters, same order
             cw, seeds = L["cw"], L["seeds"]
+            # the split-K reductions of this layer's seven weight gradients in one launch (ops.splitk_batch: measured slower, off by
+            # default), issued on the weight-gradient stream at the end of the layer -- before autograd's hooks announce the gradients
+            sk = ops.splitk_batch(dev).begin()
             # ---- FFN block: x3 = LN3(x2 + drop(y3))
             (dg3, rdg3), (db3, rdb3) = sink(PP[16]), sink(PP[17])
             dz3, dy3 = ops.layernorm_residual_bwd(L["x2"], L["y3"], g3, L["m3"], L["r3"], dx, dg3, db3, p, seeds[5])
@@ -429,6 +432,8 @@ class _DecoderFn(torch.autograd.Function):
                               dqkv[:, 2 * H:], B, A, T, T, head.mask_future_positions, ctx.lengths, p, seeds[0])
             dWin, dbin = linear_grads(L["x"], dqkv, PP[0], PP[1])
             dx = ops.gemm_nt(dqkv, cw["Win"][1], residual=dz1)
+            with wgrad_stream(dev):
+                sk.end()
             pgrads = [dWin, dbin, dWo, dbo, rdg1, rdb1, rWin2, rbin2, dWo2, dbo2, rdg2, rdb2, dW1, dbf1, dW2, dbf2,
                       rdg3, rdb3] + pgrads
         if ctx.shared:          # the projection is its own node: hand the memory's gradient back to it

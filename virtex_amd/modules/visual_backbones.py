@@ -571,6 +571,7 @@ def _backward_blocks(rec, blocks, dcur, dt, dev, grads):
             ops.gemm_tn_acc(dz2, a3, t)                                # dz^T a3
             ops.gemm_tn_acc(a3, a3, gram)                              # the Gram matrix of conv3's input
             ops.colsum_acc(a3, csum)
+            ops.splitk_flush(dev)                                      # t and gram are READ below: inside a reduction batch their folds run now
             w32 = u3.conv.weight.detach().permute(0, 2, 3, 1).reshape(K, N)          # the fp32 master (stored (KO,1,1,C): a view)
             wg = ops.gemm_nt(w32, gram)                                # W3 (a3^T a3), fp32 (gram is symmetric)
             ops.wgrad_fold_combine(dw.view(K, N), t, wg, csum, abc)
@@ -583,6 +584,9 @@ def _backward_blocks(rec, blocks, dcur, dt, dev, grads):
     for bi in reversed(range(len(blocks))):
         (u1, u2, u3, ud) = blocks[bi]
         s1, s2, s3 = rec[u1], rec[u2], rec[u3]
+        # the split-K reductions of this block's three or four weight gradients in ONE launch, issued below on the weight-gradient
+        # stream right before the block's gradients are announced (ops.splitk_batch: measured slower, off by default)
+        sk = ops.splitk_batch(dev).begin()
         fused3 = (fuse and FUSE_CONV3_BWD and st3 is not None and u3.is_gemm and u3.cin_pad == u3.cin
                   and s3.wt is not None and ops.conv3_bwd_fused_supported(dcur, s3.wt.view(u3.cin, u3.cout)))
         if s3.a is None and not fused3:
@@ -643,6 +647,8 @@ def _backward_blocks(rec, blocks, dcur, dt, dev, grads):
                                     bn=ops.BnBwd(p3.x, p3.mean, p3.rstd, ymask=p3.y, ybits=p3.bits))
         else:
             dcur, st3 = _conv_dgrad(u1, dx1, s1.wt, s1.a.shape, residual=join), None
+        with wgrad_stream(dev):
+            sk.end()
         # this block's gradient kernels are all enqueued: let the data-parallel engine start exchanging the
         # buckets they complete while the rest of the backbone's backward runs
         for u in (u3, u2, u1, ud):

@@ -4,6 +4,8 @@ Tensors are validated here (device, dtype, contiguity) and handed to the native 
 raw pointers plus the caller's current HIP stream.  Every function allocates its outputs
 with torch (device memory plumbing) and returns them.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -175,7 +177,7 @@ def gemm_nt_bnbwd(a, b, bn: BnBwd, residual=None):
 
 
 _splitk_ws = {}
-SPLITK_WS_FLOATS = 32 * 1024 * 1024      # 128 MB of fp32 partial sums per device
+SPLITK_WS_FLOATS = 64 * 1024 * 1024      # 256 MB of fp32 partial sums per (device, stream): room for the three or four contractions of a reduction batch
 
 
 def splitk_workspace(device):
@@ -188,6 +190,39 @@ def splitk_workspace(device):
         ws = torch.empty(n, dtype=torch.float32, device=device)
         _splitk_ws[key] = ws
     return ws
+
+
+class splitk_batch:
+    """The split-K reductions of the weight-gradient contractions issued between begin() and end() -- on ONE stream, the one
+    end() is called on -- are folded by a single launch at end() (vtx_splitk_batch_begin / _end; csrc/gemm.hip).  The gradients
+    are complete only after end() (ops.splitk_flush in between for a result that is read inside the batch).
+    Round 6: built, bit-identical, 68 -> 23 reduce launches per step -- and measured SLOWER (23.20 vs 23.08 ms per step, serial
+    25.54 vs 25.41; profiles/r06_splitk_batch_rejected.txt): a reduction issued right behind its contraction reads partial tiles
+    that are still in the 256-MB Infinity Cache and re-uses ONE workspace region for every contraction of the step; deferred to
+    the end of the block it reads them from HBM, out of regions that together no longer fit the cache.  OFF by default
+    (VIRTEX_AMD_SPLITK_BATCH=1 turns it on); kept with its test as the measured answer to "get rid of the reduce launches"."""
+    enabled = os.environ.get("VIRTEX_AMD_SPLITK_BATCH", "0") != "0"
+
+    def __init__(self, device):
+        self.device = device
+        self.open = False
+
+    def begin(self):
+        if splitk_batch.enabled and not self.open:
+            call("vtx_splitk_batch_begin")
+            self.open = True
+        return self
+
+    def end(self):
+        if self.open:
+            self.open = False
+            call("vtx_splitk_batch_end", _lib.c_void_p(_lib.current_stream_handle(self.device) if self.device.type == "cuda" else 0))
+
+
+def splitk_flush(device):
+    """Inside a splitk_batch: run the pending reductions now (the results of the split-K contractions issued so far are read
+    by what follows); a no-op outside a batch."""
+    call("vtx_splitk_batch_flush", _lib.c_void_p(_lib.current_stream_handle(device) if device.type == "cuda" else 0))
 
 
 def gemm_tn_acc(a, b, out, alpha=1.0, split_k=0):
