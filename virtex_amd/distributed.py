@@ -73,11 +73,12 @@ def init_process_group(backend: Optional[str] = None) -> int:
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         # A rank that never arrives at a collective must become an ERROR, not an endless wait: every collective of this
-        # process group carries a deadline (default 180 s, VIRTEX_AMD_COLLECTIVE_TIMEOUT_S; torch's own default is 600 s for
-        # nccl and 1800 s for gloo).  With nccl = RCCL the watchdog thread aborts the communicator and raises / tears the
-        # process down with the reason on stderr; gloo raises in the waiting thread.
+        # process group (the rendezvous included) carries an explicit deadline -- 600 s by default, VIRTEX_AMD_COLLECTIVE_TIMEOUT_S
+        # (torch's own defaults: 600 s for nccl, 1800 s for gloo; not shorter by default because the first `import torch` on a
+        # fresh box can take minutes and the ranks do not start together).  With nccl = RCCL the watchdog thread aborts the
+        # communicator and tears the process down with the reason on stderr; gloo raises in the waiting thread.
         import datetime
-        deadline = datetime.timedelta(seconds=float(os.environ.get("VIRTEX_AMD_COLLECTIVE_TIMEOUT_S", "180")))
+        deadline = datetime.timedelta(seconds=float(os.environ.get("VIRTEX_AMD_COLLECTIVE_TIMEOUT_S", "600")))
         dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world, timeout=deadline)
     return local_rank
 
