@@ -32,7 +32,7 @@ def main():
     got = vj.decode_jpeg(blobs[0], dev).cpu().numpy()
     print(f"{a.images} images of 640x480 4:2:0 q90, {sum(map(len, blobs)) / a.images / 1e3:.0f} KB each; bit-exact with Pillow: {np.array_equal(ref, got)}; "
           f"host CPUs {os.cpu_count()}")
-    for threads in (1, 8, 32):
+    for threads in (1, 2, 8, 16, 32):
         vj.decode_jpeg_batch(blobs[:16], dev, threads=threads)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -50,33 +50,73 @@ def decode_jpeg(data: bytes, device, apply_orientation: bool = True) -> torch.Te
     return rgb
 
 
-def decode_jpeg_batch(blobs, device, threads: int = 8, apply_orientation: bool = True) -> List[torch.Tensor]:
-    """Many files at once: the serial Huffman decoding of the images runs on `threads` host threads (the C entry points hold no
-    Python state and ctypes releases the GIL), every image's device work is enqueued on the caller's stream as its coefficients
-    become available.  Returns the uint8 (H, W, 3) tensors in input order."""
+_staging = {}        # device -> [pinned int16 buffer, event recorded after the last copy out of it]: ONE staging area per device, grown on demand
+
+
+def _staging_area(device, n16: int):
+    """A pinned int16 buffer of at least n16 elements, reused from call to call (allocating page-locked memory costs
+    milliseconds).  The previous call's copies out of it must have finished before a new decode writes into it."""
+    ent = _staging.get(device)
+    if ent is not None and ent[1] is not None:
+        ent[1].synchronize()
+    if ent is None or ent[0].numel() < n16:
+        ent = _staging[device] = [torch.empty(max(n16, 1 << 20), dtype=torch.int16, pin_memory=(device.type == "cuda")), None]
+    return ent
+
+
+def decode_jpeg_batch(blobs, device, threads: int = 8, apply_orientation: bool = True, chunk: int = 16) -> List[torch.Tensor]:
+    """Many files at once.  The serial Huffman decoding of the images runs on `threads` host threads (the C entry points hold no
+    Python state and ctypes releases the GIL), each writing its int16 coefficients into ITS slice of one page-locked staging
+    buffer; the main thread follows in input order: as soon as the next `chunk` images are decoded, their slice crosses PCIe in ONE
+    asynchronous copy and the per-image device work (inverse DCT, upsampling, colour conversion: two launches per image, all
+    images sharing one plane scratch in stream order) is enqueued on the caller's stream.  Per image the main thread issues one C
+    call and one small allocation (round 5 allocated page-locked memory and issued two copies per image: 7 400-9 900 images/s
+    whatever the thread count; this form scales with the host threads).  Returns the uint8 (H, W, 3) tensors in input order."""
     from concurrent.futures import ThreadPoolExecutor
     device = torch.device(device)
-    pin = device.type == "cuda"
+    n = len(blobs)
+    if n == 0:
+        return []
+    infos = [jpeg_info(b) for b in blobs]
+    QT = 4 * 64
+    sizes = [i["blocks"] * 64 + QT for i in infos]                       # coefficients, then the four quantisation tables
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + ((sz + 7) // 8) * 8)                       # 16-byte aligned slices
+    stage = _staging_area(device, offs[-1])
+    host = stage[0]
+    base = host.data_ptr()
 
-    def host(data):
-        info = jpeg_info(data)
-        coef = torch.empty(info["blocks"] * 64, dtype=torch.int16, pin_memory=pin)
-        qt = torch.empty(4 * 64, dtype=torch.int16, pin_memory=pin)
-        _lib.call("vtx_jpeg_entropy_decode", ctypes.c_char_p(data), c_long(len(data)), ctypes.c_void_p(coef.data_ptr()),
-                  c_long(coef.numel()), ctypes.c_void_p(qt.data_ptr()))
-        return info, coef, qt
+    def work(i):
+        data = blobs[i]
+        _lib.call("vtx_jpeg_entropy_decode", ctypes.c_char_p(data), c_long(len(data)), ctypes.c_void_p(base + 2 * offs[i]),
+                  c_long(infos[i]["blocks"] * 64), ctypes.c_void_p(base + 2 * (offs[i] + infos[i]["blocks"] * 64)))
+        return i
 
+    dev_all = torch.empty(offs[-1], dtype=torch.int16, device=device)
+    planes = torch.empty(max(i["plane_bytes"] for i in infos), dtype=torch.uint8, device=device)   # shared: the images' kernels run in stream order
     out = []
     with ThreadPoolExecutor(max_workers=max(1, threads)) as pool:
-        for data, (info, coef, qt) in zip(blobs, pool.map(host, blobs)):
-            coef_d, qt_d = coef.to(device, non_blocking=True), qt.to(device, non_blocking=True)
-            planes = torch.empty(info["plane_bytes"], dtype=torch.uint8, device=device)
-            swap = apply_orientation and info["orientation"] >= 5
-            H, W = (info["width"], info["height"]) if swap else (info["height"], info["width"])
-            rgb = torch.empty(H, W, 3, dtype=torch.uint8, device=device)
-            _lib.call("vtx_jpeg_reconstruct", ctypes.c_char_p(data), c_long(len(data)), ptr(coef_d), ptr(qt_d), ptr(planes), ptr(rgb),
-                      c_int(1 if apply_orientation else 0), stream_ptr(rgb))
-            out.append(rgb)
+        done = pool.map(work, range(n))
+        for c0 in range(0, n, chunk):
+            c1 = min(n, c0 + chunk)
+            for _ in range(c0, c1):
+                next(done)                                                # (raises here what a worker raised)
+            dev_all[offs[c0]:offs[c1]].copy_(host[offs[c0]:offs[c1]], non_blocking=True)
+            for i in range(c0, c1):
+                info, data = infos[i], blobs[i]
+                swap = apply_orientation and info["orientation"] >= 5
+                H, W = (info["width"], info["height"]) if swap else (info["height"], info["width"])
+                rgb = torch.empty(H, W, 3, dtype=torch.uint8, device=device)
+                nb = info["blocks"] * 64
+                _lib.call("vtx_jpeg_reconstruct", ctypes.c_char_p(data), c_long(len(data)), ptr(dev_all[offs[i]:offs[i] + nb]),
+                          ptr(dev_all[offs[i] + nb:offs[i] + nb + QT]), ptr(planes), ptr(rgb), c_int(1 if apply_orientation else 0),
+                          stream_ptr(rgb))
+                out.append(rgb)
+    if device.type == "cuda":
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        stage[1] = ev
     return out
 
 
