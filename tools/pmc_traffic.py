@@ -34,6 +34,8 @@ def class_name(kernel):
     if k.startswith("contraction_") or k.startswith("conv3x3_shared_kernel"):
         k = re.sub(r"(, (true|false))+>$", ">", k)            # trailing compile-time flags (LEAN, persistent form)
         return re.sub(r"\s*>\s*$", ">", k).replace(" >", ">")
+    if k.startswith("bn_reduce_kernel"):     # one kernel, two launch families: <T, BWD = true> is the stand-alone BACKWARD reduction
+        return "bn_bwd_reduce" if re.search(r",\s*true\s*>", k) else "bn_fwd_reduce"
     for prefix, fam in FAMILIES:
         if k.startswith(prefix):
             return fam

@@ -38,7 +38,7 @@ __device__ __forceinline__ int st_qdiv(int n, int d) { return vtx_fdiv30(n, d, _
 
 __global__ __launch_bounds__(64 * ST_WAVES, 4) void stem_stream_fwd_kernel(
     const bf16_t* __restrict__ X, const bf16_t* __restrict__ Wt, bf16_t* __restrict__ Y, const float* __restrict__ shift,
-    float* __restrict__ parts, int M, int H, int W, int OH, int OW, int nt_store) {
+    float* __restrict__ parts, int M, int H, int W, int OH, int OW, int nt_store, int xcd_major) {
     HIP_DYNAMIC_SHARED(char, smem)
     bf16_t* wimg = reinterpret_cast<bf16_t*>(smem);                        // [7][64][32] swizzled
     char* strips = smem + (size_t)ST_KH * ST_N * 32 * 2;                   // [ST_WAVES][16][ST_ROWB]
@@ -73,7 +73,13 @@ __global__ __launch_bounds__(64 * ST_WAVES, 4) void stem_stream_fwd_kernel(
         for (int kh = 0; kh < ST_KH; ++kh) f[kh] = *reinterpret_cast<const bf16x8_t*>(p + kh * rowpitch);
     };
     bf16x8_t fa[ST_KH], fn[ST_KH];
+    // Which strips a workgroup walks.  Workgroups are dealt to the eight XCDs round-robin (XCD = blockIdx.x & 7) and every XCD has an
+    // L2 of its own: with strip s on workgroup (s / ST_WAVES) % gridDim.x, vertically adjacent strips -- 7 strips apart, sharing five
+    // of their seven input rows -- sit on different XCDs and every XCD fetched (almost) the whole input: PMC 370 MB for a 108-MB
+    // image tensor (profiles/r05_traffic_ratio.txt, 1.50 x the kernel's algorithmic bytes).  XCD-major order instead: in every round
+    // XCD x owns ONE contiguous band of (gridDim.x / 8) * ST_WAVES strips, so an input row is fetched by one L2 (plus band edges).
     int s = blockIdx.x * ST_WAVES + wave;
+    if (xcd_major && (gridDim.x & 7) == 0) s = ((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) * ST_WAVES + wave;
     if (s < nstrips) load_a(s, fa);
     for (; s < nstrips; s += stride) {
         const bool more = s + stride < nstrips;
@@ -169,7 +175,8 @@ int vtx_stem_stream_try(int N, int H, int W, int C, int KO, int R, int S, int st
     const int nt = (double)M * ST_N * 2 >= 200e6;
     dim3 grid(gx), block(64 * ST_WAVES);
     VTX_KLAUNCH("stem_stream_fwd", 2.0 * M * ST_N * (ST_KH * 32), 2.0 * ((double)N * H * W * 4 + (double)ST_N * ST_KH * 32 + (double)M * ST_N),
-                stem_stream_fwd_kernel, grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, shift, parts, M, H, W, OH, OW, nt);
+                stem_stream_fwd_kernel, grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)y, shift, parts, M, H, W, OH, OW, nt,
+                g_vtx_sw_stem_stream != 2 /* vtx_set_switch("stem_stream", 2): the plain strip order (A/B) */);
     if (hipGetLastError() != hipSuccess) { vtx_set_error("stem_stream_fwd: launch failed"); return VTX_ERR_LAUNCH; }
     return gx;
 }
