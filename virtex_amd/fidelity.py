@@ -51,8 +51,12 @@ def summarize(dist: Dict[str, dict]) -> dict:
         if not rows:
             return None
         rel = sorted(r["rel"] for r in rows)
+        cos = sorted(r["cos"] for r in rows)
+        # min_cos is the single worst tensor: on a chaotic state (randomised BatchNorm, 100+ layers) it moves by several hundredths
+        # under a rounding-level perturbation; p10_cos (the 10th percentile) is the robust low end of the same distribution
         return {"tensors": len(rows), "median_rel": round(rel[len(rel) // 2], 5), "p90_rel": round(rel[int(len(rel) * 0.9)], 5),
-                "max_rel": round(rel[-1], 5), "min_cos": round(min(r["cos"] for r in rows), 5)}
+                "max_rel": round(rel[-1], 5), "min_cos": round(cos[0], 5), "p10_cos": round(cos[int(len(cos) * 0.1)], 5),
+                "median_cos": round(cos[len(cos) // 2], 5)}
     return {"backbone": stats([v for k, v in dist.items() if "cnn" in k]),
             "text": stats([v for k, v in dist.items() if "cnn" not in k])}
 
