@@ -17,6 +17,7 @@
 #include "pool_windows.h"
 
 extern int g_vtx_sw_bn_red_adj;      // vtx_set_switch("bn_red_adj"): stand-alone BatchNorm reductions walk the tensor in interleaved trips
+extern int g_vtx_sw_pool_xcd;        // vtx_set_switch("pool_xcd"): XCD-major block order of the stem's pooling tails
 extern int g_vtx_sw_bn_adj, g_vtx_sw_bn_grid;   // vtx_set_switch("bn_adj" / "bn_grid"): form and grid cap of the flat apply kernels
 extern int g_vtx_sw_bn_fin_wide;     // vtx_set_switch("bn_fin_wide"): 1024-thread finalize / compaction blocks (default off)
 
@@ -501,20 +502,23 @@ template <class T>
 __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(
     const T* __restrict__ x, const T* __restrict__ dpool, const uint8_t* __restrict__ argmax, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ coef, const float* __restrict__ gamma, const float* __restrict__ beta,
-    T* __restrict__ dx, int N, int H, int W, int C, int OH, int OW) {
+    T* __restrict__ dx, int N, int H, int W, int C, int OH, int OW, int xcd_major) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC;
     const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
     const long total = (long)N * QH * QW * cv;
+    // XCD-major block order (vtx_common.h): the pixel quads of neighbouring blocks share pooling windows and argmax rows.  Only where
+    // a block covers whole channel-vector groups (256 % cv == 0), so that a thread's channel vector does not depend on the block
+    const int blk = (xcd_major && 256 % cv == 0) ? vtx_xcd_major_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     // gridDim.x * 256 is a multiple of cv (apply_grid): a thread keeps its channel vector, coefficients live in registers
-    const int c0 = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cv) * VEC;
+    const int c0 = (int)(((long)blk * 256 + threadIdx.x) % cv) * VEC;
     float mu[VEC], rs[VEC], ga[VEC], be[VEC], k0[VEC], k1[VEC], k2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         mu[j] = mean[c0 + j]; rs[j] = rstd[c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
         k0[j] = coef[c0 + j]; k1[j] = coef[C + c0 + j]; k2[j] = coef[2 * C + c0 + j];
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int q = (int)(i / cv);
         const int n = bnpool_qdiv(q, QH * QW), rem = q - n * QH * QW;
         const int qa = bnpool_qdiv(rem, QW), qb = rem - qa * QW;
@@ -548,7 +552,7 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                                   const float* __restrict__ scale, const float* __restrict__ beta,
                                                                   T* __restrict__ y, uint8_t* __restrict__ argmax, int N, int H, int W,
-                                                                  int C, int OH, int OW, int TX) {
+                                                                  int C, int OH, int OW, int TX, int xcd_major) {
     constexpr int VEC = Elem<T>::VEC;
     const int cv = C / VEC, TY = 256 / TX;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -558,7 +562,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const T* __res
     float mu[VEC], sc[VEC], be[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { mu[j] = mean[c0 + j]; sc[j] = scale[c0 + j]; be[j] = beta[c0 + j]; }
-    for (int p = blockIdx.x * TY + ty; p < P; p += gridDim.x * TY) {
+    // (pooling windows of vertically / horizontally adjacent output pixels overlap: with consecutive blocks on consecutive XCDs the
+    //  input was fetched 1.5 x -- 621 MB for 411 MB, PMC; in XCD-major order the overlaps meet in one L2)
+    const int blk = (xcd_major && gridDim.y == 1) ? vtx_xcd_major_block((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    for (int p = blk * TY + ty; p < P; p += gridDim.x * TY) {
         const int n = bnpool_qdiv(p, OH * OW), rem = p - n * OH * OW;
         const int oh = bnpool_qdiv(rem, OW), ow = rem - oh * OW;
         float best[VEC]; int idx[VEC];
@@ -878,10 +885,10 @@ extern "C" int vtx_bn_bwd_maxpool(int dtype, const void* x, const void* dpool, c
     const long nvec = (long)NQ * C / vec;
     if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<bf16_t>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const bf16_t*)x,
-                    (const bf16_t*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (bf16_t*)dx, N, H, W, C, OH, OW);
+                    (const bf16_t*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (bf16_t*)dx, N, H, W, C, OH, OW, g_vtx_sw_pool_xcd);
     else
         VTX_KLAUNCH("bn_bwd_apply", 0, 2.0 * el * P * C + pool_bytes, (pool_bn_bwd_apply_kernel<float>), dim3(apply_grid(nvec, C / vec)), dim3(256), 0, st, (const float*)x,
-                    (const float*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (float*)dx, N, H, W, C, OH, OW);
+                    (const float*)dpool, argmax, save_mean, save_rstd, coef, gamma, beta, (float*)dx, N, H, W, C, OH, OW, g_vtx_sw_pool_xcd);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }
@@ -935,10 +942,10 @@ extern "C" int vtx_bn_fwd_maxpool(int dtype, const void* x, const float* gamma, 
     const double el = dtype == VTX_BF16 ? 2.0 : 4.0;
     if (dtype == VTX_BF16)
         VTX_KLAUNCH("bn_fwd_apply", 0, el * P * C + (el + 1.0) * N * OH * OW * C, (bn_relu_maxpool_fwd_kernel<bf16_t>), dim3((int)gx, gy), dim3(256), 0, st,
-                    (const bf16_t*)x, save_mean, scale, beta, (bf16_t*)pooled, argmax, N, H, W, C, OH, OW, TX);
+                    (const bf16_t*)x, save_mean, scale, beta, (bf16_t*)pooled, argmax, N, H, W, C, OH, OW, TX, g_vtx_sw_pool_xcd);
     else
         VTX_KLAUNCH("bn_fwd_apply", 0, el * P * C + (el + 1.0) * N * OH * OW * C, (bn_relu_maxpool_fwd_kernel<float>), dim3((int)gx, gy), dim3(256), 0, st,
-                    (const float*)x, save_mean, scale, beta, (float*)pooled, argmax, N, H, W, C, OH, OW, TX);
+                    (const float*)x, save_mean, scale, beta, (float*)pooled, argmax, N, H, W, C, OH, OW, TX, g_vtx_sw_pool_xcd);
     VTX_LAUNCH_CHECK();
     return VTX_OK;
 }

@@ -40,6 +40,13 @@ static inline int vtx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // VTX_PIXEL_LIMIT is what the host entry points check.
 // ---------------------------------------------------------------------------------------
 constexpr long VTX_PIXEL_LIMIT = 1L << 30;
+// Workgroups are dealt to the eight XCDs round-robin (XCD = block index & 7) and every XCD has an L2 of its own.  A kernel whose
+// NEIGHBOURING blocks read overlapping data (pooling windows, convolution strips) should therefore give each XCD a CONTIGUOUS
+// range of its work: logical block = (b & 7) * (g / 8) + (b >> 3) for a grid of g blocks (g % 8 == 0; otherwise the plain order).
+// Measured on the stem's streaming kernel: 370 -> 118 MB fetched per launch for a 108-MB input (profiles/r06_stem_xcd_order.txt).
+#if defined(__HIPCC__) || defined(HIPEMU)
+__device__ __forceinline__ int vtx_xcd_major_block(int b, int g) { return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3); }
+#endif
 #if defined(__HIPCC__) || defined(HIPEMU)
 __device__ __forceinline__ int vtx_fdiv30(int n, int d, float inv) {
     int q = (int)((float)n * inv);
