@@ -66,7 +66,7 @@ namespace vtxg { int g_vtx_sw_stats_tile = getenv("VIRTEX_AMD_STATS_TILE") ? ato
 int g_vtx_sw_bn_red_adj = getenv("VIRTEX_AMD_BN_RED_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_RED_ADJ")) : 0;   // stand-alone BatchNorm reductions in interleaved trips: measured neutral (step 23.96 vs 23.94, kernel time 25.78 vs 25.71 ms: profiles/r04_ab_bn_red_adj.txt) -> off, the summation order of rounds 1-3 stays
 int g_vtx_sw_bn_adj = getenv("VIRTEX_AMD_BN_ADJ") ? atoi(getenv("VIRTEX_AMD_BN_ADJ")) : 1;      // flat BatchNorm apply kernels: adjacent vectors per trip
 int g_vtx_sw_bn_grid = getenv("VIRTEX_AMD_BN_GRID") ? atoi(getenv("VIRTEX_AMD_BN_GRID")) : 8192;  // ... and their grid cap
-int g_vtx_sw_pool_xcd = getenv("VIRTEX_AMD_POOL_XCD") ? atoi(getenv("VIRTEX_AMD_POOL_XCD")) : 0;   // the stem's pooling tails walk their pixels in XCD-major block order (vtx_xcd_major_block): overlapping windows of neighbouring blocks meet in ONE L2.  Measured (profiles/r06_pool_xcd_order.txt): fetch 621 -> 412 MB (forward tail, = its input exactly) and 728 -> 569 MB (backward apply) per launch, and NOT faster -- 242-276 vs 220-234 us per forward call, step 22.85 vs 22.80 ms: the re-fetched windows were Infinity-Cache hits, and eight contiguous streams spread over the HBM channels no better than one interleaved one.  Off
+int g_vtx_sw_pool_xcd = getenv("VIRTEX_AMD_POOL_XCD") ? atoi(getenv("VIRTEX_AMD_POOL_XCD")) : 0;   // the stem's pooling tails walk their pixels in XCD-major block order (vtx_xcd_major_block): overlapping windows of neighbouring blocks meet in ONE L2.  Measured (profiles/r06_pool_xcd_order.txt): fetch 621 -> 412 MB (forward tail, = its input exactly) and 728 -> 569 MB (backward apply) per launch, and NOT faster -- 242-276 vs 220-234 us per forward call, step 22.85 vs 22.80 ms (consistent with the re-fetched windows having been Infinity-Cache hits).  Off
 namespace vtxg { int g_vtx_sw_conv3x3_shared = getenv("VIRTEX_AMD_CONV3X3_SHARED") ? atoi(getenv("VIRTEX_AMD_CONV3X3_SHARED")) : 1; }   // conv3x3_kernel.h
 namespace vtxg { int g_vtx_sw_tile64x256 = getenv("VIRTEX_AMD_TILE64X256") ? atoi(getenv("VIRTEX_AMD_TILE64X256")) : 1; }   // launch_auto: the stem's weight gradient on one 64x256 tile
 namespace vtxg { int g_vtx_sw_gen3 = getenv("VIRTEX_AMD_GEN3") ? atoi(getenv("VIRTEX_AMD_GEN3")) : 80; }   // generation-3 contraction kernels (gemm_v3.h): 0 forced only, n >= 2: taken when the cost model predicts n % of the generation-2 class rate (step A/B: 80 -> 24.26, 100 -> 24.46, off 24.65 ms/step)
