@@ -749,6 +749,7 @@ def main(argv=None, device=None, backend=None):
                 rec["stock_pytorch_baseline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(rec), flush=True)
     vd.synchronize()
+    vd.shutdown()
 
 
 if __name__ == "__main__":

@@ -83,6 +83,13 @@ def init_process_group(backend: Optional[str] = None) -> int:
     return local_rank
 
 
+def shutdown():
+    """Tear the process group down (what torch asks for before the interpreter exits: a communicator left alive can leak its
+    proxy threads or stall the exit of a multi-rank job)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def ranks_seen(device=None) -> int:
     """All-reduce (SUM) of a one: how many ranks the process group's transport really connects.  1 without a group."""
     if not active():
