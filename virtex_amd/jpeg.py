@@ -11,6 +11,7 @@ kernels do not take (progressive, CMYK, ...) raises VtxError -- convert such fil
 import ctypes
 import json
 import os
+import threading
 import unicodedata
 from collections import defaultdict
 from typing import Dict, List, Tuple
@@ -51,6 +52,7 @@ def decode_jpeg(data: bytes, device, apply_orientation: bool = True) -> torch.Te
 
 
 _staging = {}        # device -> [pinned int16 buffer, event recorded after the last copy out of it]: ONE staging area per device, grown on demand
+_staging_lock = threading.Lock()      # ... used by one decode_jpeg_batch call at a time (calls from several threads take turns)
 
 
 def _staging_area(device, n16: int):
@@ -72,11 +74,16 @@ def decode_jpeg_batch(blobs, device, threads: int = 8, apply_orientation: bool =
     images sharing one plane scratch in stream order) is enqueued on the caller's stream.  Per image the main thread issues one C
     call and one small allocation (round 5 allocated page-locked memory and issued two copies per image: 7 400-9 900 images/s
     whatever the thread count; this form scales with the host threads).  Returns the uint8 (H, W, 3) tensors in input order."""
-    from concurrent.futures import ThreadPoolExecutor
     device = torch.device(device)
-    n = len(blobs)
-    if n == 0:
+    if len(blobs) == 0:
         return []
+    with _staging_lock:
+        return _decode_jpeg_batch(blobs, device, threads, apply_orientation, chunk)
+
+
+def _decode_jpeg_batch(blobs, device, threads, apply_orientation, chunk):
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(blobs)
     infos = [jpeg_info(b) for b in blobs]
     QT = 4 * 64
     sizes = [i["blocks"] * 64 + QT for i in infos]                       # coefficients, then the four quantisation tables
