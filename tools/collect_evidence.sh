@@ -5,7 +5,7 @@ set -e
 R=${1:?round prefix, e.g. r06}
 cd "$(dirname "$0")/.."
 G=gpurun_out
-for f in bench_default bench_serial bench_config4 bench_config5 bench_b256 bench_b320 bench_b384 bench_b512 bench_stock_pytorch_baseline bench_stock_pytorch_baseline_config4 bench_stock_pytorch_baseline_config5; do
+for f in bench_default bench_serial bench_config4 bench_config5 bench_b256 bench_b320 bench_b384 bench_b512 bench_b768 bench_b1024 bench_stock_pytorch_baseline bench_stock_pytorch_baseline_config4 bench_stock_pytorch_baseline_config5; do
   [ -s $G/$f.json ] && grep -h '^{' $G/$f.json | tail -1 > profiles/${R}_$f.json
 done
 for f in gpu_tests smoke kernel_stats kernel_stats_serial kernel_stats_serial_config4 kernel_stats_serial_config5 pmc_traffic pmc_traffic_config4 pmc_traffic_config5 bench_jpeg conv3_bwd; do

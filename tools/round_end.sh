@@ -17,10 +17,10 @@ cd $R
 [ -n "$SKIP_PMC" ] || python tools/pmc_traffic.py gpurun_out/pmc_fetch.txt gpurun_out/pmc_write.txt --json gpurun_out/traffic_table.json > gpurun_out/pmc_traffic.txt 2>&1
 [ -n "$SKIP_PMC" ] || cp gpurun_out/traffic_table.json profiles/traffic_table.json
 # round 6: the same command beyond the old 2^24-pixel envelope -> profiles/best_batch.json (bench.py's config.best_batch)
-for B in 256 320 384 512; do
+for B in 256 320 384 512 768 1024; do
   python bench.py --batch $B --no-cpu-baseline --no-roofline > gpurun_out/bench_b$B.json 2> gpurun_out/bench_b$B.err
 done
-python tools/best_batch.py gpurun_out/bench_b256.json gpurun_out/bench_b320.json gpurun_out/bench_b384.json gpurun_out/bench_b512.json > gpurun_out/best_batch.json && cp gpurun_out/best_batch.json profiles/best_batch.json
+python tools/best_batch.py gpurun_out/bench_b256.json gpurun_out/bench_b320.json gpurun_out/bench_b384.json gpurun_out/bench_b512.json gpurun_out/bench_b768.json gpurun_out/bench_b1024.json > gpurun_out/best_batch.json && cp gpurun_out/best_batch.json profiles/best_batch.json
 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 python bench.py --no-cpu-baseline --no-roofline --no-fidelity --steps 10 --warmup 5 | python -c "import sys, json; r = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('config.best_batch as the bench line reports it:', r['config']['best_batch'])" > gpurun_out/best_batch_check.txt 2>&1
 cd /tmp
