@@ -130,3 +130,44 @@ def test_gradient_buckets_match_averaged_gradients():
         assert differs > 0                                           # it really went through bf16
     for r in range(world):
         assert outs[r][2] == {"a": pytest.approx(0.5), "b": pytest.approx(2.0)}
+
+
+def _deadline_worker(rank, world, port, q):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), VIRTEX_AMD_COLLECTIVE_TIMEOUT_S="4")
+    from virtex_amd import distributed as vd
+
+    vd.init_process_group("gloo")
+    assert vd.ranks_seen() == world                      # everybody arrives: the transport connects `world` ranks
+    if rank == 1:
+        time.sleep(25)                                   # ... and now rank 1 never arrives at the next collective
+        q.put((rank, "slept", 25.0))
+        return
+    t0 = time.time()
+    try:
+        vd.ranks_seen()
+        q.put((rank, "no error", time.time() - t0))
+    except Exception as e:                               # gloo raises in the waiting thread (nccl: the watchdog tears the process down)
+        q.put((rank, type(e).__name__, time.time() - t0))
+
+
+def test_a_rank_that_never_arrives_is_an_error_not_a_hang():
+    """Every collective of the process group carries the deadline of init_process_group (VIRTEX_AMD_COLLECTIVE_TIMEOUT_S):
+    when a peer never reaches a collective, the waiting rank fails after the deadline instead of waiting for ever -- what lets
+    a multi-GPU bench run end with an error the driver can read.  `ranks_seen` (an all-reduce of
+    ones) is the record's "did the transport connect N ranks" answer."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_deadline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, what, dt = q.get(timeout=120)
+        got[r] = (what, dt)
+    for p in procs:
+        p.join(timeout=60)
+    assert got[0][0] != "no error", got
+    assert got[0][1] < 20.0, got                         # the 4-s deadline, not rank 1's 25-s nap
