@@ -83,6 +83,30 @@ __global__ __launch_bounds__(256) void weight_prep_batched_kernel(const VtxPrepD
     T* w = (T*)d.w;
     T* wt = (T*)d.wt;
     __shared__ float tile[32][33];
+    // Interior tiles of unpadded, 4-aligned matrices (all but the stem's and the last tile row of the 10 000-row tied matrix): ONE
+    // 16-byte load and one or two 8-byte (bf16) / 16-byte (fp32) stores per thread -- the scalar form below moved the same tile
+    // with 4-byte loads and 2-byte stores, four of each per thread, and ran at 3.0 TB/s (round 6: the launch sits at the very
+    // start of the step, on the critical path).
+    const bool vec = k0 + 32 <= d.KO && c0 + 32 <= d.C && d.C == d.Cp && (d.C & 3) == 0 && (d.KO & 3) == 0 &&
+                     (((uintptr_t)w32 | (uintptr_t)w | (uintptr_t)wt) & 15) == 0;
+    if (vec) {
+        const int r = threadIdx.x >> 3, q = (threadIdx.x & 7) * 4;           // row of the tile, first of this thread's four columns
+        const float4 v = *reinterpret_cast<const float4*>(w32 + ((long)(k0 + r) * d.T + t) * d.C + c0 + q);
+        tile[r][q] = v.x; tile[r][q + 1] = v.y; tile[r][q + 2] = v.z; tile[r][q + 3] = v.w;
+        if (w) {
+            T* dst = w + ((long)(k0 + r) * d.T + t) * d.Cp + c0 + q;
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(f2bf2(v.x, v.y), f2bf2(v.z, v.w));
+            else *reinterpret_cast<float4*>(dst) = v;
+        }
+        __syncthreads();
+        if (wt) {                                                           // row r of the transposed tile = channel c0 + r, four ko
+            T* dst = wt + ((long)(c0 + r) * d.T + t) * d.KO + k0 + q;
+            const float a0 = tile[q][r], a1 = tile[q + 1][r], a2 = tile[q + 2][r], a3 = tile[q + 3][r];
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(dst) = make_uint2(f2bf2(a0, a1), f2bf2(a2, a3));
+            else *reinterpret_cast<float4*>(dst) = make_float4(a0, a1, a2, a3);
+        }
+        return;
+    }
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
         const int ko = k0 + r, c = c0 + tx;
