@@ -58,18 +58,34 @@ __global__ __launch_bounds__(256) void sgd_lookahead_kernel(
         const float coef = max_norm / (total + 1e-6f);
         gs *= coef < 1.f ? coef : 1.f;
     }
+    auto update = [&](float& pv, float gv, float& mv, float& sv) {          // one element; sv is touched on Lookahead steps only
+        gv = gv * gs + wd * pv;
+        mv = momentum * mv + gv;
+        pv -= lr * mv;
+        if (do_lookahead) { sv = sv + alpha * (pv - sv); pv = sv; }
+    };
+    if (((off | len) & 3) == 0) {
+        // 16-byte accesses (every chunk of the model qualifies: parameter sizes are multiples of 4): a quarter of the memory
+        // instructions of the scalar loop below, same arithmetic per element
+        float4* p4 = reinterpret_cast<float4*>(p + off); const float4* g4 = reinterpret_cast<const float4*>(g + off);
+        float4* m4 = reinterpret_cast<float4*>(m + off); float4* s4 = reinterpret_cast<float4*>(slow + off);
+        for (int i = threadIdx.x; i < len / 4; i += 256) {
+            float4 pv = p4[i], mv = m4[i];
+            const float4 gv = g4[i];
+            float4 sv = do_lookahead ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            update(pv.x, gv.x, mv.x, sv.x); update(pv.y, gv.y, mv.y, sv.y); update(pv.z, gv.z, mv.z, sv.z); update(pv.w, gv.w, mv.w, sv.w);
+            m4[i] = mv;
+            if (do_lookahead) s4[i] = sv;
+            p4[i] = pv;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < len; i += 256) {
         const long k = off + i;
-        float pv = p[k];
-        const float gv = g[k] * gs + wd * pv;
-        const float mv = momentum * m[k] + gv;
+        float pv = p[k], mv = m[k], sv = do_lookahead ? slow[k] : 0.f;
+        update(pv, g[k], mv, sv);
         m[k] = mv;
-        pv -= lr * mv;
-        if (do_lookahead) {
-            const float sv = slow[k] + alpha * (pv - slow[k]);
-            slow[k] = sv;
-            pv = sv;
-        }
+        if (do_lookahead) slow[k] = sv;
         p[k] = pv;
     }
 }
